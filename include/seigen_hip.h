@@ -1,0 +1,194 @@
+/*
+ * seigen_hip.h - C-ABI of libseigen_hip.so: the MI355X (gfx950) replacement for
+ * the per-timestep hot path of devitocodes/seigen.
+ *
+ * Every entry point below replaces something Firedrake/PyOP2 generate or run
+ * for `seigen/elastic.py` (paths relative to the reference checkout).  The
+ * host side (seigen_amd/elastic.py) binds these with ctypes; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (streams and
+ *     device buffers cross as void*).
+ *   - every call returns SG_OK (0) or a negative error code; the message is
+ *     available from sg_last_error().
+ *   - one host thread drives a handle.  The handle owns its device memory;
+ *     host buffers are caller-owned and copied synchronously.
+ *   - there is NO CPU fallback: sg_create fails if no HIP device is usable.
+ *
+ * Host field layout = the reference's `Function.dat.data` layout [upstream]:
+ *   velocity  [cell][node][dim]        (VectorFunctionSpace, elastic.py:82)
+ *   stress    [cell][node][dim][dim]   (TensorFunctionSpace, elastic.py:81)
+ * cells ordered cube-major (x fastest) / simplex-class-minor, nodes on the
+ * equispaced lattice ordered with the first reference coordinate fastest
+ * (see DESIGN.md "Mesh and numbering").
+ */
+#ifndef SEIGEN_HIP_H
+#define SEIGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_OK 0
+#define SG_ERR_ARG (-1)      /* bad argument */
+#define SG_ERR_DEVICE (-2)   /* HIP runtime error / no device */
+#define SG_ERR_STATE (-3)    /* call sequence error (e.g. params not set) */
+#define SG_ERR_NOMEM (-4)
+
+/* device-resident fields.  The ten Functions of elastic.py:93-103 map onto
+ * four buffers because the fused stages never materialise uh2 / sh2 and
+ * u0.assign(u1) / s0.assign(s1) (elastic.py:296,304) are in-place updates. */
+enum sg_field {
+  SG_FIELD_U = 0,  /* VelocityOld / VelocityNew   (u0, u1)      */
+  SG_FIELD_UH = 1, /* VelocityHalf1 / VelocityTemp (uh1, utemp) */
+  SG_FIELD_S = 2,  /* StressOld / StressNew       (s0, s1)      */
+  SG_FIELD_SH = 3  /* StressTemp / StressHalf1    (stemp, sh1)  */
+};
+
+/* the six fused launches of one LF4 step (elastic.py:291-304) */
+enum sg_stage {
+  SG_STAGE_UH1 = 0,   /* uh1   = Minv f(s0; u0)                          :292 */
+  SG_STAGE_STEMP = 1, /* stemp = Minv g(uh1)                              :293 */
+  SG_STAGE_U1 = 2,    /* u1 = rho*u0 + dt*uh1 + dt^3/24 * Minv f(stemp; u0); u0<-u1   :294-296 */
+  SG_STAGE_SH1 = 3,   /* sh1   = Minv g(u1)                               :300 */
+  SG_STAGE_UTEMP = 4, /* utemp = Minv f(sh1; u1)                          :301 */
+  SG_STAGE_S1 = 5     /* s1 = s0 + dt*sh1 + dt^3/24 * Minv g(utemp); s0<-s1           :302-304 */
+};
+
+/* which cubes of the block a stage launch covers (halo overlap) */
+enum sg_region {
+  SG_REGION_ALL = 0,
+  SG_REGION_INTERIOR = 1, /* cubes whose stencil needs no remote trace */
+  SG_REGION_BOUNDARY = 2  /* the one-cube shell next to sides that have a neighbour block */
+};
+
+typedef struct sg_handle sg_handle;
+
+typedef struct sg_config {
+  int32_t dim;       /* 1, 2 or 3          (ElasticLF4.create(..., dimension), elastic.py:28) */
+  int32_t degree;    /* 1..4               (ElasticLF4.create(..., degree)) */
+  int32_t n[3];      /* squares / cubes per axis in THIS block */
+  double h[3];       /* cell size per axis */
+  double origin[3];  /* physical coordinate of the block's low corner */
+  int32_t diagonal;  /* 2-D only: 0 = "left" (Firedrake default), 1 = "right" */
+  int32_t nbr_mask;  /* bit (2*axis + side) set: that side touches another block (halo), else free surface */
+  int32_t device;    /* HIP device ordinal */
+  void* stream;      /* hipStream_t to launch on, or NULL for the handle's own stream */
+} sg_config;
+
+typedef struct sg_info {
+  int32_t dim, degree;
+  int32_t nd;        /* scalar nodes per cell */
+  int32_t nf;        /* nodes per facet */
+  int32_t nfaces;    /* facets per cell */
+  int32_t nclasses;  /* simplices per square / cube */
+  int64_t ncells;
+  int64_t u_dofs;    /* dim   * nd * ncells */
+  int64_t s_dofs;    /* dim^2 * nd * ncells */
+  int32_t halo_faces[6]; /* cell-facets lying on each block side (2*axis+side) */
+} sg_info_t;
+
+typedef struct sg_counters {
+  double kernel_ms[6];   /* accumulated device time per stage (hipEvent), only when timing is enabled */
+  int64_t launches[6];
+  int64_t steps;
+} sg_counters_t;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+/* replaces: function-space/field construction (elastic.py:66-103) and
+ * ExplicitElasticLF4.setup (elastic.py:369-385: element-wise inverse mass). */
+int sg_create(const sg_config* cfg, sg_handle** out);
+void sg_destroy(sg_handle* h);
+const char* sg_last_error(const sg_handle* h); /* h may be NULL: error of the last failed sg_create */
+int sg_get_info(const sg_handle* h, sg_info_t* out);
+int sg_sync(sg_handle* h);
+
+/* physical coordinates of the DG nodes, [cell][node][dim]; `degree` may differ
+ * from the solver's (e.g. 4 for the DG4 sponge space of
+ * tests/explosive_source/explosive_source_lf4.py:43).  Replaces what
+ * Function.interpolate(Expression) needs from the mesh (elastic.py:141,154). */
+int sg_node_coords(const sg_handle* h, int degree, double* out, size_t nbytes);
+/* the same from a configuration alone (device-free; cfg->device / stream ignored) */
+int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t nbytes);
+
+/* ---- parameters (plain attributes density, dt, mu, l: eigenmode_2d.py:17-20) ------- */
+/* per_cell = 0: lambda/mu point to one value each; 1: one value per cell
+ * (build-defined heterogeneous extension). */
+int sg_set_params(sg_handle* h, double density, double dt, const double* lambda, const double* mu, int per_cell);
+
+/* ---- field transfer (u0.assign(...), s0.assign(...): eigenmode_2d.py:32,36) -------- */
+int sg_set_field(sg_handle* h, int field, const double* host, size_t nbytes);
+int sg_get_field(sg_handle* h, int field, double* host, size_t nbytes);
+
+/* ---- absorption (elastic.py:136-141, :207-208) ------------------------------------ */
+/* sigma_nodes: [cell][nd(sigma_degree)] nodal values of the DG_q sponge field, or NULL to disable. */
+int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree);
+
+/* ---- source (elastic.py:149-154, :217-218, :285-288) ------------------------------- */
+/* Sparse nodal source: `nnz` scalar DG nodes (flat index = cell*nd + node) carry a
+ * source; values[k][i][dim*dim] is the nodal S_ij of entry i during step k
+ * (k = 0 .. nsteps-1 counted from this call; no source afterwards).  This is the
+ * re-interpolated `source_function` of elastic.py:285-288 restricted to its
+ * support.  nnz = 0 disables. */
+int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+/* whole steps (all six stages, source included); replaces the body of
+ * ElasticLF4.run's while-loop (elastic.py:283-313). */
+int sg_step(sg_handle* h, int64_t nsteps);
+/* one fused stage over a region (multi-block overlap and stage-level tests). */
+int sg_run_stage(sg_handle* h, int stage, int region);
+/* advance the source-amplitude index after a manually staged step */
+int sg_end_step(sg_handle* h);
+
+/* un-fused operators for stage-level parity tests:
+ *   out = Minv f(w; s_in, u_abs)   (elastic.py:204-209 + :358-367)
+ *   out = Minv g(v; u_in)          (elastic.py:211-219 + :358-367)
+ * `use_source` adds the current step's source to g. */
+int sg_apply_F(sg_handle* h, int s_in, int u_abs, int u_out);
+int sg_apply_G(sg_handle* h, int u_in, int s_out, int use_source);
+
+/* ---- halo layer (replaces PyOP2's implicit halo exchange, elastic.py:404-436) ------- */
+/* Facet traces of `field` on block side `side` (2*axis + hi), packed as
+ * [facet][facet-node][comp] with comp = dim (velocity) or dim*dim (stress),
+ * written to the DEVICE buffer `dev_out` (caller-allocated, e.g. a torch tensor). */
+int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes);
+int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out);
+/* register the DEVICE buffer holding the neighbour block's packed traces of
+ * `field` for `side`; read by the next stages that consume `field`. */
+int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in);
+
+/* ---- instrumentation --------------------------------------------------------------- */
+int sg_enable_timing(sg_handle* h, int on);
+int sg_get_counters(sg_handle* h, sg_counters_t* out);
+/* ms of the last sg_step call measured with hipEvents on the launch stream */
+int sg_last_step_ms(sg_handle* h, double* ms);
+
+/* ---- device-free setup queries (host logic; usable without a GPU) ------------------------ */
+/* Reference-element operators of equispaced Lagrange P_degree on the dim-simplex
+ * (what `assemble(..., inverse=True)`, elastic.py:376-382, and the generated
+ * element kernels tabulate [upstream]).  which = 0: D[r][a][b] = (Mhat^-1 Shat_r)
+ * (dim*nd*nd), 1: L[f][a][b'] facet lifts (nfaces*nd*nf), 2: Mhat (nd*nd),
+ * 3: sponge tensor A[a][c][b] for a DG_q sigma (nd*nq*nd), 4: facet node lists
+ * fnode[f][b'] as doubles (nfaces*nf).  out = NULL: size query.
+ * Returns the number of doubles or a negative error. */
+int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out, size_t nbytes);
+/* phi[p][a]: Lagrange basis of P_degree (degree <= 8) at reference points xi[p][dim] - the
+ * tabulation behind Function evaluation / the error functional of eigenmode_2d.py:49-63. */
+int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi);
+/* Translation-invariant neighbour tables of the structured simplicial mesh:
+ * nb [cls][face][5] = {axis crossed (-1: same cube), direction, neighbour class,
+ * neighbour facet, ordinal on the cube side}; nb_node [cls][face][nf] neighbour
+ * element node matching each facet node; cn [cls][face][3] = |F|/|detJ| * outward
+ * normal; jinv [cls][3][3]. */
+int sg_mesh_tables(int dim, int degree, int diagonal, const double* h, int32_t* nb, int32_t* nb_node, double* cn,
+                   double* jinv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEIGEN_HIP_H */

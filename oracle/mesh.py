@@ -1,0 +1,178 @@
+"""Simplicial meshes with EXPLICIT connectivity.  ORACLE (test infrastructure).
+
+[upstream] ``UnitSquareMesh(N, N)`` / ``RectangleMesh(nx, ny, Lx, Ly)``
+(``tests/eigenmode/eigenmode_2d.py:11``, ``tests/explosive_source/
+explosive_source_lf4.py:10``) are nx*ny squares each cut into two triangles by
+one fixed diagonal; ``UnitCubeMesh(N, N, N)`` (``eigenmode_3d.py:11``) is N^3
+cubes each cut into six tetrahedra that share the cube's main diagonal (Kuhn /
+Freudenthal split); ``IntervalMesh`` is n equal intervals.
+
+The cell ORDER (cube-major with x fastest, class-minor) and the local vertex
+order are this build's documented convention so fields can be compared array
+to array with the HIP path; everything else here (facets, neighbours, normals)
+is derived from vertex ids and coordinates with no structured-mesh shortcut.
+"""
+import itertools
+import numpy as np
+from . import refelem
+
+# local vertex offsets (in units of cells) of the simplex classes inside one
+# square / cube.  2-D "left" = Firedrake's default diagonal (from (i,j+1) to
+# (i+1,j)); "right" = the (i,j)-(i+1,j+1) diagonal.
+CLASSES_1D = [[(0,), (1,)]]
+CLASSES_2D = {
+    "left": [[(0, 0), (1, 0), (0, 1)], [(1, 1), (0, 1), (1, 0)]],
+    "right": [[(0, 0), (1, 0), (1, 1)], [(0, 0), (1, 1), (0, 1)]],
+}
+
+
+def kuhn_classes():
+    out = []
+    for perm in itertools.permutations(range(3)):
+        v = [np.zeros(3, dtype=int)]
+        for ax in perm:
+            w = v[-1].copy()
+            w[ax] += 1
+            v.append(w)
+        out.append([tuple(int(c) for c in w) for w in v])
+    return out
+
+
+CLASSES_3D = kuhn_classes()
+
+
+def class_table(dim, diagonal="left"):
+    if dim == 1:
+        return CLASSES_1D
+    if dim == 2:
+        return CLASSES_2D[diagonal]
+    return CLASSES_3D
+
+
+class Mesh(object):
+    """vertices [nv, dim]; cells [nc, dim+1] vertex ids."""
+
+    def __init__(self, vertices, cells):
+        self.vertices = np.asarray(vertices, dtype=np.float64)
+        self.cells = np.asarray(cells, dtype=np.int64)
+        self.dim = self.vertices.shape[1]
+        self.ncells = len(self.cells)
+        self._geometry()
+        self._facets()
+
+    def _geometry(self):
+        d = self.dim
+        X = self.vertices[self.cells]              # [nc, d+1, d]
+        self.v0 = X[:, 0, :]
+        # J[:, i, m] = d x_i / d xi_m
+        self.J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))
+        self.detJ = np.linalg.det(self.J)
+        self.Jinv = np.linalg.inv(self.J)          # [nc, m, i] = d xi_m / d x_i
+
+    def _facets(self):
+        d = self.dim
+        table = {}
+        for c in range(self.ncells):
+            for f in range(d + 1):
+                key = tuple(sorted(int(self.cells[c, v]) for v in refelem.face_vertices(d, f)))
+                table.setdefault(key, []).append((c, f))
+        interior, exterior = [], []
+        for key in sorted(table):
+            ent = table[key]
+            if len(ent) == 2:
+                interior.append((ent[0][0], ent[0][1], ent[1][0], ent[1][1]))
+            elif len(ent) == 1:
+                exterior.append(ent[0])
+            else:
+                raise RuntimeError("non-manifold facet")
+        self.interior_facets = np.array(interior, dtype=np.int64).reshape(-1, 4)
+        self.exterior_facets = np.array(exterior, dtype=np.int64).reshape(-1, 2)
+
+    def facet_geometry(self, cell, f):
+        """Outward unit normal and measure of local face f of the given cells
+        (arrays), computed from vertex coordinates."""
+        d = self.dim
+        cell = np.asarray(cell)
+        f = np.asarray(f)
+        n = np.empty((len(cell), d))
+        area = np.empty(len(cell))
+        for ff in range(d + 1):
+            sel = np.nonzero(f == ff)[0]
+            if len(sel) == 0:
+                continue
+            fv = refelem.face_vertices(d, ff)
+            X = self.vertices[self.cells[cell[sel]]]      # [n, d+1, d]
+            P0 = X[:, fv[0], :]
+            opp = X[:, ff, :]
+            if d == 1:
+                nn = np.ones((len(sel), 1))
+                ar = np.ones(len(sel))
+            elif d == 2:
+                t = X[:, fv[1], :] - P0
+                ar = np.linalg.norm(t, axis=1)
+                nn = np.stack([t[:, 1], -t[:, 0]], axis=1) / ar[:, None]
+            else:
+                t1 = X[:, fv[1], :] - P0
+                t2 = X[:, fv[2], :] - P0
+                cr = np.cross(t1, t2)
+                nrm = np.linalg.norm(cr, axis=1)
+                ar = 0.5 * nrm
+                nn = cr / nrm[:, None]
+            # orient away from the opposite vertex
+            sgn = np.sign(np.einsum('ij,ij->i', nn, P0 - opp))
+            n[sel] = nn * sgn[:, None]
+            area[sel] = ar
+        return n, area
+
+    def node_coords(self, P):
+        """[nc, nd, dim] physical coordinates of the DG nodes."""
+        xi = refelem.node_ref_coords(self.dim, P)           # [nd, d]
+        return self.v0[:, None, :] + np.einsum('cim,am->cai', self.J, xi)
+
+
+def structured(dim, n, L, diagonal="left", origin=None):
+    """n = cells per axis (tuple), L = extents (tuple)."""
+    n = tuple(int(x) for x in n)
+    L = tuple(float(x) for x in L)
+    origin = (0.0,) * dim if origin is None else tuple(origin)
+    classes = class_table(dim, diagonal)
+    nvx = [k + 1 for k in n]
+    # vertex id with x fastest
+    strides = [1]
+    for a in range(1, dim):
+        strides.append(strides[-1] * nvx[a - 1])
+    grids = np.meshgrid(*[np.arange(k) for k in nvx], indexing='ij')
+    nv = int(np.prod(nvx))
+    vertices = np.zeros((nv, dim))
+    ids = sum(g * s for g, s in zip(grids, strides)).ravel()
+    for a in range(dim):
+        # multiply before divide, as a plain "i*L/n" lattice
+        vertices[ids, a] = origin[a] + grids[a].ravel() * (L[a] / n[a])
+    cells = []
+    # cube order: x fastest
+    ranges = [range(k) for k in reversed(n)]
+    for rev in itertools.product(*ranges):
+        idx = tuple(reversed(rev))
+        for cl in classes:
+            cells.append([sum((idx[a] + off[a]) * strides[a] for a in range(dim)) for off in cl])
+    return Mesh(vertices, cells)
+
+
+def UnitSquareMesh(nx, ny, diagonal="left"):
+    return structured(2, (nx, ny), (1.0, 1.0), diagonal)
+
+
+def RectangleMesh(nx, ny, Lx, Ly, diagonal="left"):
+    return structured(2, (nx, ny), (Lx, Ly), diagonal)
+
+
+def UnitCubeMesh(nx, ny, nz):
+    return structured(3, (nx, ny, nz), (1.0, 1.0, 1.0))
+
+
+def BoxMesh(nx, ny, nz, Lx, Ly, Lz):
+    return structured(3, (nx, ny, nz), (Lx, Ly, Lz))
+
+
+def IntervalMesh(n, L):
+    return structured(1, (n,), (L,))

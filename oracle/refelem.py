@@ -1,0 +1,141 @@
+"""Reference simplex: equispaced Lagrange P_k basis and collapsed Gauss-Jacobi
+quadrature.  ORACLE (test infrastructure) - see oracle/__init__.py.
+
+[upstream] Firedrake ``FunctionSpace(mesh, "DG", k)`` on simplices is FIAT's
+DiscontinuousLagrange: the nodal basis of P_k at the principal (equispaced)
+lattice.  The reference selects it at ``seigen/elastic.py:81-82``.  The node
+ORDER inside a cell is this build's own convention (lattice-lexicographic,
+first reference coordinate fastest); the discrete function is independent of it.
+"""
+import itertools
+import numpy as np
+from scipy.special import roots_jacobi
+
+
+def lattice(dim, P):
+    """Integer lattice points alpha (|alpha| <= P) of the P_k simplex,
+    ordered with alpha_1 fastest.  Node coordinates are alpha / P."""
+    pts = []
+    if dim == 1:
+        pts = [(a,) for a in range(P + 1)]
+    elif dim == 2:
+        pts = [(a1, a2) for a2 in range(P + 1) for a1 in range(P + 1 - a2)]
+    elif dim == 3:
+        pts = [(a1, a2, a3) for a3 in range(P + 1) for a2 in range(P + 1 - a3)
+               for a1 in range(P + 1 - a3 - a2)]
+    else:
+        raise ValueError("dim must be 1, 2 or 3")
+    return np.array(pts, dtype=np.int64)
+
+
+def nnodes(dim, P):
+    return len(lattice(dim, P))
+
+
+def _psi(n, P, lam):
+    """psi_n(lam) = prod_{s<n} (P lam - s)/(n - s) and its derivative."""
+    val = np.ones_like(lam)
+    der = np.zeros_like(lam)
+    for s in range(n):
+        f = (P * lam - s) / (n - s)
+        df = P / (n - s)
+        der = der * f + val * df
+        val = val * f
+    return val, der
+
+
+def tabulate(dim, P, xi):
+    """Lagrange basis at reference points xi [npts, dim].
+
+    Closed form on the principal lattice: phi_alpha(lambda) =
+    prod_m psi_{alpha_m}(lambda_m) with barycentrics lambda_0 = 1 - sum xi,
+    lambda_m = xi_m and alpha_0 = P - |alpha|.
+    Returns phi [npts, nd] and dphi [npts, nd, dim] (d/dxi)."""
+    xi = np.atleast_2d(np.asarray(xi, dtype=np.float64))
+    npts = xi.shape[0]
+    lat = lattice(dim, P)
+    nd = len(lat)
+    lam = np.empty((npts, dim + 1))
+    lam[:, 0] = 1.0 - xi.sum(axis=1)
+    lam[:, 1:] = xi
+    # psi tables: val[m][n], der[m][n]
+    val = [[None] * (P + 1) for _ in range(dim + 1)]
+    der = [[None] * (P + 1) for _ in range(dim + 1)]
+    for m in range(dim + 1):
+        for n in range(P + 1):
+            val[m][n], der[m][n] = _psi(n, P, lam[:, m])
+    phi = np.empty((npts, nd))
+    dphi = np.empty((npts, nd, dim))
+    for a, al in enumerate(lat):
+        full = (P - int(al.sum()),) + tuple(int(x) for x in al)
+        v = np.ones(npts)
+        for m in range(dim + 1):
+            v = v * val[m][full[m]]
+        phi[:, a] = v
+        # d/dlambda_m
+        dl = []
+        for m in range(dim + 1):
+            t = der[m][full[m]].copy()
+            for m2 in range(dim + 1):
+                if m2 != m:
+                    t = t * val[m2][full[m2]]
+            dl.append(t)
+        for r in range(dim):
+            dphi[:, a, r] = dl[r + 1] - dl[0]
+    return phi, dphi
+
+
+def _gj01(n, alpha):
+    """n-point Gauss-Jacobi rule on [0,1] for weight (1-t)^alpha."""
+    x, w = roots_jacobi(n, alpha, 0.0)
+    return 0.5 * (x + 1.0), w / 2.0 ** (alpha + 1)
+
+
+def simplex_quadrature(dim, degree):
+    """Collapsed (Stroud conical) Gauss-Jacobi rule on the unit simplex exact
+    for polynomials of total degree <= ``degree``.  [upstream] FIAT's
+    ``create_quadrature`` of that era builds the same family with
+    m = ceil((degree+1)/2) points per direction.
+    Returns points [nq, dim], weights [nq] (weights sum to 1/dim!)."""
+    m = max(1, (degree + 2) // 2)
+    if dim == 0:
+        return np.zeros((1, 0)), np.ones(1)
+    if dim == 1:
+        t, w = _gj01(m, 0.0)
+        return t[:, None], w
+    if dim == 2:
+        u, wu = _gj01(m, 1.0)
+        s, ws = _gj01(m, 0.0)
+        pts = np.array([(ui, (1 - ui) * sj) for ui in u for sj in s])
+        wts = np.array([wi * wj for wi in wu for wj in ws])
+        return pts, wts
+    if dim == 3:
+        u, wu = _gj01(m, 2.0)
+        s, ws = _gj01(m, 1.0)
+        r, wr = _gj01(m, 0.0)
+        pts = np.array([(ui, (1 - ui) * sj, (1 - ui) * (1 - sj) * rk)
+                        for ui in u for sj in s for rk in r])
+        wts = np.array([wi * wj * wk for wi in wu for wj in ws for wk in wr])
+        return pts, wts
+    raise ValueError(dim)
+
+
+def face_vertices(dim, f):
+    """Local vertex numbers of face f (the facet opposite vertex f)."""
+    return [v for v in range(dim + 1) if v != f]
+
+
+def face_nodes(dim, P, f):
+    """Element-node indices lying on face f (barycentric lambda_f == 0), in
+    increasing element-node order."""
+    lat = lattice(dim, P)
+    lam0 = P - lat.sum(axis=1)
+    if f == 0:
+        mask = lam0 == 0
+    else:
+        mask = lat[:, f - 1] == 0
+    return np.nonzero(mask)[0]
+
+
+def node_ref_coords(dim, P):
+    return lattice(dim, P).astype(np.float64) / P

@@ -1,0 +1,145 @@
+"""Thin object wrapper around one `sg_handle` (one mesh block on one GPU)."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import SgConfig, SgInfo, SgCounters, check
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HipBlock(object):
+    def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None):
+        self.lib = _lib.load()
+        cfg = SgConfig()
+        cfg.dim, cfg.degree = dim, degree
+        for a in range(3):
+            cfg.n[a] = int(n[a]) if a < dim else 1
+            cfg.h[a] = float(h[a]) if a < dim else 1.0
+            cfg.origin[a] = float(origin[a]) if a < dim else 0.0
+        cfg.diagonal = 1 if diagonal == "right" else 0
+        cfg.nbr_mask = int(nbr_mask)
+        cfg.device = int(device)
+        cfg.stream = C.c_void_p(stream) if stream else None
+        hp = C.c_void_p()
+        rc = self.lib.sg_create(C.byref(cfg), C.byref(hp))
+        if rc != 0:
+            raise _lib.SeigenHipError("sg_create failed (%d): %s" %
+                                      (rc, (self.lib.sg_last_error(None) or b"").decode()))
+        self.h = hp
+        info = SgInfo()
+        check(self.lib.sg_get_info(self.h, C.byref(info)), self.h)
+        self.dim, self.degree = dim, degree
+        self.nd, self.nf, self.nfaces, self.ncls = info.nd, info.nf, info.nfaces, info.nclasses
+        self.ncells = int(info.ncells)
+        self.u_dofs, self.s_dofs = int(info.u_dofs), int(info.s_dofs)
+        self.halo_faces = [int(x) for x in info.halo_faces]
+        self.nbr_mask = int(nbr_mask)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- shapes ---------------------------------------------------------------------
+    def field_shape(self, field):
+        d = self.dim
+        if field in (_lib.FIELD_S, _lib.FIELD_SH):
+            return (self.ncells, self.nd, d, d)
+        return (self.ncells, self.nd, d)
+
+    def node_coords(self, degree=None):
+        degree = self.degree if degree is None else int(degree)
+        nq = {1: degree + 1, 2: (degree + 1) * (degree + 2) // 2,
+              3: (degree + 1) * (degree + 2) * (degree + 3) // 6}[self.dim]
+        out = np.empty((self.ncells, nq, self.dim))
+        check(self.lib.sg_node_coords(self.h, degree, out.ctypes.data, out.nbytes), self.h)
+        return out
+
+    # ---- data -------------------------------------------------------------------------
+    def set_field(self, field, arr):
+        arr = _f64(arr).reshape(self.field_shape(field))
+        check(self.lib.sg_set_field(self.h, field, arr.ctypes.data, arr.nbytes), self.h)
+
+    def get_field(self, field):
+        out = np.empty(self.field_shape(field))
+        check(self.lib.sg_get_field(self.h, field, out.ctypes.data, out.nbytes), self.h)
+        return out
+
+    def set_params(self, density, dt, lam, mu):
+        lam_a, mu_a = _f64(np.atleast_1d(lam)).ravel(), _f64(np.atleast_1d(mu)).ravel()
+        per_cell = int(lam_a.size > 1 or mu_a.size > 1)
+        if per_cell:
+            lam_a = _f64(np.broadcast_to(lam_a, (self.ncells,)))
+            mu_a = _f64(np.broadcast_to(mu_a, (self.ncells,)))
+        check(self.lib.sg_set_params(self.h, float(density), float(dt), lam_a.ctypes.data, mu_a.ctypes.data,
+                                     per_cell), self.h)
+
+    def set_absorption(self, sigma_nodes, sigma_degree):
+        if sigma_nodes is None:
+            check(self.lib.sg_set_absorption(self.h, None, 0), self.h)
+            return
+        s = _f64(sigma_nodes).reshape(self.ncells, -1)
+        check(self.lib.sg_set_absorption(self.h, s.ctypes.data, int(sigma_degree)), self.h)
+
+    def set_source(self, nodes, values):
+        """nodes: flat scalar node indices [nnz]; values [nsteps, nnz, d, d]."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64).ravel()
+        if nodes.size == 0 or values is None or len(values) == 0:
+            check(self.lib.sg_set_source(self.h, 0, None, 0, None), self.h)
+            return
+        values = _f64(values).reshape(-1, nodes.size, self.dim, self.dim)
+        check(self.lib.sg_set_source(self.h, nodes.size, nodes.ctypes.data, values.shape[0],
+                                     values.ctypes.data), self.h)
+
+    # ---- hot path ---------------------------------------------------------------------
+    def step(self, nsteps=1):
+        check(self.lib.sg_step(self.h, int(nsteps)), self.h)
+
+    def run_stage(self, stage, region=_lib.REGION_ALL):
+        check(self.lib.sg_run_stage(self.h, int(stage), int(region)), self.h)
+
+    def end_step(self):
+        check(self.lib.sg_end_step(self.h), self.h)
+
+    def apply_F(self, s_in, u_abs, u_out):
+        check(self.lib.sg_apply_F(self.h, s_in, u_abs, u_out), self.h)
+
+    def apply_G(self, u_in, s_out, use_source=False):
+        check(self.lib.sg_apply_G(self.h, u_in, s_out, int(use_source)), self.h)
+
+    def sync(self):
+        check(self.lib.sg_sync(self.h), self.h)
+
+    def last_step_ms(self):
+        ms = C.c_double()
+        check(self.lib.sg_last_step_ms(self.h, C.byref(ms)), self.h)
+        return ms.value
+
+    def enable_timing(self, on=True):
+        check(self.lib.sg_enable_timing(self.h, int(on)), self.h)
+
+    def counters(self):
+        c = SgCounters()
+        check(self.lib.sg_get_counters(self.h, C.byref(c)), self.h)
+        return dict(kernel_ms=list(c.kernel_ms), launches=list(c.launches), steps=int(c.steps))
+
+    # ---- halo ---------------------------------------------------------------------------
+    def halo_bytes(self, field, side):
+        nb = C.c_size_t()
+        check(self.lib.sg_halo_bytes(self.h, field, side, C.byref(nb)), self.h)
+        return nb.value
+
+    def halo_pack(self, field, side, dev_ptr):
+        check(self.lib.sg_halo_pack(self.h, field, side, C.c_void_p(dev_ptr)), self.h)
+
+    def halo_attach(self, field, side, dev_ptr):
+        check(self.lib.sg_halo_attach(self.h, field, side, C.c_void_p(dev_ptr)), self.h)

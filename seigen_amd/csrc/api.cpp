@@ -1,0 +1,700 @@
+// C-ABI of libseigen_hip.so (see include/seigen_hip.h).  Host-side driver of the
+// HIP stage kernels: owns device memory, the fused six-launch LF4 step
+// (seigen/elastic.py:283-313) and the facet-trace halo buffers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/seigen_hip.h"
+#include "kernels.hpp"
+#include "mesh_tables.hpp"
+#include "refelem.hpp"
+
+using namespace sg;
+
+struct sg_handle {
+  sg_config cfg;
+  RefElem re;
+  MeshDev md;
+  MeshDev* md_dev = nullptr;
+  double* Dt = nullptr;
+  double* Lt = nullptr;
+  double* field[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t field_len[4] = {0, 0, 0, 0};  // doubles
+  int64_t ncells = 0;
+  int ncls = 0;
+  // parameters
+  bool params_set = false;
+  double rho = 1.0, dt = 0.0, lam0 = 0.0, mu0 = 0.0;
+  int per_cell = 0;
+  double* lam_d = nullptr;
+  double* mu_d = nullptr;
+  // sponge
+  int32_t* sponge_slot = nullptr;
+  double* sponge_B = nullptr;
+  // source
+  int64_t src_nnz = 0;
+  int64_t* src_nodes = nullptr;
+  double* src_values = nullptr;  // [nsteps][nnz][dim*dim]
+  int64_t src_nsteps = 0;
+  int64_t src_step = 0;
+  // halo
+  const double* ghost[4][6];
+  // execution
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  bool timing = false;
+  sg_counters_t counters;
+  std::string err;
+};
+
+static std::string g_create_err;
+
+#define HIPCHECK(h, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                              \
+      return SG_ERR_DEVICE;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+static int fail(sg_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+static bool field_is_stress(int f) { return f == SG_FIELD_S || f == SG_FIELD_SH; }
+
+extern "C" {
+
+const char* sg_last_error(const sg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+void sg_destroy(sg_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int f = 0; f < 4; ++f)
+    if (h->field[f]) (void)hipFree(h->field[f]);
+  if (h->md_dev) (void)hipFree(h->md_dev);
+  if (h->Dt) (void)hipFree(h->Dt);
+  if (h->Lt) (void)hipFree(h->Lt);
+  if (h->lam_d) (void)hipFree(h->lam_d);
+  if (h->mu_d) (void)hipFree(h->mu_d);
+  if (h->sponge_slot) (void)hipFree(h->sponge_slot);
+  if (h->sponge_B) (void)hipFree(h->sponge_B);
+  if (h->src_nodes) (void)hipFree(h->src_nodes);
+  if (h->src_values) (void)hipFree(h->src_values);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int create_impl(const sg_config* cfg, sg_handle* h) {
+  if (cfg->dim < 1 || cfg->dim > 3) return fail(h, SG_ERR_ARG, "dim must be 1, 2 or 3");
+  if (cfg->degree < 1 || cfg->degree > 4) return fail(h, SG_ERR_ARG, "degree must be 1..4");
+  for (int a = 0; a < cfg->dim; ++a) {
+    if (cfg->n[a] < 1) return fail(h, SG_ERR_ARG, "n[axis] must be >= 1");
+    if (!(cfg->h[a] > 0.0)) return fail(h, SG_ERR_ARG, "h[axis] must be > 0");
+  }
+  h->cfg = *cfg;
+  for (int a = cfg->dim; a < 3; ++a) {
+    h->cfg.n[a] = 1;
+    h->cfg.h[a] = 1.0;
+    h->cfg.origin[a] = 0.0;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(h, SG_ERR_DEVICE, "no HIP device available (libseigen_hip has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(h, SG_ERR_ARG, "device ordinal out of range");
+  HIPCHECK(h, hipSetDevice(cfg->device));
+
+  try {
+    h->re = make_refelem(cfg->dim, cfg->degree);
+    std::memset(&h->md, 0, sizeof(MeshDev));
+    h->md.nd = h->re.nd;
+    h->md.nf = h->re.nf;
+    build_mesh_tables(cfg->dim, cfg->degree, cfg->diagonal, h->cfg.h, h->re.fnode.data(), h->re.lattice.data(), h->md);
+  } catch (const std::exception& e) {
+    return fail(h, SG_ERR_ARG, e.what());
+  }
+  for (int a = 0; a < 3; ++a) h->md.n[a] = h->cfg.n[a];
+  for (int s = 0; s < 6; ++s) h->md.has_nbr[s] = (s < 2 * cfg->dim) ? ((cfg->nbr_mask >> s) & 1) : 0;
+  h->ncls = h->md.ncls;
+  h->ncells = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2] * h->ncls;
+  for (int f = 0; f < 4; ++f)
+    for (int s = 0; s < 6; ++s) h->ghost[f][s] = nullptr;
+  std::memset(&h->counters, 0, sizeof(h->counters));
+
+  const int d = cfg->dim, nd = h->re.nd, nf = h->re.nf, nfaces = h->re.nfaces;
+  // transposed operators: Dt[r][b][a], Lt[f][b'][a]
+  std::vector<double> Dt((size_t)d * nd * nd), Lt((size_t)nfaces * nf * nd);
+  for (int r = 0; r < d; ++r)
+    for (int a = 0; a < nd; ++a)
+      for (int b = 0; b < nd; ++b) Dt[((size_t)r * nd + b) * nd + a] = h->re.D[((size_t)r * nd + a) * nd + b];
+  for (int f = 0; f < nfaces; ++f)
+    for (int a = 0; a < nd; ++a)
+      for (int b = 0; b < nf; ++b) Lt[((size_t)f * nf + b) * nd + a] = h->re.L[((size_t)f * nd + a) * nf + b];
+  HIPCHECK(h, hipMalloc((void**)&h->Dt, Dt.size() * sizeof(double)));
+  HIPCHECK(h, hipMalloc((void**)&h->Lt, Lt.size() * sizeof(double)));
+  HIPCHECK(h, hipMalloc((void**)&h->md_dev, sizeof(MeshDev)));
+  HIPCHECK(h, hipMemcpy(h->Dt, Dt.data(), Dt.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHECK(h, hipMemcpy(h->Lt, Lt.data(), Lt.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHECK(h, hipMemcpy(h->md_dev, &h->md, sizeof(MeshDev), hipMemcpyHostToDevice));
+
+  for (int f = 0; f < 4; ++f) {
+    size_t comps = field_is_stress(f) ? (size_t)d * d : (size_t)d;
+    h->field_len[f] = (size_t)h->ncells * nd * comps;
+    if (hipMalloc((void**)&h->field[f], h->field_len[f] * sizeof(double)) != hipSuccess)
+      return fail(h, SG_ERR_NOMEM, "hipMalloc of a field buffer failed");
+    HIPCHECK(h, hipMemset(h->field[f], 0, h->field_len[f] * sizeof(double)));
+  }
+  if (cfg->stream) {
+    h->stream = (hipStream_t)cfg->stream;
+  } else {
+    HIPCHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  HIPCHECK(h, hipEventCreate(&h->ev0));
+  HIPCHECK(h, hipEventCreate(&h->ev1));
+  HIPCHECK(h, hipDeviceSynchronize());
+  return SG_OK;
+}
+
+int sg_create(const sg_config* cfg, sg_handle** out) {
+  if (!cfg || !out) {
+    g_create_err = "null argument";
+    return SG_ERR_ARG;
+  }
+  *out = nullptr;
+  sg_handle* h = new sg_handle();
+  int rc = create_impl(cfg, h);
+  if (rc != SG_OK) {
+    g_create_err = h->err;
+    sg_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SG_OK;
+}
+
+int sg_get_info(const sg_handle* h, sg_info_t* out) {
+  if (!h || !out) return SG_ERR_ARG;
+  const int d = h->cfg.dim;
+  out->dim = d;
+  out->degree = h->cfg.degree;
+  out->nd = h->re.nd;
+  out->nf = h->re.nf;
+  out->nfaces = h->re.nfaces;
+  out->nclasses = h->ncls;
+  out->ncells = h->ncells;
+  out->u_dofs = (int64_t)d * h->re.nd * h->ncells;
+  out->s_dofs = (int64_t)d * d * h->re.nd * h->ncells;
+  for (int s = 0; s < 6; ++s) {
+    int axis = s >> 1;
+    if (axis >= d) {
+      out->halo_faces[s] = 0;
+      continue;
+    }
+    int64_t n2 = 1;
+    for (int a = 0; a < 3; ++a)
+      if (a != axis) n2 *= h->cfg.n[a];
+    out->halo_faces[s] = (int32_t)(n2 * h->md.halo_per_cube);
+  }
+  return SG_OK;
+}
+
+int sg_sync(sg_handle* h) {
+  if (!h) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  return SG_OK;
+}
+
+int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t nbytes) {
+  if (!cfg || !out || degree < 1 || degree > 8 || cfg->dim < 1 || cfg->dim > 3) return SG_ERR_ARG;
+  const int d = cfg->dim;
+  std::vector<int> lat;
+  lattice_points(d, degree, lat);
+  const int nq = num_nodes(d, degree);
+  int off[MAX_CLS][4][3], ncls;
+  class_vertices(d, cfg->diagonal, ncls, off);
+  int n[3] = {1, 1, 1};
+  for (int a = 0; a < d; ++a) n[a] = cfg->n[a];
+  if (nbytes != (size_t)n[0] * n[1] * n[2] * ncls * nq * d * sizeof(double)) return SG_ERR_ARG;
+  size_t o = 0;
+  for (int ck = 0; ck < n[2]; ++ck)
+    for (int cj = 0; cj < n[1]; ++cj)
+      for (int ci = 0; ci < n[0]; ++ci) {
+        int c[3] = {ci, cj, ck};
+        for (int k = 0; k < ncls; ++k) {
+          double X[4][3];
+          for (int v = 0; v <= d; ++v)
+            for (int i = 0; i < d; ++i) X[v][i] = cfg->origin[i] + (double)(c[i] + off[k][v][i]) * cfg->h[i];
+          for (int a = 0; a < nq; ++a)
+            for (int i = 0; i < d; ++i) {
+              double x = X[0][i];
+              for (int m = 0; m < d; ++m) x += (X[m + 1][i] - X[0][i]) * ((double)lat[a * d + m] / (double)degree);
+              out[o++] = x;
+            }
+        }
+      }
+  return SG_OK;
+}
+
+int sg_node_coords(const sg_handle* h, int degree, double* out, size_t nbytes) {
+  if (!h) return SG_ERR_ARG;
+  return sg_block_node_coords(&h->cfg, degree, out, nbytes);
+}
+
+int sg_set_params(sg_handle* h, double density, double dt, const double* lambda, const double* mu, int per_cell) {
+  if (!h || !lambda || !mu) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  h->rho = density;
+  h->dt = dt;
+  h->per_cell = per_cell ? 1 : 0;
+  if (per_cell) {
+    size_t nb = (size_t)h->ncells * sizeof(double);
+    if (!h->lam_d) HIPCHECK(h, hipMalloc((void**)&h->lam_d, nb));
+    if (!h->mu_d) HIPCHECK(h, hipMalloc((void**)&h->mu_d, nb));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipMemcpy(h->lam_d, lambda, nb, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->mu_d, mu, nb, hipMemcpyHostToDevice));
+    h->lam0 = lambda[0];
+    h->mu0 = mu[0];
+  } else {
+    h->lam0 = lambda[0];
+    h->mu0 = mu[0];
+  }
+  h->params_set = true;
+  return SG_OK;
+}
+
+int sg_set_field(sg_handle* h, int field, const double* host, size_t nbytes) {
+  if (!h || !host || field < 0 || field > 3) return SG_ERR_ARG;
+  if (nbytes != h->field_len[field] * sizeof(double)) return fail(h, SG_ERR_ARG, "sg_set_field: size mismatch");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, hipMemcpy(h->field[field], host, nbytes, hipMemcpyHostToDevice));
+  return SG_OK;
+}
+
+int sg_get_field(sg_handle* h, int field, double* host, size_t nbytes) {
+  if (!h || !host || field < 0 || field > 3) return SG_ERR_ARG;
+  if (nbytes != h->field_len[field] * sizeof(double)) return fail(h, SG_ERR_ARG, "sg_get_field: size mismatch");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, hipMemcpy(host, h->field[field], nbytes, hipMemcpyDeviceToHost));
+  return SG_OK;
+}
+
+int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree) {
+  if (!h) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (h->sponge_slot) {
+    (void)hipFree(h->sponge_slot);
+    h->sponge_slot = nullptr;
+  }
+  if (h->sponge_B) {
+    (void)hipFree(h->sponge_B);
+    h->sponge_B = nullptr;
+  }
+  if (!sigma_nodes) return SG_OK;
+  if (sigma_degree < 1 || sigma_degree > 6) return fail(h, SG_ERR_ARG, "sigma_degree must be 1..6");
+  const int d = h->cfg.dim, nd = h->re.nd;
+  const int nq = num_nodes(d, sigma_degree);
+  // B_e[a][b] = sum_c A[a][c][b] sigma_{e,c}  for cells with a non-zero sigma
+  std::vector<double> A = sponge_tensor(d, h->cfg.degree, sigma_degree);
+  std::vector<int32_t> slot((size_t)h->ncells, -1);
+  std::vector<double> B;
+  int32_t nslots = 0;
+  for (int64_t e = 0; e < h->ncells; ++e) {
+    const double* sg_ = sigma_nodes + (size_t)e * nq;
+    bool nz = false;
+    for (int c = 0; c < nq; ++c) nz = nz || (sg_[c] != 0.0);
+    if (!nz) continue;
+    slot[e] = nslots++;
+    size_t base = B.size();
+    B.resize(base + (size_t)nd * nd, 0.0);
+    for (int a = 0; a < nd; ++a)
+      for (int c = 0; c < nq; ++c) {
+        double s = sg_[c];
+        if (s == 0.0) continue;
+        const double* Arow = &A[((size_t)a * nq + c) * nd];
+        double* Brow = &B[base + (size_t)a * nd];
+        for (int b = 0; b < nd; ++b) Brow[b] += Arow[b] * s;
+      }
+  }
+  HIPCHECK(h, hipMalloc((void**)&h->sponge_slot, slot.size() * sizeof(int32_t)));
+  HIPCHECK(h, hipMemcpy(h->sponge_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nslots > 0) {
+    HIPCHECK(h, hipMalloc((void**)&h->sponge_B, B.size() * sizeof(double)));
+    HIPCHECK(h, hipMemcpy(h->sponge_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    HIPCHECK(h, hipMalloc((void**)&h->sponge_B, sizeof(double)));
+  }
+  return SG_OK;
+}
+
+int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values) {
+  if (!h || nnz < 0) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (h->src_nodes) {
+    (void)hipFree(h->src_nodes);
+    h->src_nodes = nullptr;
+  }
+  if (h->src_values) {
+    (void)hipFree(h->src_values);
+    h->src_values = nullptr;
+  }
+  h->src_nnz = 0;
+  h->src_nsteps = 0;
+  h->src_step = 0;
+  if (nnz == 0 || nsteps == 0) return SG_OK;
+  if (!nodes || !values || nsteps < 0) return SG_ERR_ARG;
+  const int d = h->cfg.dim;
+  int64_t nscalar = h->ncells * h->re.nd;
+  for (int64_t k = 0; k < nnz; ++k)
+    if (nodes[k] < 0 || nodes[k] >= nscalar) return fail(h, SG_ERR_ARG, "sg_set_source: node index out of range");
+  size_t vbytes = (size_t)nsteps * nnz * d * d * sizeof(double);
+  HIPCHECK(h, hipMalloc((void**)&h->src_nodes, (size_t)nnz * sizeof(int64_t)));
+  HIPCHECK(h, hipMalloc((void**)&h->src_values, vbytes));
+  HIPCHECK(h, hipMemcpy(h->src_nodes, nodes, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHECK(h, hipMemcpy(h->src_values, values, vbytes, hipMemcpyHostToDevice));
+  h->src_nnz = nnz;
+  h->src_nsteps = nsteps;
+  return SG_OK;
+}
+
+// ---- stage launches --------------------------------------------------------------------
+
+struct Box {
+  int o[3], n[3];
+};
+
+static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
+  out.clear();
+  const int d = h->cfg.dim;
+  int lo[3] = {0, 0, 0}, hi[3];
+  for (int a = 0; a < 3; ++a) hi[a] = h->cfg.n[a];
+  if (region == SG_REGION_ALL) {
+    out.push_back(Box{{0, 0, 0}, {hi[0], hi[1], hi[2]}});
+    return;
+  }
+  // interior: peel one cube off every side that has a neighbour block
+  int ilo[3] = {0, 0, 0}, ihi[3] = {hi[0], hi[1], hi[2]};
+  for (int a = 0; a < d; ++a) {
+    if (h->md.has_nbr[2 * a]) ilo[a] = 1;
+    if (h->md.has_nbr[2 * a + 1]) ihi[a] = hi[a] - 1;
+    if (ihi[a] < ilo[a]) ihi[a] = ilo[a];
+  }
+  if (region == SG_REGION_INTERIOR) {
+    out.push_back(Box{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}});
+    return;
+  }
+  // boundary shell = all \ interior, as disjoint slabs: peel axis by axis
+  int clo[3] = {lo[0], lo[1], lo[2]}, chi[3] = {hi[0], hi[1], hi[2]};
+  for (int a = 0; a < d; ++a) {
+    if (ilo[a] > clo[a]) {
+      Box b;
+      for (int k = 0; k < 3; ++k) {
+        b.o[k] = clo[k];
+        b.n[k] = chi[k] - clo[k];
+      }
+      b.n[a] = ilo[a] - clo[a];
+      out.push_back(b);
+      clo[a] = ilo[a];
+    }
+    if (ihi[a] < chi[a] && ihi[a] >= clo[a]) {
+      Box b;
+      for (int k = 0; k < 3; ++k) {
+        b.o[k] = clo[k];
+        b.n[k] = chi[k] - clo[k];
+      }
+      b.o[a] = ihi[a];
+      b.n[a] = chi[a] - ihi[a];
+      out.push_back(b);
+      chi[a] = ihi[a];
+    }
+  }
+}
+
+static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mode, double c_self, double c_aux,
+                  double c_new, int region, int uabs_f = SG_FIELD_U) {
+  StageArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = h->field[in_f];
+  a.out = h->field[out_f];
+  a.aux = aux_f >= 0 ? h->field[aux_f] : nullptr;
+  a.uabs = h->field[uabs_f];
+  for (int s = 0; s < 6; ++s) {
+    a.ghost[s] = h->ghost[in_f][s];
+    if (h->md.has_nbr[s] && !a.ghost[s] && region != SG_REGION_INTERIOR)
+      return fail(h, SG_ERR_STATE, "stage needs a halo buffer that was not attached (sg_halo_attach)");
+  }
+  a.Dt = h->Dt;
+  a.Lt = h->Lt;
+  a.md = h->md_dev;
+  a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
+  a.sponge_B = h->sponge_B;
+  a.lam = h->lam_d;
+  a.mu = h->mu_d;
+  a.lam0 = h->lam0;
+  a.mu0 = h->mu0;
+  a.per_cell = h->per_cell;
+  a.mode = mode;
+  a.c_self = c_self;
+  a.c_aux = c_aux;
+  a.c_new = c_new;
+  std::vector<Box> boxes;
+  region_boxes(h, region, boxes);
+  for (const Box& b : boxes) {
+    bool empty = false;
+    for (int k = 0; k < 3; ++k) {
+      a.box_o[k] = b.o[k];
+      a.box_n[k] = b.n[k];
+      empty = empty || (b.n[k] <= 0);
+    }
+    if (empty) continue;
+    int rc = launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
+    if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+  }
+  return SG_OK;
+}
+
+static int add_source(sg_handle* h, int field, double coef) {
+  if (h->src_nnz == 0 || h->src_step >= h->src_nsteps) return SG_OK;
+  const int d = h->cfg.dim;
+  const double* vals = h->src_values + (size_t)h->src_step * h->src_nnz * d * d;
+  int rc = launch_source(h->field[field], d * d, h->src_nnz, h->src_nodes, vals, coef, h->stream);
+  if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
+  return SG_OK;
+}
+
+static int run_stage_impl(sg_handle* h, int stage, int region) {
+  const double dt = h->dt, c3 = dt * dt * dt / 24.0;
+  int rc = SG_OK;
+  // the source lives on single nodes; apply it once per stage, with the region that owns everything
+  const bool src = (region == SG_REGION_ALL || region == SG_REGION_BOUNDARY);
+  switch (stage) {
+    case SG_STAGE_UH1:
+      return run_op(h, 0, SG_FIELD_S, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
+    case SG_STAGE_STEMP:
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
+      if (rc == SG_OK && src) rc = add_source(h, SG_FIELD_SH, 1.0);
+      return rc;
+    case SG_STAGE_U1:
+      // explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (elastic.py:341-345, :354-356)
+      return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, h->rho, dt, c3, region);
+    case SG_STAGE_SH1:
+      rc = run_op(h, 1, SG_FIELD_U, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
+      if (rc == SG_OK && src) rc = add_source(h, SG_FIELD_SH, 1.0);
+      return rc;
+    case SG_STAGE_UTEMP:
+      return run_op(h, 0, SG_FIELD_SH, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
+    case SG_STAGE_S1:
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, SG_FIELD_SH, 1, 1.0, dt, c3, region);
+      if (rc == SG_OK && src) rc = add_source(h, SG_FIELD_S, c3);
+      return rc;
+  }
+  return fail(h, SG_ERR_ARG, "unknown stage");
+}
+
+int sg_run_stage(sg_handle* h, int stage, int region) {
+  if (!h) return SG_ERR_ARG;
+  if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
+  if (region < 0 || region > 2) return fail(h, SG_ERR_ARG, "unknown region");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (h->timing) HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
+  int rc = run_stage_impl(h, stage, region);
+  if (rc != SG_OK) return rc;
+  if (h->timing) {
+    HIPCHECK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHECK(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->counters.kernel_ms[stage] += ms;
+  }
+  h->counters.launches[stage] += 1;
+  return SG_OK;
+}
+
+int sg_end_step(sg_handle* h) {
+  if (!h) return SG_ERR_ARG;
+  h->src_step += 1;
+  h->counters.steps += 1;
+  return SG_OK;
+}
+
+int sg_step(sg_handle* h, int64_t nsteps) {
+  if (!h || nsteps < 0) return SG_ERR_ARG;
+  if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
+  for (int s = 0; s < 6; ++s)
+    if (h->md.has_nbr[s]) return fail(h, SG_ERR_STATE, "sg_step on a block with neighbours: drive stages + halo from the host");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
+  for (int64_t k = 0; k < nsteps; ++k) {
+    for (int st = 0; st < 6; ++st) {
+      if (h->timing) {
+        int rc = sg_run_stage(h, st, SG_REGION_ALL);
+        if (rc != SG_OK) return rc;
+      } else {
+        int rc = run_stage_impl(h, st, SG_REGION_ALL);
+        if (rc != SG_OK) return rc;
+        h->counters.launches[st] += 1;
+      }
+    }
+    h->src_step += 1;
+    h->counters.steps += 1;
+  }
+  HIPCHECK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHECK(h, hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->last_ms = ms;
+  return SG_OK;
+}
+
+int sg_last_step_ms(sg_handle* h, double* ms) {
+  if (!h || !ms) return SG_ERR_ARG;
+  *ms = h->last_ms;
+  return SG_OK;
+}
+
+int sg_apply_F(sg_handle* h, int s_in, int u_abs, int u_out) {
+  if (!h) return SG_ERR_ARG;
+  if (!field_is_stress(s_in) || field_is_stress(u_out) || field_is_stress(u_abs) || u_abs == u_out)
+    return fail(h, SG_ERR_ARG, "sg_apply_F: s_in must be a stress field, u_abs/u_out distinct velocity fields");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return run_op(h, 0, s_in, u_out, -1, 0, 0, 0, 0, SG_REGION_ALL, u_abs);
+}
+
+int sg_apply_G(sg_handle* h, int u_in, int s_out, int use_source) {
+  if (!h) return SG_ERR_ARG;
+  if (field_is_stress(u_in) || !field_is_stress(s_out))
+    return fail(h, SG_ERR_ARG, "sg_apply_G: u_in must be a velocity field, s_out a stress field");
+  if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called first");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  int rc = run_op(h, 1, u_in, s_out, -1, 0, 0, 0, 0, SG_REGION_ALL);
+  if (rc == SG_OK && use_source) rc = add_source(h, s_out, 1.0);
+  return rc;
+}
+
+// ---- halo ---------------------------------------------------------------------------------
+
+int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes) {
+  if (!h || !nbytes || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
+  const int d = h->cfg.dim;
+  int axis = side >> 1;
+  size_t n2 = 1;
+  for (int a = 0; a < 3; ++a)
+    if (a != axis) n2 *= (size_t)h->cfg.n[a];
+  size_t comps = field_is_stress(field) ? (size_t)d * d : (size_t)d;
+  *nbytes = n2 * h->md.halo_per_cube * h->re.nf * comps * sizeof(double);
+  return SG_OK;
+}
+
+int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out) {
+  if (!h || !dev_out || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  const int d = h->cfg.dim;
+  int comps = field_is_stress(field) ? d * d : d;
+  int rc = launch_pack(d, h->cfg.degree, h->md_dev, h->md, h->field[field], comps, side, (double*)dev_out, h->stream);
+  if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
+  return SG_OK;
+}
+
+int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in) {
+  if (!h || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
+  h->ghost[field][side] = (const double*)dev_in;
+  return SG_OK;
+}
+
+// ---- instrumentation ----------------------------------------------------------------------------
+
+int sg_enable_timing(sg_handle* h, int on) {
+  if (!h) return SG_ERR_ARG;
+  h->timing = on != 0;
+  return SG_OK;
+}
+
+int sg_get_counters(sg_handle* h, sg_counters_t* out) {
+  if (!h || !out) return SG_ERR_ARG;
+  *out = h->counters;
+  return SG_OK;
+}
+
+int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out, size_t nbytes) {
+  std::vector<double> v;
+  try {
+    if (which == 3) {
+      if (q < 1 || q > 6 || dim < 1 || dim > 3 || degree < 1 || degree > 4) return SG_ERR_ARG;
+      v = sponge_tensor(dim, degree, q);
+    } else {
+      RefElem re = make_refelem(dim, degree);
+      if (which == 0) v = re.D;
+      else if (which == 1) v = re.L;
+      else if (which == 2) v = re.Mhat;
+      else if (which == 4) v.assign(re.fnode.begin(), re.fnode.end());
+      else return SG_ERR_ARG;
+    }
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return SG_ERR_ARG;
+  }
+  if (out) {
+    if (nbytes != v.size() * sizeof(double)) return SG_ERR_ARG;
+    std::memcpy(out, v.data(), nbytes);
+  }
+  return (int64_t)v.size();
+}
+
+int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi) {
+  if (dim < 1 || dim > 3 || degree < 1 || degree > 8 || npts < 0 || !xi || !phi) return SG_ERR_ARG;
+  tabulate(dim, degree, (int)npts, xi, phi);
+  return SG_OK;
+}
+
+int sg_mesh_tables(int dim, int degree, int diagonal, const double* h, int32_t* nb, int32_t* nb_node, double* cn,
+                   double* jinv) {
+  if (!h || !nb || !nb_node || !cn || !jinv) return SG_ERR_ARG;
+  try {
+    RefElem re = make_refelem(dim, degree);
+    MeshDev md;
+    std::memset(&md, 0, sizeof(md));
+    md.nd = re.nd;
+    md.nf = re.nf;
+    double hh[3] = {1, 1, 1};
+    for (int a = 0; a < dim; ++a) hh[a] = h[a];
+    build_mesh_tables(dim, degree, diagonal, hh, re.fnode.data(), re.lattice.data(), md);
+    for (int c = 0; c < md.ncls; ++c) {
+      for (int f = 0; f < md.nfaces; ++f) {
+        int32_t* o = nb + ((size_t)c * md.nfaces + f) * 5;
+        o[0] = md.nb_axis[c][f];
+        o[1] = md.nb_dir[c][f];
+        o[2] = md.nb_cls[c][f];
+        o[3] = md.nb_face[c][f];
+        o[4] = md.face_ord[c][f];
+        for (int b = 0; b < md.nf; ++b) nb_node[((size_t)c * md.nfaces + f) * md.nf + b] = md.nb_node[c][f][b];
+        for (int j = 0; j < 3; ++j) cn[((size_t)c * md.nfaces + f) * 3 + j] = md.cn[c][f][j];
+      }
+      for (int r = 0; r < 3; ++r)
+        for (int j = 0; j < 3; ++j) jinv[((size_t)c * 3 + r) * 3 + j] = md.Jinv[c][r][j];
+    }
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return SG_ERR_ARG;
+  }
+  return SG_OK;
+}
+
+}  // extern "C"

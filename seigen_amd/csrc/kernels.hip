@@ -1,0 +1,404 @@
+// HIP kernels (gfx950) for the velocity / stress right-hand sides.
+//
+// One launch evaluates, for every cell of a box of cubes, the whole of what
+// Firedrake runs as a cell loop + interior-facet loop (+ exterior-facet loop)
+// + inverse-mass mat-vec (seigen/elastic.py:204-219, :358-367), optionally
+// fused with the LF4 combine (elastic.py:340-352):
+//
+//   F:  uh_i  = -sum_r D_r (Jinv_rj T_ij) + sum_f L_f [ (c n)_j {T_ij} ]  - sponge
+//   G:  W_ik  = -Jinv_rk (D_r u_i)        + sum_f (c n)_k L_f [ u^_i ]
+//       sh_ij = lam d_ij W_kk + mu (W_ij + W_ji)
+//
+// Generic path: a 256-thread workgroup owns EB consecutive cells; thread
+// (cell, node) accumulates all components of its node.  Cell data, numerical
+// fluxes, the transposed reference operators and the mesh tables live in LDS.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace sg {
+
+template <int DIM, int P>
+struct Geo {
+  static constexpr int ND = (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
+  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
+  static constexpr int NFACES = DIM + 1;
+  static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
+  static constexpr int BLOCK = 256;
+  static constexpr int EB_RAW = BLOCK / ND;
+  static constexpr int EB = EB_RAW > 32 ? 32 : EB_RAW;  // cells per workgroup
+};
+
+__device__ __forceinline__ void decode_cube(long cube, const int n[3], int c[3]) {
+  c[0] = (int)(cube % n[0]);
+  long t = cube / n[0];
+  c[1] = (int)(t % n[1]);
+  c[2] = (int)(t / n[1]);
+}
+
+// index of a boundary cube within its side's 2-D array
+__device__ __forceinline__ long cube2d(int axis, const int c[3], const int n[3]) {
+  if (axis == 0) return c[1] + (long)n[1] * c[2];
+  if (axis == 1) return c[0] + (long)n[0] * c[2];
+  return c[0] + (long)n[0] * c[1];
+}
+
+template <int DIM, int P, int KIND>
+__global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
+  using G = Geo<DIM, P>;
+  constexpr int ND = G::ND, NF = G::NF, NFACES = G::NFACES, NCLS = G::NCLS, EB = G::EB;
+  constexpr int NC = (KIND == 0) ? DIM * DIM : DIM;  // input components per node
+  constexpr int NT = 256;
+
+  __shared__ double sDt[DIM * ND * ND];
+  __shared__ double sLt[NFACES * NF * ND];
+  __shared__ double sQ[EB * ND * NC];
+  __shared__ double sFlux[EB * NFACES * NF * DIM];
+  __shared__ long sElem[EB];
+  __shared__ MeshDev sMd;
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < DIM * ND * ND; i += NT) sDt[i] = A.Dt[i];
+  for (int i = tid; i < NFACES * NF * ND; i += NT) sLt[i] = A.Lt[i];
+  {
+    const int* src = reinterpret_cast<const int*>(A.md);
+    int* dst = reinterpret_cast<int*>(&sMd);
+    for (int i = tid; i < (int)(sizeof(MeshDev) / sizeof(int)); i += NT) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const long ncube_box = (long)A.box_n[0] * A.box_n[1] * A.box_n[2];
+  const long nelem_box = ncube_box * NCLS;
+  const long nbatch = (nelem_box + EB - 1) / EB;
+
+  for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    __syncthreads();
+    if (tid < EB) {
+      long eb = batch * EB + tid;
+      long g = -1;
+      if (eb < nelem_box) {
+        long cb = eb / NCLS;
+        int cls = (int)(eb % NCLS);
+        int c[3];
+        decode_cube(cb, A.box_n, c);
+        long cube = (c[0] + A.box_o[0]) + (long)sMd.n[0] * ((c[1] + A.box_o[1]) + (long)sMd.n[1] * (c[2] + A.box_o[2]));
+        g = cube * NCLS + cls;
+      }
+      sElem[tid] = g;
+    }
+    __syncthreads();
+
+    // ---- stage the cells' own data -------------------------------------------------
+    for (int idx = tid; idx < EB * ND * NC; idx += NT) {
+      int el = idx / (ND * NC);
+      int rem = idx - el * (ND * NC);
+      long g = sElem[el];
+      sQ[idx] = (g >= 0) ? A.in[g * (ND * NC) + rem] : 0.0;
+    }
+    __syncthreads();
+
+    // ---- numerical fluxes at facet nodes --------------------------------------------
+    for (int it = tid; it < EB * NFACES * NF; it += NT) {
+      int el = it / (NFACES * NF);
+      int r2 = it - el * (NFACES * NF);
+      int f = r2 / NF;
+      int b = r2 - f * NF;
+      long g = sElem[el];
+      if (g < 0) continue;
+      int cls = (int)(g % NCLS);
+      long cube = g / NCLS;
+      int c[3];
+      decode_cube(cube, sMd.n, c);
+      const double* own = &sQ[(el * ND + sMd.fnode[f][b]) * NC];
+      const double* nbr = nullptr;
+      int axis = sMd.nb_axis[cls][f];
+      bool physical = false;
+      if (axis < 0) {
+        long ng = cube * NCLS + sMd.nb_cls[cls][f];
+        nbr = A.in + (ng * ND + sMd.nb_node[cls][f][b]) * NC;
+      } else {
+        int dir = sMd.nb_dir[cls][f];
+        int cn = c[axis] + dir;
+        if (cn >= 0 && cn < sMd.n[axis]) {
+          long stride = (axis == 0) ? 1 : (axis == 1) ? sMd.n[0] : (long)sMd.n[0] * sMd.n[1];
+          long ng = (cube + dir * stride) * NCLS + sMd.nb_cls[cls][f];
+          nbr = A.in + (ng * ND + sMd.nb_node[cls][f][b]) * NC;
+        } else {
+          int side = 2 * axis + (dir > 0 ? 1 : 0);
+          if (sMd.has_nbr[side]) {
+            long slot = cube2d(axis, c, sMd.n) * sMd.halo_per_cube + sMd.face_ord[sMd.nb_cls[cls][f]][sMd.nb_face[cls][f]];
+            nbr = A.ghost[side] + (slot * NF + sMd.nb_fnode[cls][f][b]) * NC;
+          } else {
+            physical = true;
+          }
+        }
+      }
+      double* fl = &sFlux[it * DIM];
+      if (KIND == 0) {
+        // (c n)_j {T_ij}; no ds term in f => traction-free boundary (elastic.py:206)
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) {
+          double s = 0.0;
+          if (!physical) {
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) s += 0.5 * (own[i * DIM + j] + nbr[i * DIM + j]) * sMd.cn[cls][f][j];
+          }
+          fl[i] = s;
+        }
+      } else {
+        // u^ = avg(u) on dS, own trace on ds (elastic.py:213-216)
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) fl[i] = physical ? own[i] : 0.5 * (own[i] + nbr[i]);
+      }
+    }
+    __syncthreads();
+
+    const int el = tid / ND;
+    const int a = tid - el * ND;
+    const bool active = (el < EB) && (sElem[el < EB ? el : 0] >= 0);
+    const long g = active ? sElem[el] : 0;
+    const int cls = (int)(g % NCLS);
+
+    if (KIND == 0) {
+      // T~_ir = sum_j Jinv[r][j] T_ij, in place (each thread owns its node)
+      if (active) {
+        double* t = &sQ[(el * ND + a) * NC];
+        double tt[DIM * DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) s += sMd.Jinv[cls][r][j] * t[i * DIM + j];
+            tt[i * DIM + r] = s;
+          }
+#pragma unroll
+        for (int k = 0; k < DIM * DIM; ++k) t[k] = tt[k];
+      }
+      __syncthreads();
+      double acc[DIM];
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) acc[i] = 0.0;
+      if (active) {
+        for (int b = 0; b < ND; ++b) {
+          double d[DIM];
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) d[r] = sDt[(r * ND + b) * ND + a];
+          const double* t = &sQ[(el * ND + b) * NC];
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) acc[i] -= d[r] * t[i * DIM + r];
+        }
+#pragma unroll
+        for (int f = 0; f < NFACES; ++f)
+          for (int b = 0; b < NF; ++b) {
+            double l = sLt[(f * NF + b) * ND + a];
+            const double* fl = &sFlux[((el * NFACES + f) * NF + b) * DIM];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) acc[i] += l * fl[i];
+          }
+        if (A.sponge_slot != nullptr) {
+          int slot = A.sponge_slot[g];
+          if (slot >= 0) {
+            const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
+            const double* ua = A.uabs + g * (ND * DIM);
+            for (int b = 0; b < ND; ++b) {
+              double bb = B[b];
+#pragma unroll
+              for (int i = 0; i < DIM; ++i) acc[i] -= bb * ua[b * DIM + i];
+            }
+          }
+        }
+      }
+      // the fused combine writes `out` in place, and `uabs` may be that same buffer:
+      // every sponge read of this cell must land before any of its nodes is overwritten
+      if (A.sponge_slot != nullptr && A.mode != 0) __syncthreads();
+      if (active) {
+        long o = (g * ND + a) * DIM;
+        if (A.mode == 0) {
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) A.out[o + i] = acc[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) A.out[o + i] = A.c_self * A.out[o + i] + A.c_aux * A.aux[o + i] + A.c_new * acc[i];
+        }
+      }
+    } else {
+      if (active) {
+        double R[DIM][DIM];  // R[i][r] = (D_r u_i)_a
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) R[i][r] = 0.0;
+        for (int b = 0; b < ND; ++b) {
+          double d[DIM];
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) d[r] = sDt[(r * ND + b) * ND + a];
+          const double* u = &sQ[(el * ND + b) * NC];
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) R[i][r] += d[r] * u[i];
+        }
+        double W[DIM][DIM];  // W[i][k] = weak d u_i / d x_k
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) s -= sMd.Jinv[cls][r][k] * R[i][r];
+            W[i][k] = s;
+          }
+#pragma unroll
+        for (int f = 0; f < NFACES; ++f) {
+          double lu[DIM];
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) lu[i] = 0.0;
+          for (int b = 0; b < NF; ++b) {
+            double l = sLt[(f * NF + b) * ND + a];
+            const double* fl = &sFlux[((el * NFACES + f) * NF + b) * DIM];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) lu[i] += l * fl[i];
+          }
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) W[i][k] += sMd.cn[cls][f][k] * lu[i];
+        }
+        double lam = A.per_cell ? A.lam[g] : A.lam0;
+        double mu = A.per_cell ? A.mu[g] : A.mu0;
+        double tr = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) tr += W[k][k];
+        long o = (g * ND + a) * (DIM * DIM);
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) {
+            double v = mu * (W[i][j] + W[j][i]) + ((i == j) ? lam * tr : 0.0);
+            if (A.mode == 0)
+              A.out[o + i * DIM + j] = v;
+            else
+              A.out[o + i * DIM + j] = A.c_self * A.out[o + i * DIM + j] + A.c_aux * A.aux[o + i * DIM + j] + A.c_new * v;
+          }
+      }
+    }
+  }
+}
+
+template <int DIM, int P>
+static int launch_dp(int kind, const StageArgs& a, hipStream_t s) {
+  using G = Geo<DIM, P>;
+  long nelem = (long)a.box_n[0] * a.box_n[1] * a.box_n[2] * G::NCLS;
+  if (nelem <= 0) return 0;
+  long nbatch = (nelem + G::EB - 1) / G::EB;
+  long grid = nbatch < 256L * 8 ? nbatch : 256L * 8;
+  if (kind == 0)
+    hipLaunchKernelGGL((stage_kernel<DIM, P, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((stage_kernel<DIM, P, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+template <int DIM>
+static int launch_d(int kind, int P, const StageArgs& a, hipStream_t s) {
+  switch (P) {
+    case 1: return launch_dp<DIM, 1>(kind, a, s);
+    case 2: return launch_dp<DIM, 2>(kind, a, s);
+    case 3: return launch_dp<DIM, 3>(kind, a, s);
+    case 4: return launch_dp<DIM, 4>(kind, a, s);
+  }
+  return -1;
+}
+
+int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (dim) {
+    case 1: return launch_d<1>(kind, P, a, s);
+    case 2: return launch_d<2>(kind, P, a, s);
+    case 3: return launch_d<3>(kind, P, a, s);
+  }
+  return -1;
+}
+
+// ---- halo pack ------------------------------------------------------------------------
+__global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, int side, long nslots, double* out) {
+  const int nd = md->nd, nf = md->nf, ncls = md->ncls, nfaces = md->nfaces, hpc = md->halo_per_cube;
+  const int axis = side >> 1, hi = side & 1;
+  long total = nslots * nf * ncomp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int cpt = (int)(idx % ncomp);
+    long t = idx / ncomp;
+    int b = (int)(t % nf);
+    long slot = t / nf;
+    int ord = (int)(slot % hpc);
+    long c2 = slot / hpc;
+    // boundary cube from its 2-D index
+    int c[3] = {0, 0, 0};
+    int n0 = md->n[0], n1 = md->n[1];
+    if (axis == 0) {
+      c[1] = (int)(c2 % n1);
+      c[2] = (int)(c2 / n1);
+    } else if (axis == 1) {
+      c[0] = (int)(c2 % n0);
+      c[2] = (int)(c2 / n0);
+    } else {
+      c[0] = (int)(c2 % n0);
+      c[1] = (int)(c2 / n0);
+    }
+    c[axis] = hi ? md->n[axis] - 1 : 0;
+    long cube = c[0] + (long)n0 * (c[1] + (long)n1 * c[2]);
+    // the (class, facet) with this ordinal on this side
+    int cls = -1, f = -1;
+    for (int k = 0; k < ncls; ++k)
+      for (int ff = 0; ff < nfaces; ++ff)
+        if (md->nb_axis[k][ff] == axis && (md->nb_dir[k][ff] > 0) == (hi != 0) && md->face_ord[k][ff] == ord) {
+          cls = k;
+          f = ff;
+        }
+    long g = cube * ncls + cls;
+    out[idx] = field[(g * nd + md->fnode[f][b]) * ncomp + cpt];
+  }
+}
+
+int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& mh, const double* field, int ncomp, int side,
+                double* out, void* stream) {
+  (void)dim;
+  (void)P;
+  int axis = side >> 1;
+  long n2 = 1;
+  for (int a = 0; a < 3; ++a)
+    if (a != axis) n2 *= mh.n[a];
+  long nslots = n2 * mh.halo_per_cube;
+  long total = nslots * mh.nf * ncomp;
+  if (total <= 0) return 0;
+  long grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, field, ncomp, side,
+                     nslots, out);
+  return (int)hipGetLastError();
+}
+
+// ---- sparse source ----------------------------------------------------------------------
+__global__ void source_kernel(double* field, int ncomp, long nnz, const int64_t* nodes, const double* pattern,
+                              double coef) {
+  long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= nnz * ncomp) return;
+  long k = idx / ncomp;
+  int c = (int)(idx - k * ncomp);
+  field[nodes[k] * ncomp + c] += coef * pattern[idx];
+}
+
+int launch_source(double* field, int ncomp, int64_t nnz, const int64_t* nodes, const double* pattern, double coef,
+                  void* stream) {
+  if (nnz <= 0) return 0;
+  long total = nnz * ncomp;
+  hipLaunchKernelGGL(source_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, field,
+                     ncomp, (long)nnz, nodes, pattern, coef);
+  return (int)hipGetLastError();
+}
+
+}  // namespace sg

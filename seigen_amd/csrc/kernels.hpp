@@ -1,0 +1,40 @@
+// Launch interface between the C-ABI host code (api.cpp) and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+#include "mesh_tables.hpp"
+
+namespace sg {
+
+struct StageArgs {
+  const double* in;    // stress for F, velocity for G           [cell][node][comp]
+  double* out;         // result, or in-place target of a fused combine
+  const double* aux;   // fused combine: second operand (uh1 / sh1)
+  const double* uabs;  // F: velocity multiplied by the sponge (elastic.py:207-208)
+  const double* ghost[6];  // packed remote facet traces of `in` per block side, or null
+  const double* Dt;        // [dim][nd(b)][nd(a)]  transposed Mhat^-1 Shat_r
+  const double* Lt;        // [nfaces][nf(b')][nd(a)] transposed facet lifts
+  const MeshDev* md;       // device copy
+  const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
+  const double* sponge_B;      // [slot][nd(a)][nd(b)]
+  const double* lam;           // per-cell (per_cell=1) or null
+  const double* mu;
+  double lam0, mu0;
+  double c_self, c_aux, c_new;  // mode 1: out = c_self*out + c_aux*aux + c_new*rhs
+  int32_t mode;                 // 0: out = rhs
+  int32_t per_cell;
+  int32_t box_o[3], box_n[3];   // region of cubes covered by this launch
+};
+
+// kind: 0 = F (velocity RHS), 1 = G (stress RHS)
+int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream);
+
+// facet traces of a field on one block side -> packed device buffer
+int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& md_host, const double* field, int ncomp, int side,
+                double* out, void* stream);
+
+// field[node][c] += coef * pattern[k][c] at the sparse source nodes
+int launch_source(double* field, int ncomp, int64_t nnz, const int64_t* nodes, const double* pattern, double coef,
+                  void* stream);
+
+}  // namespace sg

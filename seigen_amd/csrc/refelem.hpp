@@ -1,0 +1,39 @@
+// Reference simplex operators for equispaced Lagrange P_k (host side, setup only).
+//
+// Replaces what `assemble(inner(w,u)*dx, inverse=True)` (seigen/elastic.py:376-382)
+// and the TSFC-generated element kernels tabulate per cell [upstream]: on affine
+// simplices with constant coefficients every integral of elastic.py:204-219 is
+// a reference matrix times a geometric factor, so the element-wise inverse
+// mass can be folded into the operators once:
+//   D_r = Mhat^-1 Shat_r,   Shat_r[a][b] = int dphi_a/dxi_r phi_b      (volume)
+//   L_f = Mhat^-1[:, face f nodes] * Mface_unit                        (facet lift)
+// with Mface_unit the facet mass matrix normalised to unit facet measure.
+#pragma once
+#include <vector>
+
+namespace sg {
+
+struct RefElem {
+  int dim = 0, P = 0, nd = 0, nf = 0, nfaces = 0;
+  std::vector<int> lattice;   // [nd][dim]
+  std::vector<int> fnode;     // [nfaces][nf] element-node index of each facet node
+  std::vector<double> Mhat;   // [nd][nd]
+  std::vector<double> Minv;   // [nd][nd]
+  std::vector<double> D;      // [dim][nd][nd]
+  std::vector<double> L;      // [nfaces][nd][nf]
+  // monomial expansion phi_a = sum_m C[m][a] xi^gamma_m (long double kept as double pairs is
+  // not needed: the sponge tensor is built inside refelem.cpp)
+};
+
+int num_nodes(int dim, int P);
+void lattice_points(int dim, int P, std::vector<int>& out);  // [nd][dim], first coord fastest
+RefElem make_refelem(int dim, int P);
+
+// phi[p][a] = Lagrange basis a of P_k at reference point xi[p][:]  (degree up to 8)
+void tabulate(int dim, int P, int npts, const double* xi, double* phi);
+
+// A[a][c][b] = sum_a' Minv[a][a'] int phi_a' psi_c phi_b, psi in P_q.  Size nd*nq*nd.
+// (absorption term -inner(w, sigma*u0)*dx, elastic.py:207-208, with sigma in DG_q)
+std::vector<double> sponge_tensor(int dim, int P, int q);
+
+}  // namespace sg

@@ -1,0 +1,340 @@
+"""`ElasticLF4` - the solver-class API of ``seigen/elastic.py`` on MI355X.
+
+Drop-in for the explicit path of the reference: same factory
+(``ElasticLF4.create``, ``seigen/elastic.py:27-64``), same plain attributes
+(``density dt mu l``), same ``absorption`` / ``source`` properties whose setters
+interpolate an ``Expression`` into a pre-assigned ``Function`` (``:126-154``),
+same ten named fields (``:93-103``) and the same ``run(T)`` loop (``:267-315``).
+What Firedrake/PyOP2 generated and ran on CPU per timestep - eight assembles,
+eight inverse-mass mat-vecs, two copies, halo exchanges - is six fused HIP
+launches in libseigen_hip.so, driven through ctypes (include/seigen_hip.h).
+
+Differences, all documented in DESIGN.md:
+  * ``uh2`` and ``sh2`` are never materialised (fused into the combine stages);
+    ``u0``/``u1`` (``s0``/``s1``) share one device buffer because
+    ``u0.assign(u1)`` (``:296``) is an in-place update.
+  * ``solver='implicit'`` (PETSc KSP, ``:318-332``) is outside the hot path and
+    raises ``NotImplementedError`` at run time.
+  * VTK output (``:221-232``) is replaced by ``.npy`` snapshots.
+"""
+import os
+import sys
+from contextlib import contextmanager
+
+import numpy as np
+
+from . import _lib
+from .backend import HipBlock
+from .functionspace import Function, FunctionSpace, TensorFunctionSpace, VectorFunctionSpace
+from .helpers import log, allreduce_sum
+from .parallel import world, HaloExchanger
+from .profiling import timed_region
+
+_SOLVER_MODES = ("implicit", "explicit", "parloop", "fusion", "tiling", "hip")
+
+
+def _device_for_rank():
+    if "SEIGEN_HIP_DEVICE" in os.environ:
+        return int(os.environ["SEIGEN_HIP_DEVICE"])
+    if world()[1] > 1:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    return 0
+
+
+class ElasticLF4(object):
+    r"""Elastic wave equation, DG in space, fourth-order leap-frog in time.
+    Create with ``ElasticLF4.create(mesh, family, degree, dimension, solver)``."""
+
+    @staticmethod
+    def create(mesh, family, degree, dimension, solver="explicit", output=True):
+        """Same signature and solver strings as ``seigen/elastic.py:27-64``; every
+        explicit mode ('explicit', 'parloop', 'fusion', 'tiling', and the alias
+        'hip') runs the fused HIP path."""
+        if solver == "implicit":
+            return ImplicitElasticLF4(mesh, family, degree, dimension, output=output)
+        elif solver in ("explicit", "hip"):
+            return ExplicitElasticLF4(mesh, family, degree, dimension, output=output)
+        elif solver == "parloop":
+            return TilingElasticLF4(mesh, family, degree, dimension, output=output, tiling_mode=None)
+        elif solver == "fusion":
+            return TilingElasticLF4(mesh, family, degree, dimension, output=output, tiling_mode="hard")
+        elif solver == "tiling":
+            return TilingElasticLF4(mesh, family, degree, dimension, output=output, tiling_mode="tile")
+        else:
+            raise ValueError("Unknown solver mode. Must be one of: implicit, explicit, parloop")
+
+    def __init__(self, mesh, family, degree, dimension, output=True):
+        with timed_region('function setup'):
+            if dimension != mesh.dim:
+                raise ValueError("dimension=%r does not match the mesh (%d-D)" % (dimension, mesh.dim))
+            if not (1 <= int(degree) <= 4):
+                raise ValueError("degree must be 1..4")
+            self.mesh = mesh
+            self.dimension = dimension
+            self.degree = int(degree)
+            self.output = output
+
+            self.S = TensorFunctionSpace(mesh, family, degree, name='S')
+            self.U = VectorFunctionSpace(mesh, family, degree, name='U')
+
+            # Assumes that the S and U function spaces are the same.
+            dofs = allreduce_sum(self.S.dof_count)
+            log("Number of degrees of freedom: %d" % dofs)
+
+            self._block = self._create_block()
+
+            def bound(space, name, field):
+                f = Function(space, name=name)
+                if field is not None:
+                    f._bind(self._block, field)
+                return f
+
+            self.s0 = bound(self.S, "StressOld", _lib.FIELD_S)
+            self.sh1 = bound(self.S, "StressHalf1", _lib.FIELD_SH)
+            self.stemp = bound(self.S, "StressTemp", _lib.FIELD_SH)
+            self.sh2 = bound(self.S, "StressHalf2", None)       # fused away, never materialised
+            self.s1 = bound(self.S, "StressNew", _lib.FIELD_S)
+
+            self.u0 = bound(self.U, "VelocityOld", _lib.FIELD_U)
+            self.uh1 = bound(self.U, "VelocityHalf1", _lib.FIELD_UH)
+            self.utemp = bound(self.U, "VelocityTemp", _lib.FIELD_UH)
+            self.uh2 = bound(self.U, "VelocityHalf2", None)      # fused away
+            self.u1 = bound(self.U, "VelocityNew", _lib.FIELD_U)
+
+            self.absorption_function = None
+            self.source_function = None
+            self.source_expression = None
+            self.density = None
+            self.dt = None
+            self.mu = None
+            self.l = None
+
+            self.invmass_velocity = None
+            self.invmass_stress = None
+            self._exchanger = None
+            self._step_index = 0
+
+        if self.output:
+            with timed_region('i/o'):
+                self.u_stream = "velocity"
+                self.s_stream = "stress"
+
+    # ---- device block ---------------------------------------------------------------------
+    def _create_block(self):
+        part = self.mesh.partition
+        stream = None
+        if part.world > 1:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.set_device(_device_for_rank())
+                stream = torch.cuda.current_stream().cuda_stream
+        origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
+        return HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin, self.mesh.diagonal,
+                        part.nbr_mask, device=_device_for_rank(), stream=stream)
+
+    @property
+    def block(self):
+        return self._block
+
+    # ---- absorption / source (elastic.py:126-154) -----------------------------------------------
+    @property
+    def absorption(self):
+        r"""The absorption coefficient :math:`\sigma` of the term :math:`\sigma\mathbf{u}`."""
+        return self.absorption_function
+
+    @absorption.setter
+    def absorption(self, expression):
+        self.absorption_function.interpolate(expression)
+
+    @property
+    def source(self):
+        r"""The source term on the RHS of the stress equation."""
+        return self.source_function
+
+    @source.setter
+    def source(self, expression):
+        self.source_function.interpolate(expression)
+
+    # ---- stage descriptors in place of the UFL forms (elastic.py:156-202) ------------------------
+    form_uh1 = property(lambda self: ("uh1", _lib.STAGE_UH1))
+    form_stemp = property(lambda self: ("stemp", _lib.STAGE_STEMP))
+    form_uh2 = property(lambda self: ("uh2+u1", _lib.STAGE_U1))
+    form_u1 = property(lambda self: ("uh2+u1", _lib.STAGE_U1))
+    form_sh1 = property(lambda self: ("sh1", _lib.STAGE_SH1))
+    form_utemp = property(lambda self: ("utemp", _lib.STAGE_UTEMP))
+    form_sh2 = property(lambda self: ("sh2+s1", _lib.STAGE_S1))
+    form_s1 = property(lambda self: ("sh2+s1", _lib.STAGE_S1))
+
+    def write(self, u=None, s=None):
+        r"""Write the velocity and/or stress fields (``.npy`` snapshots instead of the
+        reference's VTK streams, ``seigen/elastic.py:221-232``)."""
+        if self.output:
+            with timed_region('i/o'):
+                rank = world()[0]
+                if u:
+                    np.save("%s_%d_r%d.npy" % (self.u_stream, self._step_index, rank), u.dat.data)
+                if s:
+                    np.save("%s_%d_r%d.npy" % (self.s_stream, self._step_index, rank), s.dat.data)
+
+    def create_solver(self, form, result=None):
+        """Solver context of one stage = its fused-launch id (``elastic.py:354-356``)."""
+        return form[1]
+
+    def solve(self, ctx, matrix=None, result=None):
+        """Run one fused stage on the device (``elastic.py:358-367``).  The combine
+        stages are fused into ``uh2``/``sh2``, so their contexts launch nothing new."""
+        self._block.run_stage(ctx)
+
+    def setup(self):
+        """Upload parameters, sponge and source; stage contexts (``elastic.py:244-255``,
+        ``:369-385`` - the inverse mass is folded into the reference operators)."""
+        log("Creating solver contexts")
+        with timed_region('solver setup'):
+            for name in ("density", "dt", "mu", "l"):
+                if getattr(self, name) is None:
+                    raise ValueError("ElasticLF4.%s must be set before run()" % name)
+            self._block.set_params(self.density, self.dt, self.l, self.mu)
+            if self.absorption_function is not None:
+                self._block.set_absorption(self.absorption_function.dat.data_cells,
+                                           self.absorption_function.function_space().degree)
+            else:
+                self._block.set_absorption(None, 0)
+            self.ctx_uh1 = self.create_solver(self.form_uh1, self.uh1)
+            self.ctx_stemp = self.create_solver(self.form_stemp, self.stemp)
+            self.ctx_uh2 = self.create_solver(self.form_uh2, self.uh2)
+            self.ctx_u1 = self.create_solver(self.form_u1, self.u1)
+            self.ctx_sh1 = self.create_solver(self.form_sh1, self.sh1)
+            self.ctx_utemp = self.create_solver(self.form_utemp, self.utemp)
+            self.ctx_sh2 = self.create_solver(self.form_sh2, self.sh2)
+            self.ctx_s1 = self.create_solver(self.form_s1, self.s1)
+            if self.mesh.partition.world > 1 and self._exchanger is None:
+                import torch
+                dev = torch.device("cuda", _device_for_rank())
+                self._exchanger = HaloExchanger(self._block, self.mesh.partition, dev)
+
+    @property
+    def loop_context(self):
+        @contextmanager
+        def empty_loop_context():
+            yield
+        return empty_loop_context
+
+    # ---- source handling -----------------------------------------------------------------------
+    def _source_table(self, times):
+        """Sparse per-step source values (nodes, values[nsteps, nnz, d, d]).
+
+        The reference re-interpolates ``source_expression`` into ``source_function``
+        at every step (``elastic.py:285-288``).  The same nodal values are computed
+        here for all steps up front, but only on the support of the source (found
+        by sampling the expression over the run), and uploaded once."""
+        expr = self.source_expression
+        X = self.S.node_coords()
+        nsteps = len(times)
+        if expr is None or not hasattr(expr, "_params") or "t" not in expr._params:
+            vals = self.source_function.dat.data_cells
+            nz = np.nonzero(np.abs(vals).reshape(vals.shape[0] * vals.shape[1], -1).max(axis=1) > 0)[0]
+            v = vals.reshape(-1, self.dimension, self.dimension)[nz]
+            return nz, np.broadcast_to(v, (nsteps,) + v.shape)
+        t_keep = expr.t
+        sample = set(range(0, nsteps, max(1, nsteps // 64))) | {0, nsteps - 1}
+        support = np.zeros(X.shape[0] * X.shape[1], dtype=bool)
+        for k in sorted(sample):
+            expr.t = times[k]
+            v = expr.evaluate(X)
+            support |= np.abs(v).reshape(support.size, -1).max(axis=1) > 0
+        nz = np.nonzero(support)[0]
+        Xs = X.reshape(-1, X.shape[-1])[nz]
+        values = np.zeros((nsteps, len(nz), self.dimension, self.dimension))
+        for k in range(nsteps):
+            expr.t = times[k]
+            values[k] = expr.evaluate(Xs)
+        expr.t = t_keep
+        return nz, values
+
+    # ---- time loop (elastic.py:267-315) ----------------------------------------------------------
+    def step_times(self, T):
+        """The values of `t` visited by the reference loop ``t = dt; while t <= T + 1e-12``."""
+        times = []
+        t = self.dt
+        while t <= T + 1e-12:
+            times.append(t)
+            t += self.dt
+        return times
+
+    def _advance(self, nsteps):
+        if self._exchanger is not None:
+            self._exchanger.step(nsteps)
+        else:
+            self._block.step(nsteps)
+        self._step_index += nsteps
+
+    def run(self, T):
+        """Run the elastic wave simulation until t = T; returns (u1, s1)."""
+        # Write out the initial condition.
+        self.write(self.u1, self.s1)
+
+        # Call solver-specific setup
+        self.setup()
+
+        with timed_region('timestepping'):
+            times = self.step_times(T)
+            if self.source:
+                with timed_region('source term update'):
+                    nodes, values = self._source_table(times)
+                    self._block.set_source(nodes, values)
+            else:
+                self._block.set_source([], None)
+            with self.loop_context():
+                if self.output:
+                    for t in times:
+                        log("t = %f" % t)
+                        self._advance(1)
+                        self.write(self.u1, self.s1)
+                else:
+                    # the eight solves + two assigns of every step, without returning to Python
+                    self._advance(len(times))
+            self._block.sync()
+            if self.source and self.source_expression is not None and times and \
+                    "t" in getattr(self.source_expression, "_params", {}):
+                self.source_expression.t = times[-1]
+                self.source = self.source_expression
+        return self.u1, self.s1
+
+
+class ImplicitElasticLF4(ElasticLF4):
+    r"""The PETSc-KSP path of the reference (``seigen/elastic.py:318-332``) is not part
+    of the explicit hot path this package replaces."""
+
+    def run(self, T):
+        raise NotImplementedError("solver='implicit' (LinearVariationalSolver / PETSc KSP, "
+                                  "seigen/elastic.py:318-332) is out of scope; use solver='explicit'")
+
+
+class ExplicitElasticLF4(ElasticLF4):
+    r"""Explicit solves: RHS assembly and element-wise inverse mass fused on the GPU
+    (``seigen/elastic.py:335-385``)."""
+    pass
+
+
+class TilingElasticLF4(ExplicitElasticLF4):
+    r"""'parloop' / 'fusion' / 'tiling' of the reference (``seigen/elastic.py:388-515``)
+    differ from 'explicit' only in HOW the CPU executes the same arithmetic (per-cell
+    mat-vec par_loop, PyOP2 loop fusion, SLOPE tiling).  On the GPU that role is played
+    by kernel fusion inside libseigen_hip, so these modes share the explicit path."""
+
+    loop_chain_length = 28
+    num_solves = 8
+    tile_size = 1000
+    extra_halo = 0
+
+    def __init__(self, mesh, *args, **kwargs):
+        self.tiling_mode = kwargs.pop("tiling_mode", None)
+        self.num_unroll = 0 if self.tiling_mode is None else 1
+        super(TilingElasticLF4, self).__init__(mesh, *args, **kwargs)
+
+    def calculate_sdepth(self, num_solves, num_unroll, extra_halo):
+        """Halo depth the reference would request (``seigen/elastic.py:422-436``); the HIP
+        path always exchanges depth-1 facet traces per stage."""
+        if world()[1] > 1:
+            return 1 + num_solves * num_unroll + extra_halo
+        return 1

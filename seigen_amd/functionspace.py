@@ -1,0 +1,181 @@
+"""Function-space and `Function` stand-ins with the attributes the reference's
+solver class and harnesses touch (``seigen/elastic.py:81-103``, ``:136-154``;
+``tests/eigenmode/eigenmode_2d.py:30-36``): ``FunctionSpace``,
+``VectorFunctionSpace``, ``TensorFunctionSpace``, ``Function.assign``,
+``Function.interpolate``, ``Function.dat.data``, ``dof_count``.
+
+Data layout follows [upstream] Firedrake: ``dat.data`` has shape
+(nodes, *value_shape) with DG nodes numbered cell by cell; here additionally
+exposed cell-blocked as ``dat.data_cells`` = (cells, nd, *value_shape).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from .expression import Expression
+
+
+def _nnodes(dim, degree):
+    return {1: degree + 1, 2: (degree + 1) * (degree + 2) // 2,
+            3: (degree + 1) * (degree + 2) * (degree + 3) // 6}[dim]
+
+
+def block_config(mesh, degree=1, device=0):
+    """sg_config of this rank's block of `mesh`."""
+    part = mesh.partition
+    cfg = _lib.SgConfig()
+    cfg.dim, cfg.degree = mesh.dim, degree
+    for a in range(3):
+        if a < mesh.dim:
+            cfg.n[a] = part.n[a]
+            cfg.h[a] = mesh.h[a]
+            cfg.origin[a] = mesh.origin[a] + part.start[a] * mesh.h[a]
+        else:
+            cfg.n[a], cfg.h[a], cfg.origin[a] = 1, 1.0, 0.0
+    cfg.diagonal = 1 if mesh.diagonal == "right" else 0
+    cfg.nbr_mask = part.nbr_mask
+    cfg.device = device
+    cfg.stream = None
+    return cfg
+
+
+class FunctionSpace(object):
+    value_shape = ()
+
+    def __init__(self, mesh, family, degree, name=None):
+        if family not in ("DG", "Discontinuous Lagrange"):
+            raise NotImplementedError("seigen_amd implements the discontinuous-Galerkin path only "
+                                      "(family='DG'); got %r" % (family,))
+        if not (1 <= int(degree) <= 8):
+            raise ValueError("degree must be 1..8")
+        self.mesh = mesh
+        self.family = "DG"
+        self.degree = int(degree)
+        self.name = name
+        self.dim = mesh.dim
+        self.nd = _nnodes(mesh.dim, self.degree)
+        self._coords = None
+
+    def ufl_element(self):
+        return (self.family, self.degree, self.value_shape)
+
+    @property
+    def ncells(self):
+        return int(np.prod(self.mesh.partition.n)) * self.mesh.cells_per_block
+
+    @property
+    def node_count(self):
+        return self.ncells * self.nd
+
+    @property
+    def value_size(self):
+        return int(np.prod(self.value_shape)) if self.value_shape else 1
+
+    @property
+    def dof_count(self):
+        """nodes * value size on this rank (seigen/elastic.py:85)."""
+        return self.node_count * self.value_size
+
+    def node_coords(self):
+        """[cells, nd, dim] physical node coordinates of this rank's block."""
+        if self._coords is None:
+            cfg = block_config(self.mesh, min(self.degree, 4))
+            out = np.empty((self.ncells, self.nd, self.dim))
+            _lib.check(_lib.load().sg_block_node_coords(C.byref(cfg), self.degree, out.ctypes.data, out.nbytes))
+            self._coords = out
+        return self._coords
+
+
+class VectorFunctionSpace(FunctionSpace):
+    def __init__(self, mesh, family, degree, name=None):
+        super(VectorFunctionSpace, self).__init__(mesh, family, degree, name)
+        self.value_shape = (mesh.dim,)
+
+
+class TensorFunctionSpace(FunctionSpace):
+    def __init__(self, mesh, family, degree, name=None):
+        super(TensorFunctionSpace, self).__init__(mesh, family, degree, name)
+        self.value_shape = (mesh.dim, mesh.dim)
+
+
+class _Dat(object):
+    """``Function.dat``: ``data`` reads (and, by assignment, writes) the values."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    @property
+    def data(self):
+        return self._fn._get().reshape((-1,) + self._fn._space.value_shape)
+
+    @data.setter
+    def data(self, value):
+        self._fn._set(np.asarray(value, dtype=np.float64))
+
+    data_ro = data
+
+    @property
+    def data_cells(self):
+        return self._fn._get()
+
+
+class Function(object):
+    """Host-resident unless bound to a device field of a solver (then reads
+    download and ``assign``/``interpolate`` upload)."""
+
+    def __init__(self, space, name=None):
+        self._space = space
+        self._name = name
+        self._host = np.zeros((space.ncells, space.nd) + space.value_shape)
+        self._binding = None     # (HipBlock, field id)
+        self.dat = _Dat(self)
+
+    def name(self):
+        return self._name
+
+    def function_space(self):
+        return self._space
+
+    def _bind(self, block, field):
+        self._binding = (block, field)
+        self._host = None
+
+    def _get(self):
+        if self._binding is not None:
+            block, field = self._binding
+            return block.get_field(field)
+        return self._host
+
+    def _set(self, arr):
+        shape = (self._space.ncells, self._space.nd) + self._space.value_shape
+        arr = np.ascontiguousarray(np.broadcast_to(arr.reshape(shape) if arr.size == int(np.prod(shape)) else arr,
+                                                   shape), dtype=np.float64)
+        if self._binding is not None:
+            block, field = self._binding
+            block.set_field(field, arr)
+        else:
+            self._host = arr.copy()
+
+    def assign(self, other):
+        if isinstance(other, Function):
+            if other._space.ufl_element() != self._space.ufl_element():
+                raise ValueError("assign between different function spaces")
+            self._set(other._get())
+        else:
+            self._set(np.asarray(other, dtype=np.float64))
+        return self
+
+    def interpolate(self, expression):
+        """Nodal interpolation [upstream]: evaluate at the node coordinates."""
+        if callable(expression) and not isinstance(expression, Expression):
+            vals = np.asarray(expression(self._space.node_coords()), dtype=np.float64)
+        else:
+            if expression.value_shape != self._space.value_shape:
+                raise ValueError("Expression shape %r does not match the function space %r"
+                                 % (expression.value_shape, self._space.value_shape))
+            vals = expression.evaluate(self._space.node_coords())
+        self._set(vals)
+        return self
+
+    def vector(self):
+        return self.dat.data.ravel()

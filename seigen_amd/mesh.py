@@ -1,0 +1,150 @@
+"""Structured simplicial meshes: stand-ins for the Firedrake constructors the
+reference's harnesses call (``UnitSquareMesh`` ``tests/eigenmode/eigenmode_2d.py:11``,
+``UnitCubeMesh`` ``eigenmode_3d.py:11``, ``RectangleMesh``
+``tests/explosive_source/explosive_source_lf4.py:10``, ``IntervalMesh``
+``tests/pulse/pulse_1d_lf4.py``).
+
+[upstream] these are nx*ny(*nz) squares (cubes) cut into 2 triangles (6 Kuhn
+tetrahedra).  The mesh is never stored: cell/vertex numbering is implicit
+(DESIGN.md "Mesh and numbering") and libseigen_hip derives neighbours from it.
+
+Under ``torch.distributed`` (one process per GPU) the global mesh is split into
+a Cartesian grid of blocks; each rank's solver owns one block (``Partition``).
+"""
+import numpy as np
+
+
+def _factor_grid(world, dim, n):
+    """Process grid for `world` ranks: split the longest axes first."""
+    grid = [1] * dim
+    w = world
+    p = 2
+    factors = []
+    while w > 1:
+        while w % p == 0:
+            factors.append(p)
+            w //= p
+        p += 1
+    for f in sorted(factors, reverse=True):
+        # axis with the most cells per block left
+        ax = max(range(dim), key=lambda a: (n[a] / grid[a], -a))
+        grid[ax] *= f
+    return tuple(grid)
+
+
+class Partition(object):
+    """Block of a Cartesian split of the global cell grid."""
+
+    def __init__(self, n, rank=0, world=1, grid=None):
+        self.dim = len(n)
+        self.global_n = tuple(int(x) for x in n)
+        self.world = world
+        self.rank = rank
+        self.grid = tuple(grid) if grid is not None else _factor_grid(world, self.dim, self.global_n)
+        assert int(np.prod(self.grid)) == world, "process grid does not match world size"
+        for a in range(self.dim):
+            if self.grid[a] > self.global_n[a]:
+                raise ValueError("more blocks than cells along axis %d" % a)
+        self.coords = self.rank_to_coords(rank)
+        self.start, self.n = [], []
+        for a in range(self.dim):
+            lo, hi = self._range(a, self.coords[a])
+            self.start.append(lo)
+            self.n.append(hi - lo)
+        self.start, self.n = tuple(self.start), tuple(self.n)
+
+    def _range(self, axis, c):
+        n, g = self.global_n[axis], self.grid[axis]
+        base, rem = divmod(n, g)
+        lo = c * base + min(c, rem)
+        return lo, lo + base + (1 if c < rem else 0)
+
+    def rank_to_coords(self, rank):
+        c = []
+        for a in range(self.dim):
+            c.append(rank % self.grid[a])
+            rank //= self.grid[a]
+        return tuple(c)
+
+    def coords_to_rank(self, coords):
+        r, mul = 0, 1
+        for a in range(self.dim):
+            r += coords[a] * mul
+            mul *= self.grid[a]
+        return r
+
+    def neighbour(self, side):
+        """Rank across block side (2*axis + hi), or None at the domain boundary."""
+        axis, hi = side >> 1, side & 1
+        c = list(self.coords)
+        c[axis] += 1 if hi else -1
+        if c[axis] < 0 or c[axis] >= self.grid[axis]:
+            return None
+        return self.coords_to_rank(c)
+
+    @property
+    def nbr_mask(self):
+        m = 0
+        for s in range(2 * self.dim):
+            if self.neighbour(s) is not None:
+                m |= 1 << s
+        return m
+
+
+class Mesh(object):
+    def __init__(self, n, L, diagonal="left"):
+        self.dim = len(n)
+        self.n = tuple(int(x) for x in n)
+        self.L = tuple(float(x) for x in L)
+        if diagonal not in ("left", "right"):
+            raise ValueError("diagonal must be 'left' or 'right'")
+        self.diagonal = diagonal
+        self.h = tuple(l / k for l, k in zip(self.L, self.n))
+        self.origin = (0.0,) * self.dim
+        self._partition = None
+
+    @property
+    def partition(self):
+        """This rank's block (whole mesh when torch.distributed is not initialised)."""
+        if self._partition is None:
+            from .parallel import world
+            rank, size = world()
+            self._partition = Partition(self.n, rank, size)
+        return self._partition
+
+    def set_partition(self, partition):
+        self._partition = partition
+
+    def geometric_dimension(self):
+        return self.dim
+
+    @property
+    def cells_per_block(self):
+        return {1: 1, 2: 2, 3: 6}[self.dim]
+
+    def num_cells(self):
+        return int(np.prod(self.n)) * self.cells_per_block
+
+
+def IntervalMesh(ncells, length):
+    return Mesh((ncells,), (length,))
+
+
+def UnitIntervalMesh(ncells):
+    return Mesh((ncells,), (1.0,))
+
+
+def RectangleMesh(nx, ny, Lx, Ly, diagonal="left"):
+    return Mesh((nx, ny), (Lx, Ly), diagonal)
+
+
+def UnitSquareMesh(nx, ny, diagonal="left"):
+    return Mesh((nx, ny), (1.0, 1.0), diagonal)
+
+
+def BoxMesh(nx, ny, nz, Lx, Ly, Lz):
+    return Mesh((nx, ny, nz), (Lx, Ly, Lz))
+
+
+def UnitCubeMesh(nx, ny, nz):
+    return Mesh((nx, ny, nz), (1.0, 1.0, 1.0))

@@ -1,0 +1,102 @@
+"""Halo layer: facet-trace exchange between mesh blocks, one process per GPU.
+
+Replaces the implicit PyOP2/MPI halo exchange that runs inside every
+``assemble`` of the reference (``seigen/elastic.py:364``, ``:404-436``;
+``ParLoopHaloEnd`` in ``tests/tiling/utils.py:144``).  DG couples cells only
+through facets (the ``dS`` terms, ``elastic.py:206``, ``:213-215``), so per
+stage each block sends the traces of the stage's INPUT field on its block
+sides to its face neighbours (`torch.distributed` point-to-point: RCCL over
+xGMI on GPUs, gloo in the CPU tests) and meanwhile computes the cells that
+need no remote data.
+"""
+import os
+import sys
+
+from . import _lib
+
+# input field of each fused stage (include/seigen_hip.h, enum sg_stage)
+STAGE_INPUT = {
+    _lib.STAGE_UH1: _lib.FIELD_S,
+    _lib.STAGE_STEMP: _lib.FIELD_UH,
+    _lib.STAGE_U1: _lib.FIELD_SH,
+    _lib.STAGE_SH1: _lib.FIELD_U,
+    _lib.STAGE_UTEMP: _lib.FIELD_SH,
+    _lib.STAGE_S1: _lib.FIELD_UH,
+}
+
+
+def _dist():
+    if "torch" not in sys.modules and "WORLD_SIZE" not in os.environ:
+        return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist
+    return None
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) if none."""
+    dist = _dist()
+    if dist is None:
+        return 0, 1
+    return dist.get_rank(), dist.get_world_size()
+
+
+class HaloExchanger(object):
+    """Per-stage trace exchange for one block.
+
+    `block` needs: halo_bytes(field, side), halo_pack(field, side, ptr),
+    halo_attach(field, side, ptr), run_stage(stage, region), end_step().
+    Buffers are torch tensors on `device` so the same object serves RCCL
+    (device tensors) and gloo (CPU tensors)."""
+
+    def __init__(self, block, partition, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.block = block
+        self.part = partition
+        self.group = group
+        self.sides = [s for s in range(2 * partition.dim) if partition.neighbour(s) is not None]
+        self.send, self.recv = {}, {}
+        for kind, field in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S)):
+            for s in self.sides:
+                n = block.halo_bytes(field, s) // 8
+                self.send[(kind, s)] = torch.zeros(n, dtype=torch.float64, device=device)
+                self.recv[(kind, s)] = torch.zeros(n, dtype=torch.float64, device=device)
+        # both fields of a kind read the same ghost buffer: a buffer is consumed by the stage
+        # that follows its exchange before the next exchange of that kind starts
+        for field in (_lib.FIELD_U, _lib.FIELD_UH, _lib.FIELD_S, _lib.FIELD_SH):
+            kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+            for s in self.sides:
+                block.halo_attach(field, s, self.recv[(kind, s)].data_ptr())
+        self.bytes_sent = 0
+
+    def start(self, field):
+        """Pack the block-side traces of `field` and post the sends / receives."""
+        kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+        ops = []
+        for s in self.sides:
+            peer = self.part.neighbour(s)
+            self.block.halo_pack(field, s, self.send[(kind, s)].data_ptr())
+            ops.append(self.dist.P2POp(self.dist.isend, self.send[(kind, s)], peer, self.group))
+            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[(kind, s)], peer, self.group))
+            self.bytes_sent += self.send[(kind, s)].numel() * 8
+        if not ops:
+            return []
+        return self.dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def finish(reqs):
+        for r in reqs:
+            r.wait()
+
+    def step(self, nsteps=1):
+        """`nsteps` LF4 steps: per stage exchange || interior, then the boundary shell."""
+        for _ in range(int(nsteps)):
+            for stage in range(6):
+                reqs = self.start(STAGE_INPUT[stage])
+                self.block.run_stage(stage, _lib.REGION_INTERIOR)
+                self.finish(reqs)
+                self.block.run_stage(stage, _lib.REGION_BOUNDARY)
+            self.block.end_step()

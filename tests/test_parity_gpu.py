@@ -1,0 +1,110 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  FP64 everywhere; tolerance = 1e-11 relative to the largest
+entry of the expected field per operator application (different summation
+order only), looser bounds stated where many steps accumulate."""
+import numpy as np
+import pytest
+
+from oracle.forms import ElasticOperators
+from oracle.lf4 import OracleLF4
+from tests.util import oracle_mesh, rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+CASES = [
+    # dim, degree, n, L, diagonal
+    (1, 1, (7,), (2.0,), "left"),
+    (1, 3, (5,), (1.0,), "left"),
+    (2, 1, (4, 4), (1.0, 1.0), "left"),
+    (2, 2, (4, 3), (1.0, 1.5), "left"),
+    (2, 2, (3, 4), (2.0, 1.0), "right"),
+    (2, 3, (3, 3), (1.0, 1.0), "left"),
+    (2, 4, (4, 4), (1.0, 1.0), "left"),
+    (3, 1, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 2, (2, 3, 2), (1.0, 1.5, 0.5), "left"),
+    (3, 3, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 4, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 4, (3, 1, 2), (1.0, 1.0, 1.0), "left"),
+]
+
+
+def make_block(dim, degree, n, L, diagonal):
+    from seigen_amd.backend import HipBlock
+    h = [L[a] / n[a] for a in range(dim)]
+    return HipBlock(dim, degree, n, h, [0.0] * dim, diagonal)
+
+
+@pytest.mark.parametrize("dim,degree,n,L,diagonal", CASES)
+def test_node_coords_match_oracle(gpu, dim, degree, n, L, diagonal):
+    blk = make_block(dim, degree, n, L, diagonal)
+    m = oracle_mesh(dim, n, L, diagonal)
+    assert blk.ncells == m.ncells
+    np.testing.assert_allclose(blk.node_coords(), m.node_coords(degree), rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("dim,degree,n,L,diagonal", CASES)
+def test_apply_F_and_G(gpu, dim, degree, n, L, diagonal):
+    from seigen_amd import _lib
+    blk = make_block(dim, degree, n, L, diagonal)
+    m = oracle_mesh(dim, n, L, diagonal)
+    E = ElasticOperators(m, degree)
+    T = seeded(blk.field_shape(_lib.FIELD_S), 0)
+    u = seeded(blk.field_shape(_lib.FIELD_U), 1)
+    lam, mu = 0.7, 0.3
+    blk.set_params(1.0, 0.01, lam, mu)
+    blk.set_field(_lib.FIELD_S, T)
+    blk.set_field(_lib.FIELD_U, u)
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    got = blk.get_field(_lib.FIELD_UH)
+    exp = E.apply_F(T, u)
+    assert rel_err(got, exp) < TOL
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    got = blk.get_field(_lib.FIELD_SH)
+    exp = E.apply_G(u, lam, mu)
+    assert rel_err(got, exp) < TOL
+
+
+@pytest.mark.parametrize("dim,degree,n,L,diagonal", CASES)
+def test_full_steps(gpu, dim, degree, n, L, diagonal):
+    """Three whole LF4 steps (six fused launches each) against the un-fused oracle."""
+    from seigen_amd import _lib
+    blk = make_block(dim, degree, n, L, diagonal)
+    m = oracle_mesh(dim, n, L, diagonal)
+    orc = OracleLF4(m, degree)
+    hmin = min(L[a] / n[a] for a in range(dim))
+    orc.dt = 0.05 * hmin / degree ** 2
+    orc.l, orc.mu, orc.density = 0.5, 0.25, 1.0
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 2)
+    orc.s0 = seeded(blk.field_shape(_lib.FIELD_S), 3)
+    blk.set_params(orc.density, orc.dt, orc.l, orc.mu)
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(3)
+    for k in range(3):
+        orc.step((k + 1) * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+    # intermediate fields left behind by the last step
+    assert rel_err(blk.get_field(_lib.FIELD_UH), orc.last["utemp"]) < 10 * TOL
+    assert rel_err(blk.get_field(_lib.FIELD_SH), orc.last["sh1"]) < 10 * TOL
+
+
+def test_density_quirk(gpu):
+    """Explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + ... (elastic.py:341-345)."""
+    from seigen_amd import _lib
+    dim, degree, n, L = 2, 2, (3, 3), (1.0, 1.0)
+    blk = make_block(dim, degree, n, L, "left")
+    orc = OracleLF4(oracle_mesh(dim, n, L), degree)
+    orc.dt, orc.l, orc.mu, orc.density = 0.002, 0.5, 0.25, 1.7
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 4)
+    orc.s0 = seeded(blk.field_shape(_lib.FIELD_S), 5)
+    blk.set_params(orc.density, orc.dt, orc.l, orc.mu)
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(2)
+    orc.step(orc.dt)
+    orc.step(2 * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
