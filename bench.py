@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: M DoF-updates/s of the explicit velocity-stress LF4 step,
+3-D elastic eigenmode, P=4, on a structured tetrahedral mesh (BASELINE.json
+config 3: 64^3 cubes x 6 tets, P4, FP64), one mesh block per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full LF4 timestep (six fused HIP launches = the reference's
+eight solves + two assigns, seigen/elastic.py:291-304) over the whole mesh.
+DoF-updates = (U dofs + S dofs) * steps  (SURVEY.md 8d).  Weak scaling: every
+GPU owns an n^3-cube block.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def eigenmode3d_fields(X, t_u, t_s):
+    """Analytic eigenmode of tests/eigenmode/eigenmode_3d.py:30-40 (rho=1, mu=0.25)."""
+    mu, rho = 0.25, 1.0
+    A = math.sqrt(2 * rho * mu)
+    O = math.pi * math.sqrt(2 * mu / rho)
+    pi = math.pi
+    x, y, z = X[..., 0], X[..., 1], X[..., 2]
+    cx, cy, cz = np.cos(pi * x), np.cos(pi * y), np.cos(pi * z)
+    sx, sy, sz = np.sin(pi * x), np.sin(pi * y), np.sin(pi * z)
+    c, s = math.cos(O * t_u), math.sin(O * t_s)
+    u = np.stack([cx * (sy - sz) * c, cy * (sz - sx) * c, cz * (sx - sy) * c], axis=-1)
+    T = np.zeros(X.shape[:-1] + (3, 3))
+    T[..., 0, 0] = -A * sx * (sy - sz) * s
+    T[..., 1, 1] = -A * sy * (sz - sx) * s
+    T[..., 2, 2] = -A * sz * (sx - sy) * s
+    return u, T
+
+
+def fill_initial_condition(elastic, dt):
+    """Chunked (one z-layer of cubes at a time) nodal interpolation + upload."""
+    import ctypes as C
+    from seigen_amd import _lib
+    from seigen_amd.functionspace import block_config
+    blk = elastic.block
+    mesh = elastic.mesh
+    part = mesh.partition
+    nx, ny, nz = part.n
+    cells_per_layer = nx * ny * 6
+    lib = _lib.load()
+    for k in range(nz):
+        cfg = block_config(mesh, elastic.degree)
+        cfg.n[2] = 1
+        cfg.origin[2] = mesh.origin[2] + (part.start[2] + k) * mesh.h[2]
+        X = np.empty((cells_per_layer, blk.nd, 3))
+        _lib.check(lib.sg_block_node_coords(C.byref(cfg), elastic.degree, X.ctypes.data, X.nbytes))
+        u, T = eigenmode3d_fields(X, 0.0, dt / 2.0)
+        blk.set_field_range(_lib.FIELD_U, k * cells_per_layer, u)
+        blk.set_field_range(_lib.FIELD_S, k * cells_per_layer, T)
+
+
+def cpu_baseline(degree, budget_s=20.0):
+    """The oracle (numpy/scipy restatement of the reference path) timed on this
+    host: 3-D P4 eigenmode on N=6 (1296 tets), single thread.  Baseline only."""
+    from oracle import harness
+    N = 6
+    em = harness.Eigenmode3D(N, degree, 0.5 / N / 2 ** (degree - 1))
+    el = em.elastic
+    X = el.node_coords()
+    el.u0 = em.u_exact(X, 0.0)
+    el.s0 = em.s_exact(X, el.dt / 2.0)
+    el.step(el.dt)                      # warm-up
+    dofs = em.mesh.ncells * el.E.nd * 12
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        el.step((n + 2) * el.dt)
+        n += 1
+        if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": dofs * n / dt / 1e6, "unit": "M DoF-updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle (numpy/scipy CSR) 3D eigenmode N=%d P=%d, %d tets, %d steps in %.1f s"
+                      % (N, degree, em.mesh.ncells, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=64, help="cubes per axis per GPU (64 = BASELINE config 3)")
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import seigen_amd
+    from seigen_amd import ElasticLF4, BoxMesh
+    from seigen_amd.mesh import Partition, _factor_grid
+    import seigen_amd.helpers as helpers
+    helpers.log = lambda s: None
+    seigen_amd.elastic.log = lambda s: None
+
+    n, P = args.n, args.degree
+    grid = _factor_grid(world, 3, (n, n, n))
+    gn = tuple(n * g for g in grid)
+    # weak scaling: the unit cube eigenmode on an (n*gx, n*gy, n*gz) mesh of cell size 1/n
+    mesh = BoxMesh(gn[0], gn[1], gn[2], gn[0] / n, gn[1] / n, gn[2] / n)
+    mesh.set_partition(Partition(gn, rank, world, grid))
+    elastic = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False)
+    elastic.density, elastic.mu, elastic.l = 1.0, 0.25, 0.5
+    elastic.dt = 0.5 * (1.0 / n) / 2 ** (P - 1)
+    fill_initial_condition(elastic, elastic.dt)
+    elastic.setup()
+    blk = elastic.block
+    blk.set_source([], None)
+
+    def sync():
+        blk.sync()
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    elastic._advance(args.warmup)
+    sync()
+    blk.enable_timing(True)
+    c0 = blk.counters()
+    t0 = time.perf_counter()
+    elastic._advance(args.steps)
+    sync()
+    t1 = time.perf_counter()
+    c1 = blk.counters()
+    blk.enable_timing(False)
+    elapsed = t1 - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # sanity: the field must still be finite
+    probe = blk.get_field_range(seigen_amd._lib.FIELD_U, 0, 6)
+    assert np.isfinite(probe).all(), "non-finite solution"
+
+    d = 3
+    nodes = blk.ncells * blk.nd
+    dofs_per_gpu = blk.u_dofs + blk.s_dofs
+    total_dofs = dofs_per_gpu * world
+    value = total_dofs * args.steps / elapsed / 1e6
+
+    # dominant kernel: F launches are stages 0,2,4; G launches are 1,3,5
+    ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
+    nl = [c1["launches"][i] - c0["launches"][i] for i in range(6)]
+    words = [d * d + d, d + d * d, d * d + 3 * d, d + d * d, d * d + d, 3 * d * d + d]   # per node per launch
+    kern = {}
+    for name, stages in (("stage_kernel<3,%d,F>" % P, (0, 2, 4)), ("stage_kernel<3,%d,G>" % P, (1, 3, 5))):
+        tot_ms = sum(ms[i] for i in stages)
+        launches = sum(nl[i] for i in stages)
+        byts = sum(words[i] * nl[i] for i in stages) * nodes * 8.0
+        kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(launches, 1),
+                          gbs=byts / max(tot_ms, 1e-12) / 1e6)
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": kern[dom]["avg_ms"],
+            "kernels": {k: {"avg_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"]} for k, v in kern.items()},
+            "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9)}
+
+    if rank == 0:
+        out = {
+            "metric": "M DoF-updates/sec, 3D elastic P=%d" % P, "value": value, "unit": "M DoF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3D eigenmode, %dx%dx%d cubes x 6 tets (%d^3 per GPU), DG P%d, FP64, LF4"
+                                   % (gn[0], gn[1], gn[2], n, P),
+                       "cells": int(blk.ncells * world), "dofs": int(total_dofs),
+                       "block_grid": list(grid), "dt": elastic.dt},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

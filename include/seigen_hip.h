@@ -124,6 +124,10 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
 int sg_set_field(sg_handle* h, int field, const double* host, size_t nbytes);
 int sg_get_field(sg_handle* h, int field, double* host, size_t nbytes);
 
+/* the same for `ncells` consecutive cells starting at `cell0` (chunked transfer of large fields) */
+int sg_set_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, const double* host, size_t nbytes);
+int sg_get_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, size_t nbytes);
+
 /* ---- absorption (elastic.py:136-141, :207-208) ------------------------------------ */
 /* sigma_nodes: [cell][nd(sigma_degree)] nodal values of the DG_q sponge field, or NULL to disable. */
 int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree);

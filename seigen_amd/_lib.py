@@ -46,6 +46,8 @@ SYMBOLS = {
     "sg_set_params": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, C.c_int]),
     "sg_set_field": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "sg_get_field": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    "sg_set_field_range": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_size_t]),
+    "sg_get_field_range": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_size_t]),
     "sg_set_absorption": (C.c_int, [_P, _P, C.c_int]),
     "sg_set_source": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P]),
     "sg_step": (C.c_int, [_P, C.c_int64]),

@@ -74,6 +74,16 @@ class HipBlock(object):
         check(self.lib.sg_get_field(self.h, field, out.ctypes.data, out.nbytes), self.h)
         return out
 
+    def set_field_range(self, field, cell0, arr):
+        arr = _f64(arr)
+        ncells = arr.shape[0]
+        check(self.lib.sg_set_field_range(self.h, field, int(cell0), int(ncells), arr.ctypes.data, arr.nbytes), self.h)
+
+    def get_field_range(self, field, cell0, ncells):
+        out = np.empty((int(ncells),) + self.field_shape(field)[1:])
+        check(self.lib.sg_get_field_range(self.h, field, int(cell0), int(ncells), out.ctypes.data, out.nbytes), self.h)
+        return out
+
     def set_params(self, density, dt, lam, mu):
         lam_a, mu_a = _f64(np.atleast_1d(lam)).ravel(), _f64(np.atleast_1d(mu)).ravel()
         per_cell = int(lam_a.size > 1 or mu_a.size > 1)

@@ -50,6 +50,8 @@ struct sg_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
   bool timing = false;
+  std::vector<hipEvent_t> ev_pool;   // per-launch event pairs, resolved lazily (no sync in the hot loop)
+  std::vector<int> ev_stage;         // stage of pair k = events 2k, 2k+1
   sg_counters_t counters;
   std::string err;
 };
@@ -93,6 +95,7 @@ void sg_destroy(sg_handle* h) {
   if (h->src_values) (void)hipFree(h->src_values);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -292,6 +295,35 @@ int sg_get_field(sg_handle* h, int field, double* host, size_t nbytes) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   HIPCHECK(h, hipMemcpy(host, h->field[field], nbytes, hipMemcpyDeviceToHost));
+  return SG_OK;
+}
+
+static int field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, size_t nbytes, size_t* off, const char* who) {
+  if (!h || field < 0 || field > 3) return SG_ERR_ARG;
+  if (cell0 < 0 || ncells < 0 || cell0 + ncells > h->ncells) return fail(h, SG_ERR_ARG, std::string(who) + ": cell range out of bounds");
+  size_t per_cell = h->field_len[field] / (size_t)h->ncells;
+  if (nbytes != (size_t)ncells * per_cell * sizeof(double)) return fail(h, SG_ERR_ARG, std::string(who) + ": size mismatch");
+  *off = (size_t)cell0 * per_cell;
+  return SG_OK;
+}
+
+int sg_set_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, const double* host, size_t nbytes) {
+  size_t off = 0;
+  int rc = field_range(h, field, cell0, ncells, nbytes, &off, "sg_set_field_range");
+  if (rc != SG_OK || !host) return rc != SG_OK ? rc : SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, hipMemcpy(h->field[field] + off, host, nbytes, hipMemcpyHostToDevice));
+  return SG_OK;
+}
+
+int sg_get_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, size_t nbytes) {
+  size_t off = 0;
+  int rc = field_range(h, field, cell0, ncells, nbytes, &off, "sg_get_field_range");
+  if (rc != SG_OK || !host) return rc != SG_OK ? rc : SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, hipMemcpy(host, h->field[field] + off, nbytes, hipMemcpyDeviceToHost));
   return SG_OK;
 }
 
@@ -509,20 +541,43 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
   return fail(h, SG_ERR_ARG, "unknown stage");
 }
 
+static int resolve_timing(sg_handle* h) {
+  if (h->ev_stage.empty()) return SG_OK;
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  for (size_t k = 0; k < h->ev_stage.size(); ++k) {
+    float ms = 0;
+    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]));
+    h->counters.kernel_ms[h->ev_stage[k]] += ms;
+  }
+  h->ev_stage.clear();
+  return SG_OK;
+}
+
 int sg_run_stage(sg_handle* h, int stage, int region) {
   if (!h) return SG_ERR_ARG;
   if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
   if (region < 0 || region > 2) return fail(h, SG_ERR_ARG, "unknown region");
+  if (stage < 0 || stage > 5) return fail(h, SG_ERR_ARG, "unknown stage");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  if (h->timing) HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
+  size_t k = h->ev_stage.size();
+  if (h->timing) {
+    if (k >= 8192) {
+      int rc = resolve_timing(h);
+      if (rc != SG_OK) return rc;
+      k = 0;
+    }
+    while (h->ev_pool.size() < 2 * k + 2) {
+      hipEvent_t e;
+      HIPCHECK(h, hipEventCreate(&e));
+      h->ev_pool.push_back(e);
+    }
+    HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k], h->stream));
+  }
   int rc = run_stage_impl(h, stage, region);
   if (rc != SG_OK) return rc;
   if (h->timing) {
-    HIPCHECK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHECK(h, hipEventSynchronize(h->ev1));
-    float ms = 0;
-    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->counters.kernel_ms[stage] += ms;
+    HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k + 1], h->stream));
+    h->ev_stage.push_back(stage);
   }
   h->counters.launches[stage] += 1;
   return SG_OK;
@@ -623,12 +678,19 @@ int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in) {
 
 int sg_enable_timing(sg_handle* h, int on) {
   if (!h) return SG_ERR_ARG;
+  if (!on) {
+    int rc = resolve_timing(h);
+    if (rc != SG_OK) return rc;
+  }
   h->timing = on != 0;
   return SG_OK;
 }
 
 int sg_get_counters(sg_handle* h, sg_counters_t* out) {
   if (!h || !out) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  int rc = resolve_timing(h);
+  if (rc != SG_OK) return rc;
   *out = h->counters;
   return SG_OK;
 }
