@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +14,7 @@
 #include "../../include/seigen_hip.h"
 #include "kernels.hpp"
 #include "mesh_tables.hpp"
+#include "mfma_tables.hpp"
 #include "refelem.hpp"
 
 using namespace sg;
@@ -24,7 +27,14 @@ struct sg_handle {
   double* Dt = nullptr;
   double* Lt = nullptr;
   double* field[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t field_len[4] = {0, 0, 0, 0};  // doubles
+  size_t field_len[4] = {0, 0, 0, 0};    // doubles, host layout (ncells * nd * comps)
+  size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
+  bool use_mfma = false;
+  double* fragF = nullptr;  // MFMA operator fragment tables (device)
+  double* fragG = nullptr;
+  double* fragL = nullptr;
+  double* staging = nullptr;  // host-layout staging buffer for layout conversion
+  size_t staging_len = 0;
   int64_t ncells = 0;
   int ncls = 0;
   // parameters
@@ -87,6 +97,10 @@ void sg_destroy(sg_handle* h) {
   if (h->md_dev) (void)hipFree(h->md_dev);
   if (h->Dt) (void)hipFree(h->Dt);
   if (h->Lt) (void)hipFree(h->Lt);
+  if (h->fragF) (void)hipFree(h->fragF);
+  if (h->fragG) (void)hipFree(h->fragG);
+  if (h->fragL) (void)hipFree(h->fragL);
+  if (h->staging) (void)hipFree(h->staging);
   if (h->lam_d) (void)hipFree(h->lam_d);
   if (h->mu_d) (void)hipFree(h->mu_d);
   if (h->sponge_slot) (void)hipFree(h->sponge_slot);
@@ -132,6 +146,12 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   for (int s = 0; s < 6; ++s) h->md.has_nbr[s] = (s < 2 * cfg->dim) ? ((cfg->nbr_mask >> s) & 1) : 0;
   h->ncls = h->md.ncls;
   h->ncells = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2] * h->ncls;
+  // kernel path: MFMA kernels (interleaved layout) where they exist, unless SEIGEN_HIP_PATH=generic
+  const char* path_env = std::getenv("SEIGEN_HIP_PATH");
+  h->use_mfma = mfma_supported(cfg->dim, cfg->degree) && !(path_env && std::strcmp(path_env, "generic") == 0);
+  h->md.gw = h->use_mfma ? 16 : 1;
+  h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
+  h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
   for (int f = 0; f < 4; ++f)
     for (int s = 0; s < 6; ++s) h->ghost[f][s] = nullptr;
   std::memset(&h->counters, 0, sizeof(h->counters));
@@ -155,9 +175,19 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   for (int f = 0; f < 4; ++f) {
     size_t comps = field_is_stress(f) ? (size_t)d * d : (size_t)d;
     h->field_len[f] = (size_t)h->ncells * nd * comps;
-    if (hipMalloc((void**)&h->field[f], h->field_len[f] * sizeof(double)) != hipSuccess)
+    h->field_alloc[f] = (size_t)h->md.ncube_pad * h->ncls * nd * comps;
+    if (hipMalloc((void**)&h->field[f], h->field_alloc[f] * sizeof(double)) != hipSuccess)
       return fail(h, SG_ERR_NOMEM, "hipMalloc of a field buffer failed");
-    HIPCHECK(h, hipMemset(h->field[f], 0, h->field_len[f] * sizeof(double)));
+    HIPCHECK(h, hipMemset(h->field[f], 0, h->field_alloc[f] * sizeof(double)));
+  }
+  if (h->use_mfma) {
+    std::vector<double> fF = mfma_frags_F(h->re), fG = mfma_frags_G(h->re), fL = mfma_frags_L(h->re);
+    HIPCHECK(h, hipMalloc((void**)&h->fragF, fF.size() * sizeof(double)));
+    HIPCHECK(h, hipMalloc((void**)&h->fragG, fG.size() * sizeof(double)));
+    HIPCHECK(h, hipMalloc((void**)&h->fragL, fL.size() * sizeof(double)));
+    HIPCHECK(h, hipMemcpy(h->fragF, fF.data(), fF.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (cfg->stream) {
     h->stream = (hipStream_t)cfg->stream;
@@ -280,51 +310,76 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
   return SG_OK;
 }
 
+// Copy `ncells` cells from `cell0` between a host array in the reference layout and the device
+// field.  gw == 1: the layouts coincide; otherwise go through a staging buffer + layout kernel.
+static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, bool to_device) {
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  const size_t per_cell = h->field_len[field] / (size_t)h->ncells;
+  if (h->md.gw == 1) {
+    double* dev = h->field[field] + (size_t)cell0 * per_cell;
+    size_t nb = (size_t)ncells * per_cell * sizeof(double);
+    if (to_device)
+      HIPCHECK(h, hipMemcpy(dev, host, nb, hipMemcpyHostToDevice));
+    else
+      HIPCHECK(h, hipMemcpy(host, dev, nb, hipMemcpyDeviceToHost));
+    return SG_OK;
+  }
+  const size_t cap_cells = std::max<size_t>(1, ((size_t)32 << 20) / per_cell);  // 256 MB staging
+  if (!h->staging) {
+    h->staging_len = std::min(cap_cells, (size_t)h->ncells) * per_cell;
+    HIPCHECK(h, hipMalloc((void**)&h->staging, h->staging_len * sizeof(double)));
+  }
+  const size_t chunk = h->staging_len / per_cell;
+  const int comps = (int)(per_cell / h->re.nd);
+  for (int64_t done = 0; done < ncells; done += (int64_t)chunk) {
+    int64_t n = std::min<int64_t>((int64_t)chunk, ncells - done);
+    size_t nb = (size_t)n * per_cell * sizeof(double);
+    if (to_device) {
+      HIPCHECK(h, hipMemcpy(h->staging, host + (size_t)done * per_cell, nb, hipMemcpyHostToDevice));
+      if (launch_layout(h->md, comps, 0, h->field[field], h->staging, cell0 + done, n, h->stream) != 0)
+        return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
+      HIPCHECK(h, hipStreamSynchronize(h->stream));
+    } else {
+      if (launch_layout(h->md, comps, 1, h->field[field], h->staging, cell0 + done, n, h->stream) != 0)
+        return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
+      HIPCHECK(h, hipStreamSynchronize(h->stream));
+      HIPCHECK(h, hipMemcpy(host + (size_t)done * per_cell, h->staging, nb, hipMemcpyDeviceToHost));
+    }
+  }
+  return SG_OK;
+}
+
 int sg_set_field(sg_handle* h, int field, const double* host, size_t nbytes) {
   if (!h || !host || field < 0 || field > 3) return SG_ERR_ARG;
   if (nbytes != h->field_len[field] * sizeof(double)) return fail(h, SG_ERR_ARG, "sg_set_field: size mismatch");
-  HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  HIPCHECK(h, hipMemcpy(h->field[field], host, nbytes, hipMemcpyHostToDevice));
-  return SG_OK;
+  return transfer(h, field, 0, h->ncells, const_cast<double*>(host), true);
 }
 
 int sg_get_field(sg_handle* h, int field, double* host, size_t nbytes) {
   if (!h || !host || field < 0 || field > 3) return SG_ERR_ARG;
   if (nbytes != h->field_len[field] * sizeof(double)) return fail(h, SG_ERR_ARG, "sg_get_field: size mismatch");
-  HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  HIPCHECK(h, hipMemcpy(host, h->field[field], nbytes, hipMemcpyDeviceToHost));
-  return SG_OK;
+  return transfer(h, field, 0, h->ncells, host, false);
 }
 
-static int field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, size_t nbytes, size_t* off, const char* who) {
+static int field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, size_t nbytes, const char* who) {
   if (!h || field < 0 || field > 3) return SG_ERR_ARG;
   if (cell0 < 0 || ncells < 0 || cell0 + ncells > h->ncells) return fail(h, SG_ERR_ARG, std::string(who) + ": cell range out of bounds");
   size_t per_cell = h->field_len[field] / (size_t)h->ncells;
   if (nbytes != (size_t)ncells * per_cell * sizeof(double)) return fail(h, SG_ERR_ARG, std::string(who) + ": size mismatch");
-  *off = (size_t)cell0 * per_cell;
   return SG_OK;
 }
 
 int sg_set_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, const double* host, size_t nbytes) {
-  size_t off = 0;
-  int rc = field_range(h, field, cell0, ncells, nbytes, &off, "sg_set_field_range");
+  int rc = field_range(h, field, cell0, ncells, nbytes, "sg_set_field_range");
   if (rc != SG_OK || !host) return rc != SG_OK ? rc : SG_ERR_ARG;
-  HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  HIPCHECK(h, hipMemcpy(h->field[field] + off, host, nbytes, hipMemcpyHostToDevice));
-  return SG_OK;
+  return transfer(h, field, cell0, ncells, const_cast<double*>(host), true);
 }
 
 int sg_get_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, size_t nbytes) {
-  size_t off = 0;
-  int rc = field_range(h, field, cell0, ncells, nbytes, &off, "sg_get_field_range");
+  int rc = field_range(h, field, cell0, ncells, nbytes, "sg_get_field_range");
   if (rc != SG_OK || !host) return rc != SG_OK ? rc : SG_ERR_ARG;
-  HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  HIPCHECK(h, hipMemcpy(host, h->field[field] + off, nbytes, hipMemcpyDeviceToHost));
-  return SG_OK;
+  return transfer(h, field, cell0, ncells, host, false);
 }
 
 int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree) {
@@ -400,7 +455,17 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   size_t vbytes = (size_t)nsteps * nnz * d * d * sizeof(double);
   HIPCHECK(h, hipMalloc((void**)&h->src_nodes, (size_t)nnz * sizeof(int64_t)));
   HIPCHECK(h, hipMalloc((void**)&h->src_values, vbytes));
-  HIPCHECK(h, hipMemcpy(h->src_nodes, nodes, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+  // device offset of component 0 of each source node in the field layout (mesh_tables.hpp)
+  std::vector<int64_t> offs((size_t)nnz);
+  {
+    const int64_t nd = h->re.nd, ncls = h->ncls, gw = h->md.gw, nc = (int64_t)d * d;
+    for (int64_t i = 0; i < nnz; ++i) {
+      int64_t e = nodes[i] / nd, b = nodes[i] % nd;
+      int64_t cube = e / ncls, cls = e % ncls;
+      offs[(size_t)i] = ((((cube / gw) * ncls + cls) * nd + b) * nc) * gw + cube % gw;
+    }
+  }
+  HIPCHECK(h, hipMemcpy(h->src_nodes, offs.data(), (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
   HIPCHECK(h, hipMemcpy(h->src_values, values, vbytes, hipMemcpyHostToDevice));
   h->src_nnz = nnz;
   h->src_nsteps = nsteps;
@@ -476,6 +541,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.Dt = h->Dt;
   a.Lt = h->Lt;
   a.md = h->md_dev;
+  a.fragV = (kind == 0) ? h->fragF : h->fragG;
+  a.fragL = h->fragL;
   a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
   a.sponge_B = h->sponge_B;
   a.lam = h->lam_d;
@@ -497,7 +564,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       empty = empty || (b.n[k] <= 0);
     }
     if (empty) continue;
-    int rc = launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
+    int rc = h->use_mfma ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
+                         : launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
     if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
   }
   return SG_OK;
@@ -507,7 +575,7 @@ static int add_source(sg_handle* h, int field, double coef) {
   if (h->src_nnz == 0 || h->src_step >= h->src_nsteps) return SG_OK;
   const int d = h->cfg.dim;
   const double* vals = h->src_values + (size_t)h->src_step * h->src_nnz * d * d;
-  int rc = launch_source(h->field[field], d * d, h->src_nnz, h->src_nodes, vals, coef, h->stream);
+  int rc = launch_source(h->field[field], d * d, h->md.gw, h->src_nnz, h->src_nodes, vals, coef, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
   return SG_OK;
 }

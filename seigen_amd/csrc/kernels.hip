@@ -359,8 +359,9 @@ __global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, i
           cls = k;
           f = ff;
         }
-    long g = cube * ncls + cls;
-    out[idx] = field[(g * nd + md->fnode[f][b]) * ncomp + cpt];
+    const int gw = md->gw;
+    long off = ((((cube / gw) * ncls + cls) * (long)nd + md->fnode[f][b]) * ncomp + cpt) * gw + cube % gw;
+    out[idx] = field[off];
   }
 }
 
@@ -383,21 +384,50 @@ int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& mh, const 
 }
 
 // ---- sparse source ----------------------------------------------------------------------
-__global__ void source_kernel(double* field, int ncomp, long nnz, const int64_t* nodes, const double* pattern,
+__global__ void source_kernel(double* field, int ncomp, int gw, long nnz, const int64_t* offs, const double* values,
                               double coef) {
   long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= nnz * ncomp) return;
   long k = idx / ncomp;
   int c = (int)(idx - k * ncomp);
-  field[nodes[k] * ncomp + c] += coef * pattern[idx];
+  field[offs[k] + (long)c * gw] += coef * values[idx];
 }
 
-int launch_source(double* field, int ncomp, int64_t nnz, const int64_t* nodes, const double* pattern, double coef,
+int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
                   void* stream) {
   if (nnz <= 0) return 0;
   long total = nnz * ncomp;
   hipLaunchKernelGGL(source_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, field,
-                     ncomp, (long)nnz, nodes, pattern, coef);
+                     ncomp, gw, (long)nnz, offs, values, coef);
+  return (int)hipGetLastError();
+}
+
+// ---- host <-> device layout ------------------------------------------------------------------
+__global__ void layout_kernel(int nd, int ncls, int gw, int ncomp, int dir, double* field, double* staging, long cell0,
+                              long ncells) {
+  const long per_cell = (long)nd * ncomp;
+  const long total = ncells * per_cell;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long e = cell0 + idx / per_cell;
+    long rem = idx % per_cell;
+    long cube = e / ncls;
+    int cls = (int)(e % ncls);
+    long off = (((cube / gw) * ncls + cls) * per_cell + rem) * gw + cube % gw;
+    if (dir == 0)
+      field[off] = staging[idx];
+    else
+      staging[idx] = field[off];
+  }
+}
+
+int launch_layout(const MeshDev& mh, int ncomp, int dir, double* field, double* staging, int64_t cell0, int64_t ncells,
+                  void* stream) {
+  if (ncells <= 0) return 0;
+  long total = ncells * (long)mh.nd * ncomp;
+  long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(layout_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.nd, mh.ncls, mh.gw, ncomp,
+                     dir, field, staging, (long)cell0, (long)ncells);
   return (int)hipGetLastError();
 }
 

@@ -15,6 +15,8 @@ struct StageArgs {
   const double* Dt;        // [dim][nd(b)][nd(a)]  transposed Mhat^-1 Shat_r
   const double* Lt;        // [nfaces][nf(b')][nd(a)] transposed facet lifts
   const MeshDev* md;       // device copy
+  const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
+  const double* fragL;     // MFMA path: facet-lift operator fragments
   const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
   const double* sponge_B;      // [slot][nd(a)][nd(b)]
   const double* lam;           // per-cell (per_cell=1) or null
@@ -29,12 +31,21 @@ struct StageArgs {
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)
 int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream);
 
+// MFMA path (3-D, degree >= 3; fields in the gw = 16 interleaved layout)
+bool mfma_supported(int dim, int P);
+int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream);
+
+// host layout [cell][node][comp] <-> device layout (MeshDev::gw) for `ncells` cells from `cell0`
+// dir = 0: staging -> field, 1: field -> staging
+int launch_layout(const MeshDev& md_host, int ncomp, int dir, double* field, double* staging, int64_t cell0,
+                  int64_t ncells, void* stream);
+
 // facet traces of a field on one block side -> packed device buffer
 int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& md_host, const double* field, int ncomp, int side,
                 double* out, void* stream);
 
-// field[node][c] += coef * pattern[k][c] at the sparse source nodes
-int launch_source(double* field, int ncomp, int64_t nnz, const int64_t* nodes, const double* pattern, double coef,
+// field[off[k] + c*gw] += coef * values[k][c] at the sparse source nodes (off = device offset of comp 0)
+int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
                   void* stream);
 
 }  // namespace sg

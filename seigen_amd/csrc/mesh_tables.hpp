@@ -22,7 +22,14 @@ struct MeshDev {
   int32_t n[3];          // cubes per axis of this block
   int32_t has_nbr[6];    // side (2*axis+hi) touches another block
   int32_t halo_per_cube; // cell-facets per boundary cube on one side (1, 1, 2 for dim 1, 2, 3)
-  int32_t pad0;
+  // HBM layout of a field: cubes are grouped `gw` at a time along the linear cube index and
+  // the group's cells are interleaved:
+  //   offset(cube c, class k, node b, comp) = ((((c/gw)*ncls + k)*nd + b)*ncomp + comp)*gw + c%gw
+  // gw = 1 is the host (reference) layout [cell][node][comp]; gw = 16 makes 16 cells' values
+  // of one (node, comp) a 128-byte line = one MFMA B-operand row / accumulator row.
+  int32_t gw;
+  int64_t ncube;      // cubes in this block
+  int64_t ncube_pad;  // rounded up to a multiple of gw
   double Jinv[MAX_CLS][3][3];        // [cls][r][j] = d xi_r / d x_j
   double cn[MAX_CLS][MAX_FACES][3];  // (|F|/|detJ|) * outward normal
   int32_t nb_axis[MAX_CLS][MAX_FACES];  // axis crossed by the facet, -1: neighbour in the same cube

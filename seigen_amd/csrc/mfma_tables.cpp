@@ -1,0 +1,68 @@
+#include "mfma_tables.hpp"
+
+#include <cstddef>
+using std::size_t;
+
+namespace sg {
+
+MfmaGeom mfma_geom(const RefElem& re) {
+  MfmaGeom g;
+  g.nd = re.nd;
+  g.nf = re.nf;
+  g.ks = (re.nd + 3) / 4;
+  g.ksf = (re.nf + 3) / 4;
+  g.mtl = (re.nd + 15) / 16;
+  g.s4 = (re.nd + 3) / 4;
+  g.mtg = (3 * 4 * g.s4 + 15) / 16;
+  return g;
+}
+
+static inline double Dval(const RefElem& re, int r, int a, int b) {
+  if (a >= re.nd || b >= re.nd) return 0.0;
+  return re.D[((size_t)r * re.nd + a) * re.nd + b];
+}
+
+std::vector<double> mfma_frags_F(const RefElem& re) {
+  MfmaGeom g = mfma_geom(re);
+  std::vector<double> out((size_t)g.mtl * 3 * g.ks * 64, 0.0);
+  for (int t = 0; t < g.mtl; ++t)
+    for (int r = 0; r < 3; ++r)
+      for (int k0 = 0; k0 < g.ks; ++k0) {
+        size_t frag = (size_t)t * 3 * g.ks + (size_t)g.ks * r + k0;
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = -Dval(re, r, 16 * t + (l & 15), 4 * k0 + (l >> 4));
+      }
+  return out;
+}
+
+std::vector<double> mfma_frags_G(const RefElem& re) {
+  MfmaGeom g = mfma_geom(re);
+  const int S = 4 * g.s4;
+  std::vector<double> out((size_t)g.mtg * g.ks * 64, 0.0);
+  for (int t = 0; t < g.mtg; ++t)
+    for (int k0 = 0; k0 < g.ks; ++k0) {
+      size_t frag = (size_t)t * g.ks + k0;
+      for (int l = 0; l < 64; ++l) {
+        int rho = 16 * t + (l & 15);
+        int r = rho / S, a = rho % S;
+        out[frag * 64 + l] = (r < 3) ? Dval(re, r, a, 4 * k0 + (l >> 4)) : 0.0;
+      }
+    }
+  return out;
+}
+
+std::vector<double> mfma_frags_L(const RefElem& re) {
+  MfmaGeom g = mfma_geom(re);
+  std::vector<double> out((size_t)re.nfaces * g.mtl * g.ksf * 64, 0.0);
+  for (int f = 0; f < re.nfaces; ++f)
+    for (int t = 0; t < g.mtl; ++t)
+      for (int k0 = 0; k0 < g.ksf; ++k0) {
+        size_t frag = ((size_t)f * g.mtl + t) * g.ksf + k0;
+        for (int l = 0; l < 64; ++l) {
+          int a = 16 * t + (l & 15), b = 4 * k0 + (l >> 4);
+          out[frag * 64 + l] = (a < re.nd && b < re.nf) ? re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
+        }
+      }
+  return out;
+}
+
+}  // namespace sg

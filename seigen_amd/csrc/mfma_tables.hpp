@@ -1,0 +1,35 @@
+// Host-side construction of the MFMA A-operand fragment tables for the 3-D
+// high-order stage kernels (kernels_mfma.hip).
+//
+// v_mfma_f64_16x16x4_f64 takes A as one f64 per lane: lane l holds
+// A[row = l & 15][k = l >> 4].  A table is a list of 16x4 tiles ("fragments"),
+// each stored as 64 consecutive doubles in lane order, so a wave fetches a
+// fragment with one conflict-free ds_read_b64.
+#pragma once
+#include <vector>
+
+#include "refelem.hpp"
+
+namespace sg {
+
+struct MfmaGeom {
+  int nd, nf;
+  int ks;    // k-steps over the element nodes  = ceil(nd / 4)
+  int ksf;   // k-steps over the facet nodes    = ceil(nf / 4)
+  int mtl;   // 16-row tiles over the nodes     = ceil(nd / 16)
+  int s4;    // row-quads per stacked D_r block = ceil(nd / 4)
+  int mtg;   // 16-row tiles of the stacked [D_0; D_1; D_2] (stride 4*s4 rows per block)
+};
+
+MfmaGeom mfma_geom(const RefElem& re);
+
+// F volume: out = sum_r (-D_r) T~_r  as one product with K = 3 * (4*ks):
+//   frag (t, kk), kk = ks*r + k0:  A[row][col] = -D_r[16 t + row][4 k0 + col]
+std::vector<double> mfma_frags_F(const RefElem& re);
+// G volume: rows stacked rho = 4*s4*r + a:
+//   frag (t, k0): A[row][col] = D_r[a][4 k0 + col],  rho = 16 t + row
+std::vector<double> mfma_frags_G(const RefElem& re);
+// facet lifts (shared by F and G): frag ((f*mtl + t)*ksf + k0): A[row][col] = L_f[16 t + row][4 k0 + col]
+std::vector<double> mfma_frags_L(const RefElem& re);
+
+}  // namespace sg
