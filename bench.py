@@ -185,7 +185,8 @@ def main():
             "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
             "avg_launch_ms": kern[dom]["avg_ms"],
             "kernels": {k: {"avg_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"]} for k, v in kern.items()},
-            "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9)}
+            "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9),
+            "stage_avg_ms": [ms[i] / max(nl[i], 1) for i in range(6)]}
 
     if rank == 0:
         out = {

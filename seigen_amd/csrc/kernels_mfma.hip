@@ -13,6 +13,9 @@
 // rows are exactly the 128-byte lines of the layout, so operands are loaded
 // from and results stored to HBM/L2 directly in fragment form - no LDS staging
 // of cell data.  The operator tiles live in LDS in lane order (mfma_tables.cpp).
+//
+// Loads are software-pipelined by hand (PF k-steps ahead): hipcc otherwise issues
+// each B operand right before the MFMA that consumes it and waits for it.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -33,9 +36,9 @@ struct MG {
   static constexpr int NFRAG_F = MTL * 3 * KS;
   static constexpr int NFRAG_G = MTG * KS;
   static constexpr int NFRAG_L = 4 * MTL * KSF;
-  static constexpr int NCLS = 6;
-  static constexpr int GW = 16;
 };
+
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 struct LaneGeo {
   long c;      // linear cube index of this lane's cell
@@ -65,46 +68,41 @@ struct NbrRef {
   const double* p;  // base pointer of the neighbour cell (or ghost slot)
   int cstride;      // stride between (node, comp) entries: 16 in a field, 1 in a packed ghost buffer
   bool ghost;
-  bool physical;    // domain boundary: no neighbour
+  bool physical;    // domain boundary: no neighbour (p then points at the own cell)
 };
 
 template <int ND, int NF, int NC>
-__device__ __forceinline__ NbrRef nbr_ref(const MeshDev* md, const StageArgs& A, const LaneGeo& L, long g, int k, int f,
+__device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A, const LaneGeo& L, long g, int k, int f,
                                           int w, const double* own_base) {
   NbrRef R;
   R.p = own_base;
   R.cstride = 16;
   R.ghost = false;
   R.physical = false;
-  const int axis = md->nb_axis[k][f];
-  const int kn = md->nb_cls[k][f];
+  const int axis = md.nb_axis[k][f];
+  const int kn = md.nb_cls[k][f];
   if (axis < 0) {
     R.p = A.in + ((g * 6 + kn) * (long)ND) * NC * 16 + w;
     return R;
   }
-  const int dir = md->nb_dir[k][f];
+  const int dir = md.nb_dir[k][f];
   const int cn = L.cc[axis] + dir;
-  if (!L.valid) {
-    R.physical = true;
-    return R;
-  }
-  if (cn >= 0 && cn < md->n[axis]) {
-    long stride = (axis == 0) ? 1 : (axis == 1) ? md->n[0] : (long)md->n[0] * md->n[1];
-    long nc = L.c + dir * stride;
-    R.p = A.in + (((nc >> 4) * 6 + kn) * (long)ND) * NC * 16 + (nc & 15);
-    return R;
-  }
+  const bool inside = L.valid && cn >= 0 && cn < md.n[axis];
+  const long stride = (axis == 0) ? 1 : (axis == 1) ? md.n[0] : (long)md.n[0] * md.n[1];
+  const long nc = inside ? L.c + dir * stride : L.c;
+  const double* pin = A.in + (((nc >> 4) * 6 + (inside ? kn : k)) * (long)ND) * NC * 16 + (nc & 15);
   const int side = 2 * axis + (dir > 0 ? 1 : 0);
-  if (md->has_nbr[side]) {
-    long c2 = (axis == 0) ? (L.cc[1] + (long)md->n[1] * L.cc[2])
-                          : (axis == 1) ? (L.cc[0] + (long)md->n[0] * L.cc[2]) : (L.cc[0] + (long)md->n[0] * L.cc[1]);
-    long slot = c2 * md->halo_per_cube + md->face_ord[kn][md->nb_face[k][f]];
+  if (!inside && L.valid && md.has_nbr[side]) {
+    long c2 = (axis == 0) ? (L.cc[1] + (long)md.n[1] * L.cc[2])
+                          : (axis == 1) ? (L.cc[0] + (long)md.n[0] * L.cc[2]) : (L.cc[0] + (long)md.n[0] * L.cc[1]);
+    long slot = c2 * md.halo_per_cube + md.face_ord[kn][md.nb_face[k][f]];
     R.p = A.ghost[side] + slot * NF * NC;
     R.cstride = 1;
     R.ghost = true;
     return R;
   }
-  R.physical = true;
+  R.p = pin;
+  R.physical = !inside;
   return R;
 }
 
@@ -126,54 +124,82 @@ __device__ __forceinline__ ItemRange item_range(long nitems, int wave) {
   return r;
 }
 
+template <int NV, int NL>
+__device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* sMd, const StageArgs& A) {
+  for (int i = threadIdx.x; i < NV * 64; i += 256) sAV[i] = A.fragV[i];
+  for (int i = threadIdx.x; i < NL * 64; i += 256) sAL[i] = A.fragL[i];
+  const int* src = reinterpret_cast<const int*>(A.md);
+  int* dst = reinterpret_cast<int*>(sMd);
+  for (int i = threadIdx.x; i < (int)(sizeof(MeshDev) / sizeof(int)); i += 256) dst[i] = src[i];
+  __syncthreads();
+}
+
 // --------------------------------------------------------------------------------------------
 //  G: sh_ij = lam d_ij W_kk + mu (W_ij + W_ji),  W_ik = -Jinv_rk (D_r u_i) + sum_f (c n)_k L_f u^_i
+//  Volume rows are stacked rho = 4*S4*r + a (mfma_tables.cpp) so that the three D_r u_i of
+//  one node sit in the same lane; only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
 // --------------------------------------------------------------------------------------------
-template <int P>
+template <int P, int MODE>
 __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL, S4 = M::S4, MTG = M::MTG;
+  constexpr int PF = 3;  // B-operand prefetch distance, in k-steps
   __shared__ double sAV[M::NFRAG_G * 64];
   __shared__ double sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
-  for (int i = threadIdx.x; i < M::NFRAG_G * 64; i += 256) sAV[i] = A.fragV[i];
-  for (int i = threadIdx.x; i < M::NFRAG_L * 64; i += 256) sAL[i] = A.fragL[i];
-  {
-    const int* src = reinterpret_cast<const int*>(A.md);
-    int* dst = reinterpret_cast<int*>(&sMd);
-    for (int i = threadIdx.x; i < (int)(sizeof(MeshDev) / sizeof(int)); i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
+  load_tables<M::NFRAG_G, M::NFRAG_L>(sAV, sAL, &sMd, A);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, w = lane & 15;
   const MeshDev* md = A.md;  // uniform reads of class constants go through the scalar cache
+  const double* __restrict__ in = A.in;
+  const double* __restrict__ aux = A.aux;
+  double* __restrict__ out = A.out;
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range(ngroups * 6, wave);
+
+  // node index of this lane's B row per k-step; rows past ND meet all-zero operator columns,
+  // so any finite value will do there: clamp instead of branching
+  int bnode[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 3 * 16;
 
   for (long item = ir.lo; item < ir.hi; item += ir.step) {
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
-    const double* own = A.in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    const double* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    // operator tiles are item-invariant: keep the compiler from hoisting all of them into registers
+    const double* pAV = sAV + lane;
+    const double* pAL = sAL + lane;
+    asm volatile("" : "+v"(pAV), "+v"(pAL));
 
-    double Sd[3][S4], So[3][S4];  // diagonal W_ii and symmetric sums W_ij + W_ji ((0,1),(0,2),(1,2))
+    double Jm[3][3], cnf[4][3];  // class constants (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Jm[r][j] = -md->Jinv[k][r][j];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cnf[f][j] = md->cn[k][f][j];
+
+    double Sd[3][S4], So[3][S4];  // W_ii and W_ij + W_ji for (0,1), (0,2), (1,2)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = 0.0;
 
-    // ---- volume: B fragments = the cells' own nodal values, straight from memory
+    // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead
     {
-      double bf[KS][3];
+      constexpr int NS = MTG * KS;
+      double bq[PF][3];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int b = 4 * ks + q;
+      for (int s = 0; s < PF; ++s)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) bf[ks][i] = (b < ND) ? own[(b * 3 + i) * 16] : 0.0;
-      }
+        for (int i = 0; i < 3; ++i) bq[s][i] = own[bnode[s % KS] + i * 16];
 #pragma unroll
       for (int t = 0; t < MTG; ++t) {
         d4 acc[3];
@@ -181,9 +207,17 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         for (int i = 0; i < 3; ++i) acc[i] = d4{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const double a = sAV[(t * KS + ks) * 64 + lane];
+          const int s = t * KS + ks;
+          double b[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[ks][i], acc[i], 0, 0, 0);
+          for (int i = 0; i < 3; ++i) b[i] = bq[s % PF][i];
+          if (s + PF < NS) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bq[s % PF][i] = own[bnode[(s + PF) % KS] + i * 16];
+          }
+          const double a = pAV[(t * KS + ks) * 64];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[i] = MFMA64(a, b[i], acc[i]);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -195,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
               const double v = acc[i][reg];
 #pragma unroll
               for (int kk = 0; kk < 3; ++kk) {
-                const double wv = -md->Jinv[k][r][kk] * v;
+                const double wv = Jm[r][kk] * v;
                 if (i == kk)
                   Sd[i][m] += wv;
                 else
@@ -204,85 +238,144 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
             }
           }
         }
+        // pin the fold here: LLVM otherwise sinks these FMA chains down to the epilogue (their only
+        // use), which keeps every accumulator tile live and spills
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int m = (4 * t + reg) % S4;
+          if ((4 * t + reg) / S4 < 3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+          }
+        }
       }
     }
 
-    // ---- facet lifts
+    // ---- facet lifts: u^ = avg(u) on interior facets, own trace on the boundary
+    //      (elastic.py:213-216); the neighbour pointer of a boundary lane is its own cell
+    {
+      const double* np[4];
+      int nst[4];
+      int ooff[4][KSF], noff[4][KSF];  // (node*3)*stride offsets of this lane's facet node per k-step
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const NbrRef R = nbr_ref<ND, NF, 3>(md, A, L, g, k, f, w, own);
-      double fl[KSF][3];
+      for (int f = 0; f < 4; ++f) {
+        const NbrRef R = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
+        np[f] = R.p;
+        nst[f] = R.cstride;
 #pragma unroll
-      for (int ks = 0; ks < KSF; ++ks) {
-        const int b = 4 * ks + q;
-        const int bb = b < NF ? b : 0;
-        const int on = sMd.fnode[f][bb];
-        const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          // u^ = avg(u) on interior facets, own trace on the boundary (elastic.py:213-216)
-          const double ov = own[(on * 3 + i) * 16];
-          const double nv = R.p[(nn * 3 + i) * R.cstride];
-          fl[ks][i] = (b < NF) ? 0.5 * (ov + nv) : 0.0;
+        for (int ks = 0; ks < KSF; ++ks) {
+          const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
+          const int on = sMd.fnode[f][bb];
+          const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
+          ooff[f][ks] = on * 3 * 16;
+          noff[f][ks] = nn * 3 * R.cstride;
         }
       }
+      constexpr int NS = 4 * KSF;
+      double oq[3], nq[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        d4 tmp[MTL];
+        oq[i] = own[ooff[0][0] + i * 16];
+        nq[i] = np[0][noff[0][0] + i * nst[0]];
+      }
 #pragma unroll
-        for (int t = 0; t < MTL; ++t) tmp[t] = d4{0, 0, 0, 0};
+      for (int f = 0; f < 4; ++f) {
+        d4 tmp[3][MTL];
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int t = 0; t < MTL; ++t)
-            tmp[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sAL[((f * MTL + t) * KSF + ks) * 64 + lane], fl[ks][i], tmp[t], 0,
-                                                          0, 0);
+          for (int t = 0; t < MTL; ++t) tmp[i][t] = d4{0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < MTL; ++t)
+        for (int ks = 0; ks < KSF; ++ks) {
+          const int s = f * KSF + ks;
+          double fl[3];
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int m = 4 * t + reg;
-            if (m < S4) {
-              const double v = tmp[t][reg];
+          for (int i = 0; i < 3; ++i) fl[i] = 0.5 * (oq[i] + nq[i]);
+          if (s + 1 < NS) {
+            const int f1 = (s + 1) / KSF, k1 = (s + 1) % KSF;
 #pragma unroll
-              for (int kk = 0; kk < 3; ++kk) {
-                const double wv = md->cn[k][f][kk] * v;
-                if (i == kk)
-                  Sd[i][m] += wv;
-                else
-                  So[i + kk - 1][m] += wv;
-              }
+            for (int i = 0; i < 3; ++i) {
+              oq[i] = own[ooff[f1][k1] + i * 16];
+              nq[i] = np[f1][noff[f1][k1] + i * nst[f1]];
             }
           }
+#pragma unroll
+          for (int t = 0; t < MTL; ++t) {
+            const double a = pAL[((f * MTL + t) * KSF + ks) * 64];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tmp[i][t] = MFMA64(a, fl[i], tmp[i][t]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int t = 0; t < MTL; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int m = 4 * t + reg;
+              if (m < S4) {
+                const double v = tmp[i][t][reg];
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                  const double wv = cnf[f][kk] * v;
+                  if (i == kk)
+                    Sd[i][m] += wv;
+                  else
+                    So[i + kk - 1][m] += wv;
+                }
+              }
+            }
+#pragma unroll
+        for (int m = 0; m < S4; ++m)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
       }
     }
 
-    // ---- stress and epilogue
-    if (L.active) {
-      const long e = L.c * 6 + k;
+    // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
+    {
+      const long e = (L.valid ? L.c : 0) * 6 + k;
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
       const long obase = ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+      double po[9], pa[9];
+      if (MODE == 1) {
+        const long o0 = obase + (long)q * 9 * 16;
+#pragma unroll
+        for (int ij = 0; ij < 9; ++ij) {
+          po[ij] = out[o0 + ij * 16];
+          pa[ij] = aux[o0 + ij * 16];
+        }
+      }
 #pragma unroll
       for (int m = 0; m < S4; ++m) {
         const int a = 4 * m + q;
-        if (a < ND) {
-          const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
-          double s[9];
-          s[0] = 2.0 * mu * Sd[0][m] + tr;
-          s[4] = 2.0 * mu * Sd[1][m] + tr;
-          s[8] = 2.0 * mu * Sd[2][m] + tr;
-          s[1] = s[3] = mu * So[0][m];
-          s[2] = s[6] = mu * So[1][m];
-          s[5] = s[7] = mu * So[2][m];
+        const bool st = L.active && a < ND;
+        const long o = obase + (long)((a < ND) ? a : 0) * 9 * 16;
+        const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+        double s[9];
+        s[0] = 2.0 * mu * Sd[0][m] + tr;
+        s[4] = 2.0 * mu * Sd[1][m] + tr;
+        s[8] = 2.0 * mu * Sd[2][m] + tr;
+        s[1] = s[3] = mu * So[0][m];
+        s[2] = s[6] = mu * So[1][m];
+        s[5] = s[7] = mu * So[2][m];
+        if (MODE == 1) {
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij) {
-            const long o = obase + (a * 9 + ij) * 16;
-            if (A.mode == 0)
-              A.out[o] = s[ij];
-            else
-              A.out[o] = A.c_self * A.out[o] + A.c_aux * A.aux[o] + A.c_new * s[ij];
+          for (int ij = 0; ij < 9; ++ij) s[ij] = A.c_self * po[ij] + A.c_aux * pa[ij] + A.c_new * s[ij];
+          if (m + 1 < S4) {
+            const int a1 = 4 * (m + 1) + q;
+            const long o1 = obase + (long)((a1 < ND) ? a1 : 0) * 9 * 16;
+#pragma unroll
+            for (int ij = 0; ij < 9; ++ij) {
+              po[ij] = out[o1 + ij * 16];
+              pa[ij] = aux[o1 + ij * 16];
+            }
           }
+        }
+        if (st) {
+#pragma unroll
+          for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
         }
       }
     }
@@ -292,35 +385,48 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 // --------------------------------------------------------------------------------------------
 //  F: uh_i = -sum_r D_r (Jinv_rj T_ij) + sum_f L_f [ (c n)_j {T_ij} ] - sponge
 // --------------------------------------------------------------------------------------------
-template <int P>
+template <int P, int MODE>
 __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL;
   __shared__ double sAV[M::NFRAG_F * 64];
   __shared__ double sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
-  for (int i = threadIdx.x; i < M::NFRAG_F * 64; i += 256) sAV[i] = A.fragV[i];
-  for (int i = threadIdx.x; i < M::NFRAG_L * 64; i += 256) sAL[i] = A.fragL[i];
-  {
-    const int* src = reinterpret_cast<const int*>(A.md);
-    int* dst = reinterpret_cast<int*>(&sMd);
-    for (int i = threadIdx.x; i < (int)(sizeof(MeshDev) / sizeof(int)); i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
+  load_tables<M::NFRAG_F, M::NFRAG_L>(sAV, sAL, &sMd, A);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, w = lane & 15;
   const MeshDev* md = A.md;
+  const double* __restrict__ in = A.in;
+  const double* __restrict__ aux = A.aux;
+  double* __restrict__ out = A.out;
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range(ngroups * 6, wave);
+
+  int bnode[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 9 * 16;
 
   for (long item = ir.lo; item < ir.hi; item += ir.step) {
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
-    const double* own = A.in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+    const double* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+    const double* pAV = sAV + lane;
+    const double* pAL = sAL + lane;
+    asm volatile("" : "+v"(pAV), "+v"(pAL));
+
+    double Jm[3][3], cnf[4][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Jm[r][j] = md->Jinv[k][r][j];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cnf[f][j] = md->cn[k][f][j];
 
     d4 acc[3][MTL];
 #pragma unroll
@@ -329,116 +435,169 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       for (int t = 0; t < MTL; ++t) acc[i][t] = d4{0, 0, 0, 0};
 
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
+    {
+      double Tq[9];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int b = 4 * ks + q;
-      double T[9];
+      for (int c = 0; c < 9; ++c) Tq[c] = own[bnode[0] + c * 16];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) T[c] = (b < ND) ? own[(b * 9 + c) * 16] : 0.0;
+      for (int ks = 0; ks < KS; ++ks) {
+        double T[9];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        double Tt[3];
+        for (int c = 0; c < 9; ++c) T[c] = Tq[c];
+        if (ks + 1 < KS) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          Tt[i] = md->Jinv[k][r][0] * T[i * 3 + 0] + md->Jinv[k][r][1] * T[i * 3 + 1] + md->Jinv[k][r][2] * T[i * 3 + 2];
+          for (int c = 0; c < 9; ++c) Tq[c] = own[bnode[ks + 1] + c * 16];
+        }
 #pragma unroll
-        for (int t = 0; t < MTL; ++t) {
-          const double a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lane];
+        for (int r = 0; r < 3; ++r) {
+          double Tt[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) acc[i][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tt[i], acc[i][t], 0, 0, 0);
+          for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
+#pragma unroll
+          for (int t = 0; t < MTL; ++t) {
+            const double a = pAV[(t * 3 * KS + KS * r + ks) * 64];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i][t] = MFMA64(a, Tt[i], acc[i][t]);
+          }
         }
       }
     }
 
-    // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary
+    // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary (elastic.py:206)
+    {
+      const double* np[4];
+      int nst[4];
+      double pf[4];
+      int ooff[4][KSF], noff[4][KSF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const NbrRef R = nbr_ref<ND, NF, 9>(md, A, L, g, k, f, w, own);
-      const double pf = R.physical ? 0.0 : 0.5;
+      for (int f = 0; f < 4; ++f) {
+        const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
+        np[f] = R.p;
+        nst[f] = R.cstride;
+        pf[f] = R.physical ? 0.0 : 0.5;
 #pragma unroll
-      for (int ks = 0; ks < KSF; ++ks) {
-        const int b = 4 * ks + q;
-        const int bb = b < NF ? b : 0;
-        const int on = sMd.fnode[f][bb];
-        const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-        double fl[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          double s = 0.0;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            s += md->cn[k][f][j] * (own[(on * 9 + i * 3 + j) * 16] + R.p[(nn * 9 + i * 3 + j) * R.cstride]);
-          fl[i] = (b < NF) ? pf * s : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < MTL; ++t) {
-          const double a = sAL[((f * MTL + t) * KSF + ks) * 64 + lane];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) acc[i][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fl[i], acc[i][t], 0, 0, 0);
+        for (int ks = 0; ks < KSF; ++ks) {
+          const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
+          const int on = sMd.fnode[f][bb];
+          const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
+          ooff[f][ks] = on * 9 * 16;
+          noff[f][ks] = nn * 9 * R.cstride;
         }
       }
-    }
-
-    // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma
-    const long e = L.c * 6 + k;
-    int slot = -1;
-    if (A.sponge_slot != nullptr && L.active) slot = A.sponge_slot[e];
-    const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
-    if (__any(slot >= 0)) {
-      if (slot >= 0) {
+      constexpr int NS = 4 * KSF;
+      double oq[9], nq[9];
 #pragma unroll
-        for (int t = 0; t < MTL; ++t)
+      for (int c = 0; c < 9; ++c) {
+        oq[c] = own[ooff[0][0] + c * 16];
+        nq[c] = np[0][noff[0][0] + c * nst[0]];
+      }
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int a = 16 * t + 4 * reg + q;
-            if (a < ND) {
-              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
-              double s0 = 0, s1 = 0, s2 = 0;
-              for (int b = 0; b < ND; ++b) {
-                const double bb = B[b];
-                s0 += bb * A.uabs[ubase + (b * 3 + 0) * 16];
-                s1 += bb * A.uabs[ubase + (b * 3 + 1) * 16];
-                s2 += bb * A.uabs[ubase + (b * 3 + 2) * 16];
-              }
-              acc[0][t][reg] -= s0;
-              acc[1][t][reg] -= s1;
-              acc[2][t][reg] -= s2;
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) {
+          const int s = f * KSF + ks;
+          double fl[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            fl[i] = pf[f] * (cnf[f][0] * (oq[i * 3 + 0] + nq[i * 3 + 0]) + cnf[f][1] * (oq[i * 3 + 1] + nq[i * 3 + 1]) +
+                             cnf[f][2] * (oq[i * 3 + 2] + nq[i * 3 + 2]));
+          if (s + 1 < NS) {
+            const int f1 = (s + 1) / KSF, k1 = (s + 1) % KSF;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+              oq[c] = own[ooff[f1][k1] + c * 16];
+              nq[c] = np[f1][noff[f1][k1] + c * nst[f1]];
             }
           }
+#pragma unroll
+          for (int t = 0; t < MTL; ++t) {
+            const double a = pAL[((f * MTL + t) * KSF + ks) * 64];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i][t] = MFMA64(a, fl[i], acc[i][t]);
+          }
+        }
       }
-      // in-place combine: all sponge reads of u (= out) must precede the writes below.  Lanes of
-      // one cell sit in this wave only, and a wave executes in program order, so no barrier is needed.
     }
 
-    if (L.active) {
+    // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
+    // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
+    // wave runs in program order, so all reads below precede the writes of the epilogue.
+    const long e = (L.valid ? L.c : 0) * 6 + k;
+    const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    if (A.sponge_slot != nullptr) {
+      const int slot = L.active ? A.sponge_slot[e] : -1;
+      if (__any(slot >= 0)) {
+        if (slot >= 0) {
 #pragma unroll
-      for (int t = 0; t < MTL; ++t)
+          for (int t = 0; t < MTL; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int a = 16 * t + 4 * reg + q;
+              if (a < ND) {
+                const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
+                double s0 = 0, s1 = 0, s2 = 0;
+                for (int b = 0; b < ND; ++b) {
+                  const double bb = B[b];
+                  s0 += bb * A.uabs[ubase + (b * 3 + 0) * 16];
+                  s1 += bb * A.uabs[ubase + (b * 3 + 1) * 16];
+                  s2 += bb * A.uabs[ubase + (b * 3 + 2) * 16];
+                }
+                acc[0][t][reg] -= s0;
+                acc[1][t][reg] -= s1;
+                acc[2][t][reg] -= s2;
+              }
+            }
+        }
+      }
+    }
+
+    // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345)
+#pragma unroll
+    for (int t = 0; t < MTL; ++t) {
+      double po[4][3], pa[4][3];
+      if (MODE == 1) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int a = 16 * t + 4 * reg + q;
-          if (a < ND) {
+          const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const long o = ubase + (a * 3 + i) * 16;
-              const double v = acc[i][t][reg];
-              if (A.mode == 0)
-                A.out[o] = v;
-              else
-                A.out[o] = A.c_self * A.out[o] + A.c_aux * A.aux[o] + A.c_new * v;
-            }
+          for (int i = 0; i < 3; ++i) {
+            po[reg][i] = out[o + i * 16];
+            pa[reg][i] = aux[o + i * 16];
           }
         }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int a = 16 * t + 4 * reg + q;
+        const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
+        if (L.active && a < ND) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            double v = acc[i][t][reg];
+            if (MODE == 1) v = A.c_self * po[reg][i] + A.c_aux * pa[reg][i] + A.c_new * v;
+            out[o + i * 16] = v;
+          }
+        }
+      }
     }
   }
 }
 
 template <int P>
 static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
-  const long grid = 512;  // 2 blocks per CU, a multiple of 8 (one contiguous item range per XCD label)
-  if (kind == 0)
-    hipLaunchKernelGGL((mfma_stage_F<P>), dim3((unsigned)grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((mfma_stage_G<P>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  const dim3 grid(512), block(256);  // 2 blocks per CU; a multiple of 8 (one item range per XCD label)
+  if (kind == 0) {
+    if (a.mode == 0)
+      hipLaunchKernelGGL((mfma_stage_F<P, 0>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((mfma_stage_F<P, 1>), grid, block, 0, s, a);
+  } else {
+    if (a.mode == 0)
+      hipLaunchKernelGGL((mfma_stage_G<P, 0>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((mfma_stage_G<P, 1>), grid, block, 0, s, a);
+  }
   return (int)hipGetLastError();
 }
 
