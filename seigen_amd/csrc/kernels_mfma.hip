@@ -251,12 +251,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       }
     }
 
-    // ---- facet lifts: u^ = avg(u) on interior facets, own trace on the boundary
-    //      (elastic.py:213-216); the neighbour pointer of a boundary lane is its own cell
+    // ---- facet lifts.  u^ = avg(u) on interior facets, own trace on the boundary
+    //      (elastic.py:213-216).  The own half of avg(u) is part of the volume tiles (E_r,
+    //      mfma_tables.cpp), so the lift carries 1/2 u- on interior facets and the missing
+    //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
+    //      (a boundary lane's neighbour pointer is its own cell).
     {
+      constexpr int PFL = 3;  // prefetch distance in facet k-steps
       const double* np[4];
       int nst[4];
-      int ooff[4][KSF], noff[4][KSF];  // (node*3)*stride offsets of this lane's facet node per k-step
+      int noff[4][KSF];  // (node*3)*stride offset of this lane's facet node per k-step
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const NbrRef R = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
@@ -267,17 +271,15 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
           const int on = sMd.fnode[f][bb];
           const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-          ooff[f][ks] = on * 3 * 16;
           noff[f][ks] = nn * 3 * R.cstride;
         }
       }
       constexpr int NS = 4 * KSF;
-      double oq[3], nq[3];
+      double nq[PFL][3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        oq[i] = own[ooff[0][0] + i * 16];
-        nq[i] = np[0][noff[0][0] + i * nst[0]];
-      }
+      for (int s = 0; s < PFL; ++s)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nq[s][i] = np[s / KSF][noff[s / KSF][s % KSF] + i * nst[s / KSF]];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         d4 tmp[3][MTL];
@@ -290,14 +292,11 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           const int s = f * KSF + ks;
           double fl[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) fl[i] = 0.5 * (oq[i] + nq[i]);
-          if (s + 1 < NS) {
-            const int f1 = (s + 1) / KSF, k1 = (s + 1) % KSF;
+          for (int i = 0; i < 3; ++i) fl[i] = 0.5 * nq[s % PFL][i];
+          if (s + PFL < NS) {
+            const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              oq[i] = own[ooff[f1][k1] + i * 16];
-              nq[i] = np[f1][noff[f1][k1] + i * nst[f1]];
-            }
+            for (int i = 0; i < 3; ++i) nq[s % PFL][i] = np[f1][noff[f1][k1] + i * nst[f1]];
           }
 #pragma unroll
           for (int t = 0; t < MTL; ++t) {
@@ -463,34 +462,36 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       }
     }
 
-    // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary (elastic.py:206)
+    // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary
+    //      (elastic.py:206).  The own half of {T} is part of the volume tiles (E_r), so the lift
+    //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
+    //      cancels the folded half): wf * (c n).T of whatever np[f] points at.
     {
+      constexpr int PFL = 2;
       const double* np[4];
       int nst[4];
-      double pf[4];
-      int ooff[4][KSF], noff[4][KSF];
+      double wf[4];
+      int noff[4][KSF];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
         np[f] = R.p;
         nst[f] = R.cstride;
-        pf[f] = R.physical ? 0.0 : 0.5;
+        wf[f] = R.physical ? -0.5 : 0.5;
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks) {
           const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
           const int on = sMd.fnode[f][bb];
           const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-          ooff[f][ks] = on * 9 * 16;
           noff[f][ks] = nn * 9 * R.cstride;
         }
       }
       constexpr int NS = 4 * KSF;
-      double oq[9], nq[9];
+      double nq[PFL][9];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        oq[c] = own[ooff[0][0] + c * 16];
-        nq[c] = np[0][noff[0][0] + c * nst[0]];
-      }
+      for (int s = 0; s < PFL; ++s)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) nq[s][c] = np[s / KSF][noff[s / KSF][s % KSF] + c * nst[s / KSF]];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -499,15 +500,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
           double fl[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i)
-            fl[i] = pf[f] * (cnf[f][0] * (oq[i * 3 + 0] + nq[i * 3 + 0]) + cnf[f][1] * (oq[i * 3 + 1] + nq[i * 3 + 1]) +
-                             cnf[f][2] * (oq[i * 3 + 2] + nq[i * 3 + 2]));
-          if (s + 1 < NS) {
-            const int f1 = (s + 1) / KSF, k1 = (s + 1) % KSF;
+            fl[i] = wf[f] * (cnf[f][0] * nq[s % PFL][i * 3 + 0] + cnf[f][1] * nq[s % PFL][i * 3 + 1] +
+                             cnf[f][2] * nq[s % PFL][i * 3 + 2]);
+          if (s + PFL < NS) {
+            const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) {
-              oq[c] = own[ooff[f1][k1] + c * 16];
-              nq[c] = np[f1][noff[f1][k1] + c * nst[f1]];
-            }
+            for (int c = 0; c < 9; ++c) nq[s % PFL][c] = np[f1][noff[f1][k1] + c * nst[f1]];
           }
 #pragma unroll
           for (int t = 0; t < MTL; ++t) {

@@ -17,9 +17,21 @@ MfmaGeom mfma_geom(const RefElem& re) {
   return g;
 }
 
-static inline double Dval(const RefElem& re, int r, int a, int b) {
+// E_r = D_r - C_r with the own-trace half of the central flux folded in:
+//   C_r = 1/4 (L_0 R_0 - L_{r+1} R_{r+1}),  R_f = restriction to the nodes of facet f.
+// On an affine tetrahedron (c n)_f = -grad(lambda_f)/2 and grad(lambda_f) is row f-1 of
+// Jinv (minus the sum of the rows for f = 0), so the own-side part of
+//   sum_f L_f [ (c n)_f . 1/2 T+ ]   is   sum_r C_r (Jinv_r . T),
+// i.e. it has the shape of the volume term.  The facet lifts then only carry the
+// NEIGHBOUR half (and a correction on domain-boundary facets, kernels_mfma.hip).
+static inline double Eval(const RefElem& re, int r, int a, int b) {
   if (a >= re.nd || b >= re.nd) return 0.0;
-  return re.D[((size_t)r * re.nd + a) * re.nd + b];
+  double v = re.D[((size_t)r * re.nd + a) * re.nd + b];
+  for (int bf = 0; bf < re.nf; ++bf) {
+    if (re.fnode[(size_t)0 * re.nf + bf] == b) v -= 0.25 * re.L[((size_t)0 * re.nd + a) * re.nf + bf];
+    if (re.fnode[(size_t)(r + 1) * re.nf + bf] == b) v += 0.25 * re.L[((size_t)(r + 1) * re.nd + a) * re.nf + bf];
+  }
+  return v;
 }
 
 std::vector<double> mfma_frags_F(const RefElem& re) {
@@ -29,7 +41,7 @@ std::vector<double> mfma_frags_F(const RefElem& re) {
     for (int r = 0; r < 3; ++r)
       for (int k0 = 0; k0 < g.ks; ++k0) {
         size_t frag = (size_t)t * 3 * g.ks + (size_t)g.ks * r + k0;
-        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = -Dval(re, r, 16 * t + (l & 15), 4 * k0 + (l >> 4));
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = -Eval(re, r, 16 * t + (l & 15), 4 * k0 + (l >> 4));
       }
   return out;
 }
@@ -44,7 +56,7 @@ std::vector<double> mfma_frags_G(const RefElem& re) {
       for (int l = 0; l < 64; ++l) {
         int rho = 16 * t + (l & 15);
         int r = rho / S, a = rho % S;
-        out[frag * 64 + l] = (r < 3) ? Dval(re, r, a, 4 * k0 + (l >> 4)) : 0.0;
+        out[frag * 64 + l] = (r < 3) ? Eval(re, r, a, 4 * k0 + (l >> 4)) : 0.0;
       }
     }
   return out;

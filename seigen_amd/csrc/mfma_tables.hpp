@@ -24,10 +24,11 @@ struct MfmaGeom {
 MfmaGeom mfma_geom(const RefElem& re);
 
 // F volume: out = sum_r (-D_r) T~_r  as one product with K = 3 * (4*ks):
-//   frag (t, kk), kk = ks*r + k0:  A[row][col] = -D_r[16 t + row][4 k0 + col]
+//   frag (t, kk), kk = ks*r + k0:  A[row][col] = -E_r[16 t + row][4 k0 + col]
+// (E_r = D_r minus the own-trace half of the central flux, see mfma_tables.cpp)
 std::vector<double> mfma_frags_F(const RefElem& re);
 // G volume: rows stacked rho = 4*s4*r + a:
-//   frag (t, k0): A[row][col] = D_r[a][4 k0 + col],  rho = 16 t + row
+//   frag (t, k0): A[row][col] = E_r[a][4 k0 + col],  rho = 16 t + row
 std::vector<double> mfma_frags_G(const RefElem& re);
 // facet lifts (shared by F and G): frag ((f*mtl + t)*ksf + k0): A[row][col] = L_f[16 t + row][4 k0 + col]
 std::vector<double> mfma_frags_L(const RefElem& re);
