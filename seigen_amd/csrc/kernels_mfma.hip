@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
     const double* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
-    // operator tiles are item-invariant: keep the compiler from hoisting all of them into registers
-    const double* pAV = sAV + lane;
-    const double* pAL = sAL + lane;
-    asm volatile("" : "+v"(pAV), "+v"(pAL));
+    // operator tiles are item-invariant: an opaque lane offset keeps the compiler from hoisting
+    // all of them into registers (and, unlike a laundered pointer, keeps the reads ds_read_b64)
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
 
     double Jm[3][3], cnf[4][3];  // class constants (wave-uniform)
 #pragma unroll
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) bq[s % PF][i] = own[bnode[(s + PF) % KS] + i * 16];
           }
-          const double a = pAV[(t * KS + ks) * 64];
+          const double a = sAV[(t * KS + ks) * 64 + lo];
 #pragma unroll
           for (int i = 0; i < 3; ++i) acc[i] = MFMA64(a, b[i], acc[i]);
         }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           }
 #pragma unroll
           for (int t = 0; t < MTL; ++t) {
-            const double a = pAL[((f * MTL + t) * KSF + ks) * 64];
+            const double a = sAL[((f * MTL + t) * KSF + ks) * 64 + lo];
 #pragma unroll
             for (int i = 0; i < 3; ++i) tmp[i][t] = MFMA64(a, fl[i], tmp[i][t]);
           }
@@ -413,9 +413,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
     const double* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
-    const double* pAV = sAV + lane;
-    const double* pAL = sAL + lane;
-    asm volatile("" : "+v"(pAV), "+v"(pAL));
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
 
     double Jm[3][3], cnf[4][3];
 #pragma unroll
@@ -454,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
           for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
 #pragma unroll
           for (int t = 0; t < MTL; ++t) {
-            const double a = pAV[(t * 3 * KS + KS * r + ks) * 64];
+            const double a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[i][t] = MFMA64(a, Tt[i], acc[i][t]);
           }
@@ -509,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
           }
 #pragma unroll
           for (int t = 0; t < MTL; ++t) {
-            const double a = pAL[((f * MTL + t) * KSF + ks) * 64];
+            const double a = sAL[((f * MTL + t) * KSF + ks) * 64 + lo];
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[i][t] = MFMA64(a, fl[i], acc[i][t]);
           }
