@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Regenerates the committed fixtures under tests/golden/ (run from the repo root in the
+build container: `python tests/golden/make_golden.py`).
+
+  ref_c{1,2,3}.txt        every 5th row of the reference's receiver traces
+                          /root/reference/tests/explosive_source/REF-C{1,2,3}
+                          (data files of the reference's own test; `t ux uy`, uy.py:7-17 reads them)
+  explosive_oracle.npz    the oracle's receiver traces for the explosive_source_lf4.py set-up
+                          with dt = 0.001 (uy.py:25), T = 2.5
+  stage_vectors.npz       F / G / full-step outputs of the oracle for seeded inputs on tiny meshes
+                          (numpy.random.default_rng(seed), uniform [-1, 1))
+  eigenmode_errors.json   oracle error functionals of the eigenmode sweeps
+                          (eigenmode_2d.py:68-84, eigenmode_3d.py:72-88, reduced to what runs in minutes)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import harness, mesh as omesh  # noqa: E402
+from oracle.forms import ElasticOperators  # noqa: E402
+from oracle.lf4 import OracleLF4  # noqa: E402
+
+REF = "/root/reference/tests/explosive_source"
+
+
+def ref_traces():
+    for i in (1, 2, 3):
+        rows = np.loadtxt(os.path.join(REF, "REF-C%d" % i))
+        np.savetxt(os.path.join(HERE, "ref_c%d.txt" % i), rows[4::5], fmt="%.9e")
+
+
+def explosive():
+    ex = harness.ExplosiveSource()
+    ex.elastic.dt = 0.001
+    times, tr = ex.run(2.5)
+    np.savez_compressed(os.path.join(HERE, "explosive_oracle.npz"), times=times[4::5], traces=tr[4::5])
+
+
+STAGE_CASES = [
+    (1, 2, (6,), (1.5,), "left"),
+    (2, 1, (4, 4), (1.0, 1.0), "left"),
+    (2, 2, (4, 4), (1.0, 1.0), "left"),
+    (2, 4, (4, 4), (1.0, 1.0), "right"),
+    (3, 1, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 3, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 4, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+]
+
+
+def stage_vectors():
+    out = {}
+    for ci, (dim, P, n, L, diag) in enumerate(STAGE_CASES):
+        m = omesh.structured(dim, n, L, diag)
+        E = ElasticOperators(m, P)
+        nd = E.nd
+        rng = np.random.default_rng(ci)
+        u = rng.uniform(-1, 1, (m.ncells, nd, dim))
+        T = rng.uniform(-1, 1, (m.ncells, nd, dim, dim))
+        key = "c%d" % ci
+        out[key + "_meta"] = np.array([dim, P] + list(n))
+        out[key + "_L"] = np.array(L)
+        out[key + "_u"] = u
+        out[key + "_T"] = T
+        out[key + "_F"] = E.apply_F(T, u)
+        out[key + "_G"] = E.apply_G(u, 0.7, 0.3)
+        orc = OracleLF4(m, P)
+        orc.u0, orc.s0 = u.copy(), T.copy()
+        orc.dt = 0.05 * min(L[a] / n[a] for a in range(dim)) / P ** 2
+        orc.l, orc.mu, orc.density = 0.5, 0.25, 1.0
+        for k in range(10):
+            orc.step((k + 1) * orc.dt)
+            if k == 0:
+                out[key + "_u_step1"], out[key + "_s_step1"] = orc.u1.copy(), orc.s1.copy()
+        out[key + "_dt"] = np.array(orc.dt)
+        out[key + "_u_step10"], out[key + "_s_step10"] = orc.u1.copy(), orc.s1.copy()
+    np.savez_compressed(os.path.join(HERE, "stage_vectors.npz"), **out)
+
+
+def eigenmode_errors():
+    res = {"2d": [], "3d": []}
+    for P in (1, 2, 3, 4):
+        for N in (4, 8, 16):
+            dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
+            em = harness.Eigenmode2D(N, P, dt)
+            u1, s1 = em.run()
+            e = em.errors(u1, s1)
+            res["2d"].append(dict(P=P, N=N, dt=dt, **e))
+            print("2d", P, N, e, flush=True)
+    em = harness.Eigenmode2D(40, 1, 0.0125)
+    u1, s1 = em.run()
+    res["config1"] = dict(P=1, N=40, dt=0.0125, **em.errors(u1, s1))
+    for P in (1, 2, 3):
+        for N in (2, 4):
+            dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
+            em = harness.Eigenmode3D(N, P, dt)
+            u1, s1 = em.run()
+            e = em.errors(u1, s1)
+            res["3d"].append(dict(P=P, N=N, dt=dt, **e))
+            print("3d", P, N, e, flush=True)
+    json.dump(res, open(os.path.join(HERE, "eigenmode_errors.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["ref", "stage", "eigen", "explosive"]
+    if "ref" in what:
+        ref_traces()
+    if "stage" in what:
+        stage_vectors()
+    if "eigen" in what:
+        eigenmode_errors()
+    if "explosive" in what:
+        explosive()

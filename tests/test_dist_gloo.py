@@ -1,0 +1,198 @@
+"""Multi-process CPU test (gloo, world_size 2 and 4) of the halo layer's host logic:
+Partition + seigen_amd.parallel.HaloExchanger with the real torch.distributed point-to-point
+calls.  The block is a numpy stand-in that packs, instead of field values, a hash of each
+trace node's physical position, with the SAME slot / ordinal / facet-node conventions the HIP
+pack kernel and the stage kernels use (taken from the library's device-free sg_mesh_tables).
+After the exchange every boundary facet node must find, at the slot and node index the
+kernels would read, the hash of its own position: sides, peers, ordering and node matching
+are all checked end to end.  (The HIP side of the same convention is checked bitwise on the
+GPU by tests/test_harness_gpu.py::test_multiblock_equals_single_block.)"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class FakeBlock(object):
+    """numpy mirror of the pack / ghost-lookup conventions (kernels.hip pack_kernel, stage kernels)."""
+
+    def __init__(self, mesh, degree, part):
+        from seigen_amd import _lib
+        from seigen_amd.functionspace import FunctionSpace
+        self.lib = _lib
+        L = _lib.load()
+        self.dim = dim = mesh.dim
+        self.part = part
+        self.n = part.n
+        self.ncls = {1: 1, 2: 2, 3: 6}[dim]
+        self.nfaces = dim + 1
+        fs = FunctionSpace(mesh, "DG", degree)
+        self.X = fs.node_coords()
+        self.nd = fs.nd
+        n4 = L.sg_reference_operator(dim, degree, 4, 0, None, 0)
+        fn = np.empty(n4)
+        L.sg_reference_operator(dim, degree, 4, 0, fn.ctypes.data, fn.nbytes)
+        self.nf = n4 // self.nfaces
+        self.fnode = fn.reshape(self.nfaces, self.nf).astype(int)
+        self.nb = np.zeros((self.ncls, self.nfaces, 5), dtype=np.int32)
+        self.nbn = np.zeros((self.ncls, self.nfaces, self.nf), dtype=np.int32)
+        cn = np.zeros((self.ncls, self.nfaces, 3))
+        ji = np.zeros((self.ncls, 3, 3))
+        h = np.ascontiguousarray(mesh.h, dtype=np.float64)
+        assert L.sg_mesh_tables(dim, degree, 0, h.ctypes.data, self.nb.ctypes.data, self.nbn.ctypes.data,
+                                cn.ctypes.data, ji.ctypes.data) == 0
+        self.hpc = 2 if dim == 3 else 1
+        self.ghost = {}
+        self.checked = 0
+        self.stages = []
+
+    # -- geometry helpers
+    def _cube2d(self, axis, c):
+        o = [a for a in range(self.dim) if a != axis]
+        idx, mul = 0, 1
+        for a in o:
+            idx += c[a] * mul
+            mul *= self.n[a]
+        return idx
+
+    def _cubes_on_side(self, side):
+        axis, hi = side >> 1, side & 1
+        rng = [range(self.n[a]) for a in range(self.dim)]
+        rng[axis] = [self.n[axis] - 1 if hi else 0]
+        import itertools
+        for rev in itertools.product(*reversed(rng)):
+            yield tuple(reversed(rev))
+
+    def _cell(self, c, k):
+        lin, mul = 0, 1
+        for a in range(self.dim):
+            lin += c[a] * mul
+            mul *= self.n[a]
+        return lin * self.ncls + k
+
+    @staticmethod
+    def _hash(x):
+        w = np.array([1.0, 1000.0, 1.0e6][:x.shape[-1]])
+        return x @ w
+
+    def ncomp(self, field):
+        d = self.dim
+        return d * d if field in (self.lib.FIELD_S, self.lib.FIELD_SH) else d
+
+    # -- interface used by HaloExchanger
+    def halo_bytes(self, field, side):
+        axis = side >> 1
+        n2 = int(np.prod([self.n[a] for a in range(self.dim) if a != axis]))
+        return n2 * self.hpc * self.nf * self.ncomp(field) * 8
+
+    def _view(self, ptr, field, side):
+        n = self.halo_bytes(field, side) // 8
+        buf = (C.c_double * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float64).reshape(-1, self.nf, self.ncomp(field))
+
+    def halo_pack(self, field, side, ptr):
+        out = self._view(ptr, field, side)
+        axis, hi = side >> 1, side & 1
+        for c in self._cubes_on_side(side):
+            for k in range(self.ncls):
+                for f in range(self.nfaces):
+                    if self.nb[k, f, 0] == axis and (self.nb[k, f, 1] > 0) == bool(hi):
+                        slot = self._cube2d(axis, c) * self.hpc + self.nb[k, f, 4]
+                        cell = self._cell(c, k)
+                        for b in range(self.nf):
+                            hv = self._hash(self.X[cell, self.fnode[f, b]])
+                            out[slot, b, :] = hv + field * 0.125 + np.arange(self.ncomp(field)) * 0.001
+
+    def halo_attach(self, field, side, ptr):
+        self.ghost[(field, side)] = ptr
+
+    def run_stage(self, stage, region):
+        from seigen_amd.parallel import STAGE_INPUT
+        self.stages.append((stage, region))
+        if region != self.lib.REGION_BOUNDARY:
+            return
+        field = STAGE_INPUT[stage]
+        for side in range(2 * self.dim):
+            if self.part.neighbour(side) is None:
+                continue
+            g = self._view(self.ghost[(field, side)], field, side)
+            axis, hi = side >> 1, side & 1
+            for c in self._cubes_on_side(side):
+                for k in range(self.ncls):
+                    for f in range(self.nfaces):
+                        if self.nb[k, f, 0] == axis and (self.nb[k, f, 1] > 0) == bool(hi):
+                            kn, fn = self.nb[k, f, 2], self.nb[k, f, 3]
+                            slot = self._cube2d(axis, c) * self.hpc + self.nb[kn, fn, 4]
+                            cell = self._cell(c, k)
+                            for b in range(self.nf):
+                                nbf = int(np.nonzero(self.fnode[fn] == self.nbn[k, f, b])[0][0])
+                                hv = self._hash(self.X[cell, self.fnode[f, b]])
+                                exp = hv + field * 0.125 + np.arange(self.ncomp(field)) * 0.001
+                                assert np.allclose(g[slot, nbf], exp, rtol=0, atol=1e-7), \
+                                    (side, c, k, f, b, g[slot, nbf], exp)
+                                self.checked += 1
+
+    def end_step(self):
+        self.stages.append("end")
+
+
+def _worker(rank, world, port, dim, n, degree, grid):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seigen_amd import _lib
+        from seigen_amd.mesh import Mesh, Partition
+        from seigen_amd.parallel import HaloExchanger, world as world_fn
+        assert world_fn() == (rank, world)
+        mesh = Mesh(n, tuple(1.0 + 0.5 * a for a in range(dim)))
+        part = Partition(n, rank, world, grid)
+        mesh.set_partition(part)
+        assert mesh.partition is part
+        blk = FakeBlock(mesh, degree, part)
+        ex = HaloExchanger(blk, part, torch.device("cpu"))
+        ex.step(2)
+        nsides = len(ex.sides)
+        assert nsides == sum(1 for s in range(2 * dim) if part.neighbour(s) is not None) and nsides > 0
+        # per step: 6 stages x (interior, boundary) + end
+        assert len(blk.stages) == 2 * 13
+        assert blk.stages[0] == (_lib.STAGE_UH1, _lib.REGION_INTERIOR)
+        assert blk.stages[1] == (_lib.STAGE_UH1, _lib.REGION_BOUNDARY)
+        assert blk.checked > 0
+        # global DoF count through allreduce_sum (helpers.get_dofs)
+        from seigen_amd.helpers import get_dofs
+        S, U = get_dofs(mesh, degree)
+        nd = blk.nd
+        ncells = int(np.prod(n)) * blk.ncls
+        assert S == ncells * nd * dim * dim and U == ncells * nd * dim
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dim,n,degree,grid", [
+    (2, (4, 3), 2, (2, 1)),
+    (3, (2, 4, 2), 2, (1, 2, 1)),
+    (3, (2, 2, 4), 3, (1, 1, 2)),
+    (1, (6,), 3, (2,)),
+])
+def test_halo_exchange_world2(dim, n, degree, grid):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(2, _free_port(), dim, n, degree, grid), nprocs=2, join=True)
+
+
+def test_halo_exchange_world4_2d_grid():
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(4, _free_port(), 2, (4, 4), 1, (2, 2)), nprocs=4, join=True)

@@ -1,0 +1,269 @@
+"""CPU-only tests of the host logic: the C-ABI library loads and exports every symbol the
+header declares, the device-free setup code (reference operators, mesh tables, node
+coordinates) agrees with the oracle, the Expression parser, partitioning, step counting."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import mesh as omesh
+from oracle import refelem
+from seigen_amd import _lib
+from seigen_amd.expression import Expression
+from seigen_amd.mesh import Partition, UnitSquareMesh, UnitCubeMesh, RectangleMesh, IntervalMesh
+from seigen_amd.functionspace import FunctionSpace, VectorFunctionSpace, TensorFunctionSpace, Function
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lib():
+    return _lib.load()
+
+
+# ------------------------------------------------------------------------------ C-ABI surface
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "seigen_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sg_[A-Za-z_]+)\s*\(", hdr))
+    assert declared, "no declarations found in the header"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    L = lib()
+    for name in declared:
+        assert hasattr(L, name), "libseigen_hip.so does not export %s" % name
+
+
+def test_create_fails_loudly_without_device_or_bad_args():
+    L = lib()
+    cfg = _lib.SgConfig()
+    cfg.dim, cfg.degree = 7, 1
+    h = C.c_void_p()
+    rc = L.sg_create(C.byref(cfg), C.byref(h))
+    assert rc != 0 and not h.value
+    assert L.sg_last_error(None)
+    from tests.conftest import have_gpu
+    if not have_gpu():
+        # no CPU fallback: a valid configuration must still fail without a HIP device
+        cfg.dim, cfg.degree = 2, 1
+        cfg.n[0] = cfg.n[1] = 2
+        cfg.h[0] = cfg.h[1] = 0.5
+        rc = L.sg_create(C.byref(cfg), C.byref(h))
+        assert rc == -2 and not h.value
+        assert b"no HIP device" in L.sg_last_error(None)
+        from seigen_amd import ElasticLF4
+        with pytest.raises(_lib.SeigenHipError):
+            ElasticLF4.create(UnitSquareMesh(2, 2), "DG", 1, dimension=2, output=False)
+
+
+# ------------------------------------------------------------------------------ reference element
+def refop(dim, P, which, q=0):
+    L = lib()
+    n = L.sg_reference_operator(dim, P, which, q, None, 0)
+    assert n > 0
+    out = np.empty(n)
+    assert L.sg_reference_operator(dim, P, which, q, out.ctypes.data, out.nbytes) == n
+    return out
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_reference_operators_match_oracle_quadrature(dim, P):
+    """C++ (exact monomial integration, long double) vs oracle (Gauss-Jacobi quadrature of the
+    closed-form Lagrange basis): D_r = Mhat^-1 Shat_r, Mhat, facet lifts."""
+    nd = refelem.nnodes(dim, P)
+    xq, wq = refelem.simplex_quadrature(dim, 2 * P)
+    phi, dphi = refelem.tabulate(dim, P, xq)
+    M = np.einsum('q,qa,qb->ab', wq, phi, phi)
+    Minv = np.linalg.inv(M)
+    D_or = np.stack([Minv @ np.einsum('q,qa,qb->ab', wq, dphi[:, :, r], phi) for r in range(dim)])
+    D = refop(dim, P, 0).reshape(dim, nd, nd)
+    Mh = refop(dim, P, 2).reshape(nd, nd)
+    assert np.abs(D - D_or).max() / np.abs(D_or).max() < 1e-12
+    assert np.abs(Mh - M).max() / np.abs(M).max() < 1e-13
+    nf = refelem.nnodes(dim - 1, P) if dim > 1 else 1
+    Lf = refop(dim, P, 1).reshape(dim + 1, nd, nf)
+    fn = refop(dim, P, 4).reshape(dim + 1, nf).astype(int)
+    xf, wf = refelem.simplex_quadrature(dim - 1, 2 * P)
+    bary = np.concatenate([1 - xf.sum(1, keepdims=True), xf], axis=1)
+    V = np.vstack([np.zeros(dim), np.eye(dim)])
+    for f in range(dim + 1):
+        assert (fn[f] == refelem.face_nodes(dim, P, f)).all()
+        pts = bary @ V[refelem.face_vertices(dim, f)]
+        ph, _ = refelem.tabulate(dim, P, pts)
+        Mf = np.einsum('q,qa,qb->ab', wf * math.factorial(dim - 1), ph, ph)   # unit facet measure
+        full = Minv @ Mf
+        mask = np.ones(nd, bool)
+        mask[fn[f]] = False
+        assert np.abs(full[:, mask]).max() < 1e-11          # basis functions off the facet vanish on it
+        assert np.abs(Lf[f] - full[:, fn[f]]).max() / np.abs(full).max() < 1e-12
+
+
+@pytest.mark.parametrize("dim,P,q", [(1, 1, 2), (2, 2, 4), (3, 2, 2), (2, 3, 4)])
+def test_sponge_tensor(dim, P, q):
+    nd, nq = refelem.nnodes(dim, P), refelem.nnodes(dim, q)
+    A = refop(dim, P, 3, q).reshape(nd, nq, nd)
+    xq, wq = refelem.simplex_quadrature(dim, 2 * P + q)
+    phi, _ = refelem.tabulate(dim, P, xq)
+    psi, _ = refelem.tabulate(dim, q, xq)
+    xm, wm = refelem.simplex_quadrature(dim, 2 * P)
+    pm, _ = refelem.tabulate(dim, P, xm)
+    Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))
+    A_or = np.einsum('ak,q,qk,qc,qb->acb', Minv, wq, phi, psi, phi)
+    assert np.abs(A - A_or).max() / np.abs(A_or).max() < 1e-11
+
+
+def test_tabulate_matches_closed_form():
+    from seigen_amd.norms import tabulate
+    rng = np.random.default_rng(0)
+    for dim in (1, 2, 3):
+        for P in (1, 3, 6):
+            xi = rng.dirichlet(np.ones(dim + 1), size=20)[:, 1:]
+            phi, _ = refelem.tabulate(dim, P, xi)
+            assert np.abs(tabulate(dim, P, xi) - phi).max() < 1e-10
+
+
+# ------------------------------------------------------------------------------ mesh tables
+@pytest.mark.parametrize("dim,P,diag", [(1, 2, "left"), (2, 1, "left"), (2, 3, "left"), (2, 2, "right"),
+                                        (3, 1, "left"), (3, 2, "left"), (3, 4, "left")])
+def test_mesh_tables_match_explicit_connectivity(dim, P, diag):
+    """Neighbour class / facet / node matching / scaled normals of the structured mesh (C++)
+    against the oracle's connectivity derived from vertex ids on a 3^dim patch."""
+    L = lib()
+    ncls = {1: 1, 2: 2, 3: 6}[dim]
+    nfaces = dim + 1
+    nf = refelem.nnodes(dim - 1, P) if dim > 1 else 1
+    h = np.array([0.5, 0.25, 0.2][:dim])
+    nb = np.zeros((ncls, nfaces, 5), dtype=np.int32)
+    nbn = np.zeros((ncls, nfaces, nf), dtype=np.int32)
+    cn = np.zeros((ncls, nfaces, 3))
+    jinv = np.zeros((ncls, 3, 3))
+    hh = np.ascontiguousarray(h)
+    rc = L.sg_mesh_tables(dim, P, 1 if diag == "right" else 0, hh.ctypes.data, nb.ctypes.data, nbn.ctypes.data,
+                          cn.ctypes.data, jinv.ctypes.data)
+    assert rc == 0
+    n = (3,) * dim
+    m = omesh.structured(dim, n, tuple(3 * h), diag)
+    X = m.node_coords(P)
+    centre = sum(1 * (3 ** a) for a in range(dim))      # cube (1,1,1)
+    nbr_of = {}
+    for (c1, f1, c2, f2) in m.interior_facets:
+        nbr_of[(c1, f1)] = (c2, f2)
+        nbr_of[(c2, f2)] = (c1, f1)
+    strides = [3 ** a for a in range(dim)]
+    for k in range(ncls):
+        cell = centre * ncls + k
+        assert np.allclose(jinv[k, :dim, :dim], m.Jinv[cell], atol=1e-13)
+        for f in range(nfaces):
+            c2, f2 = nbr_of[(cell, f)]
+            axis, d_, kn, fn_, _ = nb[k, f]
+            cube2 = centre + (d_ * strides[axis] if axis >= 0 else 0)
+            assert c2 == cube2 * ncls + kn and f2 == fn_
+            normal, area = m.facet_geometry(np.array([cell]), np.array([f]))
+            assert np.allclose(cn[k, f, :dim], normal[0] * area[0] / abs(m.detJ[cell]), atol=1e-12)
+            fnodes = refelem.face_nodes(dim, P, f)
+            for b in range(nf):
+                assert np.allclose(X[cell, fnodes[b]], X[c2, nbn[k, f, b]], atol=1e-12)
+    # facets on one cube side get distinct ordinals 0..hpc-1
+    for side in range(2 * dim):
+        ords = sorted(nb[k, f, 4] for k in range(ncls) for f in range(nfaces)
+                      if nb[k, f, 0] == side // 2 and (nb[k, f, 1] > 0) == bool(side & 1))
+        assert ords == list(range(2 if dim == 3 else 1))
+
+
+@pytest.mark.parametrize("mesh,om", [
+    (IntervalMesh(5, 2.0), omesh.IntervalMesh(5, 2.0)),
+    (UnitSquareMesh(3, 4), omesh.UnitSquareMesh(3, 4)),
+    (RectangleMesh(4, 3, 2.0, 1.5, "right"), omesh.RectangleMesh(4, 3, 2.0, 1.5, "right")),
+    (UnitCubeMesh(2, 3, 2), omesh.UnitCubeMesh(2, 3, 2)),
+])
+def test_node_coordinates(mesh, om):
+    for P in (1, 2, 4):
+        fs = FunctionSpace(mesh, "DG", P)
+        np.testing.assert_allclose(fs.node_coords(), om.node_coords(P), rtol=0, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------ Expression
+def test_expression_parser():
+    X = np.random.default_rng(1).uniform(0, 300, (50, 2))
+    x, y = X[:, 0], X[:, 1]
+    e = Expression("x[0] <= 20 || x[0] >= 280 || x[1] <= 20.0 ? 1000 : 0")
+    np.testing.assert_array_equal(e.evaluate(X), np.where((x <= 20) | (x >= 280) | (y <= 20), 1000.0, 0.0))
+    a = 159.42
+    code = ("x[0] >= 44.5 && x[0] <= 45.5 && x[1] >= 148.5 && x[1] <= 149.5 ? "
+            "(-1.0 + 2*a*pow(t - 0.3, 2))*exp(-a*pow(t - 0.3, 2)) : 0.0")
+    e = Expression(((code, "0.0"), ("0.0", code)), a=a, t=0.31)
+    Xs = np.array([[45.0, 148.75], [45.0, 140.0], [44.5, 149.5]])
+    r = (-1.0 + 2 * a * (0.31 - 0.3) ** 2) * math.exp(-a * (0.31 - 0.3) ** 2)
+    v = e.evaluate(Xs)
+    assert v.shape == (3, 2, 2)
+    np.testing.assert_allclose(v[:, 0, 0], [r, 0.0, r], rtol=1e-15)
+    np.testing.assert_array_equal(v[:, 0, 1], 0.0)
+    e.t = 0.3
+    assert e.evaluate(Xs)[0, 1, 1] == -1.0
+    e2 = Expression(('a*cos(pi*x[0])*sin(pi*x[1])*cos(a*t)', '-a*sin(pi*x[0])*cos(pi*x[1])*cos(a*t)'), a=2.0, t=0)
+    np.testing.assert_allclose(e2.evaluate(X / 300)[:, 0], 2 * np.cos(np.pi * x / 300) * np.sin(np.pi * y / 300),
+                               rtol=1e-14)
+    assert Expression("!(x[0] > 1) ? 2e-3 : -1.5E2").evaluate(np.array([[0.5], [2.0]])).tolist() == [2e-3, -150.0]
+    with pytest.raises(NameError):
+        Expression("foo*x[0]").evaluate(X)
+
+
+def test_function_interpolate_and_assign():
+    mesh = UnitSquareMesh(2, 2)
+    U = VectorFunctionSpace(mesh, "DG", 2)
+    S = TensorFunctionSpace(mesh, "DG", 2)
+    assert U.dof_count == 8 * 6 * 2 and S.dof_count == 8 * 6 * 4
+    f = Function(U).interpolate(Expression(("x[0]", "2*x[1]")))
+    X = U.node_coords()
+    np.testing.assert_allclose(f.dat.data_cells[..., 0], X[..., 0])
+    np.testing.assert_allclose(f.dat.data_cells[..., 1], 2 * X[..., 1])
+    g = Function(U).assign(f)
+    np.testing.assert_array_equal(g.dat.data, f.dat.data)
+    assert f.dat.data.shape == (48, 2)
+    with pytest.raises(ValueError):
+        Function(S).interpolate(Expression(("x[0]", "2*x[1]")))
+    with pytest.raises(NotImplementedError):
+        FunctionSpace(mesh, "CG", 1)
+
+
+# ------------------------------------------------------------------------------ partition / steps
+def test_partition_covers_mesh():
+    for n, world in (((64, 64, 64), 8), ((10, 7), 4), ((9,), 3), ((128, 128, 128), 2)):
+        seen = np.zeros(n, dtype=int)
+        for r in range(world):
+            p = Partition(n, r, world)
+            sl = tuple(slice(p.start[a], p.start[a] + p.n[a]) for a in range(len(n)))
+            seen[sl] += 1
+            for s in range(2 * len(n)):
+                nb = p.neighbour(s)
+                if nb is not None:
+                    q = Partition(n, nb, world)
+                    assert q.neighbour(s ^ 1) == r
+                    axis = s >> 1
+                    for a in range(len(n)):
+                        if a != axis:
+                            assert (p.start[a], p.n[a]) == (q.start[a], q.n[a])
+                assert bool(p.nbr_mask >> s & 1) == (nb is not None)
+        assert (seen == 1).all()
+
+
+def test_step_count_follows_reference_loop():
+    """t = dt; while t <= T + 1e-12: ...; t += dt   (seigen/elastic.py:279-313)"""
+    from oracle.lf4 import count_steps
+    from seigen_amd.elastic import ElasticLF4
+
+    class Dummy(object):
+        step_times = ElasticLF4.step_times
+    for dt, T in ((0.0125, 5.0), (0.001, 2.5), (0.5 / 32 / 8, 5.0), (0.3, 1.0)):
+        d = Dummy()
+        d.dt = dt
+        assert len(d.step_times(T)) == count_steps(dt, T)
+    assert count_steps(0.0125, 5.0) == 400
+
+
+def test_helpers():
+    from seigen_amd import Vp, Vs, cfl_dt
+    assert Vp(0.25, 0.5, 1.0) == 1.0 and Vs(0.25, 1.0) == 0.5
+    assert abs(cfl_dt(2.5, Vp(3600.0, 3599.3664, 1.0), 0.5) - 0.012028483448806774) < 1e-15

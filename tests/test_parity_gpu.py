@@ -108,3 +108,34 @@ def test_density_quirk(gpu):
     orc.step(2 * orc.dt)
     assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+
+
+def test_against_committed_golden_vectors(gpu):
+    """HIP path vs tests/golden/stage_vectors.npz (written by tests/golden/make_golden.py from
+    the oracle): un-fused F and G, and the state after 1 and 10 whole LF4 steps."""
+    import os
+    from seigen_amd import _lib
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage_vectors.npz"))
+    ncases = len([k for k in d.files if k.endswith("_meta")])
+    assert ncases >= 7
+    diag = {3: "right"}
+    for ci in range(ncases):
+        key = "c%d" % ci
+        dim, P = int(d[key + "_meta"][0]), int(d[key + "_meta"][1])
+        n = tuple(int(x) for x in d[key + "_meta"][2:])
+        L = tuple(d[key + "_L"])
+        blk = make_block(dim, P, n, L, diag.get(ci, "left"))
+        blk.set_params(1.0, float(d[key + "_dt"]), 0.7, 0.3)
+        blk.set_field(_lib.FIELD_S, d[key + "_T"])
+        blk.set_field(_lib.FIELD_U, d[key + "_u"])
+        blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+        assert rel_err(blk.get_field(_lib.FIELD_UH), d[key + "_F"]) < TOL
+        blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+        assert rel_err(blk.get_field(_lib.FIELD_SH), d[key + "_G"]) < TOL
+        blk.set_params(1.0, float(d[key + "_dt"]), 0.5, 0.25)
+        blk.step(1)
+        assert rel_err(blk.get_field(_lib.FIELD_U), d[key + "_u_step1"]) < 10 * TOL
+        assert rel_err(blk.get_field(_lib.FIELD_S), d[key + "_s_step1"]) < 10 * TOL
+        blk.step(9)
+        assert rel_err(blk.get_field(_lib.FIELD_U), d[key + "_u_step10"]) < 100 * TOL
+        assert rel_err(blk.get_field(_lib.FIELD_S), d[key + "_s_step10"]) < 100 * TOL
