@@ -169,12 +169,19 @@ def main():
     total_dofs = dofs_per_gpu * world
     value = total_dofs * args.steps / elapsed / 1e6
 
-    # dominant kernel: F launches are stages 0,2,4; G launches are 1,3,5
+    # kernels as rocprofv3 names them: <P, 0> plain store (stages uh1/utemp, stemp/sh1),
+    # <P, 1> fused LF4 combine (stage u1, stage s1)
     ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
     nl = [c1["launches"][i] - c0["launches"][i] for i in range(6)]
     words = [d * d + d, d + d * d, d * d + 3 * d, d + d * d, d * d + d, 3 * d * d + d]   # per node per launch
+    mfma = P >= 3 and os.environ.get("SEIGEN_HIP_PATH", "") != "generic"
+    if mfma:
+        names = (("sg::mfma_stage_F<%d, 0>" % P, (0, 4)), ("sg::mfma_stage_F<%d, 1>" % P, (2,)),
+                 ("sg::mfma_stage_G<%d, 0>" % P, (1, 3)), ("sg::mfma_stage_G<%d, 1>" % P, (5,)))
+    else:
+        names = (("sg::stage_kernel<3, %d, 0>" % P, (0, 2, 4)), ("sg::stage_kernel<3, %d, 1>" % P, (1, 3, 5)))
     kern = {}
-    for name, stages in (("stage_kernel<3,%d,F>" % P, (0, 2, 4)), ("stage_kernel<3,%d,G>" % P, (1, 3, 5))):
+    for name, stages in names:
         tot_ms = sum(ms[i] for i in stages)
         launches = sum(nl[i] for i in stages)
         byts = sum(words[i] * nl[i] for i in stages) * nodes * 8.0
