@@ -188,8 +188,18 @@ def main():
         kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(launches, 1),
                           gbs=byts / max(tot_ms, 1e-12) / 1e6)
     dom = max(kern, key=lambda k: kern[k]["ms"])
+    # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE,
+    # calibrated with tools/calib_fetch.hip) - measured separately, see profiles/<round>/*_traffic.json
+    traffic = None
+    if world == 1 and n == 64 and P == 4:
+        for tj in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "config3_traffic.json"))):
+            try:
+                traffic = json.load(open(tj))["kernels"].get(dom, {}).get("bytes", traffic)
+            except (OSError, ValueError, KeyError):
+                pass
     roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": kern[dom]["gbs"] * 1e6 * kern[dom]["avg_ms"],
             "avg_launch_ms": kern[dom]["avg_ms"],
             "kernels": {k: {"avg_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"]} for k, v in kern.items()},
             "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9),
