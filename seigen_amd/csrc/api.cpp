@@ -535,7 +535,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.uabs = h->field[uabs_f];
   for (int s = 0; s < 6; ++s) {
     a.ghost[s] = h->ghost[in_f][s];
-    if (h->md.has_nbr[s] && !a.ghost[s] && region != SG_REGION_INTERIOR)
+    // required for interior launches too: masked boundary lanes still form (and load through) the pointer
+    if (h->md.has_nbr[s] && !a.ghost[s])
       return fail(h, SG_ERR_STATE, "stage needs a halo buffer that was not attached (sg_halo_attach)");
   }
   a.Dt = h->Dt;

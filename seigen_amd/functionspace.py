@@ -179,3 +179,58 @@ class Function(object):
 
     def vector(self):
         return self.dat.data.ravel()
+
+
+def locate(space, point):
+    """(cell, xi) of the cell of this rank's block containing `point`, or None.
+    Stand-in for the point location behind ``vtktools.vtu.ProbeData`` in the reference's
+    receiver script (``tests/explosive_source/uy.py:36-43``)."""
+    mesh, dim, P = space.mesh, space.dim, space.degree
+    part = mesh.partition
+    p = np.asarray(point, dtype=np.float64)[:dim]
+    # candidate cubes: the one containing the point and, for a point on a grid line, the one
+    # before it; a DG field is two-valued there and the lowest-numbered cell wins (deterministic)
+    cands = [[]]
+    for a in range(dim):
+        t = (p[a] - mesh.origin[a]) / mesh.h[a]
+        i = int(np.floor(t))
+        opts = [i - 1, i] if abs(t - round(t)) < 1e-9 else [i]
+        opts = [o - part.start[a] for o in opts if 0 <= o - part.start[a] < part.n[a]]
+        cands = [c + [o] for c in cands for o in opts]
+    ncls = mesh.cells_per_block
+    X = space.node_coords()
+    # lattice corners: nodes (0,..), (P,0,..), (0,P,..), (0,0,P)
+    corner = {1: [0, P], 2: [0, P, space.nd - 1], 3: [0, P, (P + 1) * (P + 2) // 2 - 1, space.nd - 1]}[dim]
+    lins = []
+    for cube in cands:
+        lin, mul = 0, 1
+        for a in range(dim):
+            lin += cube[a] * mul
+            mul *= part.n[a]
+        lins.append(lin)
+    for lin in sorted(lins):
+        for k in range(ncls):
+            cell = lin * ncls + k
+            V = X[cell, corner]                       # [dim+1, dim]
+            J = (V[1:] - V[0]).T
+            xi = np.linalg.solve(J, p - V[0])
+            if xi.min() >= -1e-12 and xi.sum() <= 1.0 + 1e-12:
+                return cell, xi
+    return None
+
+
+def evaluate_at(function, point, cell_xi=None):
+    """Value of a DG Function at a point (owned by this rank), shape = value_shape."""
+    from .norms import tabulate
+    space = function.function_space()
+    loc = locate(space, point) if cell_xi is None else cell_xi
+    if loc is None:
+        return None
+    cell, xi = loc
+    phi = tabulate(space.dim, space.degree, xi[None, :])[0]
+    if function._binding is not None:
+        block, field = function._binding
+        vals = block.get_field_range(field, cell, 1)[0]
+    else:
+        vals = function._host[cell]
+    return np.tensordot(phi, vals, axes=(0, 0))

@@ -61,3 +61,25 @@ class ExplosiveSourceLF4():
         # Start the simulation
         with timed_region('elastic-run'):
             return self.elastic.run(T)
+
+    def record_receivers(self, T, receivers=((45.0, 149.0), (90.0, 149.0), (140.0, 149.0)), every=5):
+        """Run to T and sample VelocityNew at the receivers every `every` steps - the counterpart of
+        tests/explosive_source/uy.py:31-43 (which probes the VTU files of every 5th step).
+        Returns times [n], traces [n, nrecv, 2]."""
+        import numpy as np
+        from seigen_amd.functionspace import evaluate_at, locate
+        el = self.elastic
+        el.setup()
+        times = el.step_times(T)
+        if el.source:
+            nodes, values = el._source_table(times)
+            el.block.set_source(nodes, values)
+        locs = [locate(el.U, r) for r in receivers]
+        out_t, out_v = [], []
+        done = 0
+        while done + every <= len(times):
+            el._advance(every)
+            done += every
+            out_t.append(times[done - 1])
+            out_v.append([evaluate_at(el.u1, r, loc) for r, loc in zip(receivers, locs)])
+        return np.array(out_t), np.array(out_v)

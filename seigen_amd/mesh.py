@@ -26,8 +26,10 @@ def _factor_grid(world, dim, n):
             w //= p
         p += 1
     for f in sorted(factors, reverse=True):
-        # axis with the most cells per block left
-        ax = max(range(dim), key=lambda a: (n[a] / grid[a], -a))
+        # axis with the most cells per block left; on ties the slowest-varying one.  In 3-D the
+        # x axis is split last (weight 1/4): the MFMA layout interleaves 16 consecutive cubes along
+        # x, so a block side normal to x makes boundary groups that use 1 lane in 16.
+        ax = max(range(dim), key=lambda a: (n[a] / grid[a] * (0.25 if (dim == 3 and a == 0) else 1.0), a))
         grid[ax] *= f
     return tuple(grid)
 

@@ -218,3 +218,23 @@ def test_multiblock_equals_single_block(gpu, dim, degree, n, grid):
         sel = cells_of(p)
         assert np.array_equal(b.get_field(_lib.FIELD_U), uref[sel]), "velocity differs from the single-block run"
         assert np.array_equal(b.get_field(_lib.FIELD_S), sref[sel]), "stress differs from the single-block run"
+
+
+def test_receiver_traces_full_run_vs_oracle_and_ref_c(gpu):
+    """The whole explosive-source run of the reference (explosive_source_lf4.py, dt = 0.001 of
+    uy.py:25, T = 2.5: 2500 steps = 15 000 fused launches) on the GPU, receivers sampled every 5th
+    step as uy.py does, against the oracle's committed traces and the reference's REF-C1."""
+    import os
+    from seigen_amd.harness.explosive_source import ExplosiveSourceLF4
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(gold, "explosive_oracle.npz"))
+    ex = ExplosiveSourceLF4()
+    ex.setup(dt=1e-3)
+    t, tr = ex.record_receivers(2.5)
+    np.testing.assert_allclose(t, d["times"], atol=1e-9)
+    scale = np.abs(d["traces"]).max()
+    assert np.abs(tr - d["traces"]).max() < 1e-8 * scale
+    ref = np.loadtxt(os.path.join(gold, "ref_c1.txt"))
+    uy = -tr[:, 0, 1]
+    k, kr = uy.argmin(), ref[:, 2].argmin()
+    assert abs(t[k] - ref[kr, 0]) <= 0.0051 and abs(uy[k] / ref[kr, 2] - 1.0) < 0.08

@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Secondary measurements for the other BASELINE configs (not the contract bench):
+  c2: 2-D explosive source, 512x512 squares (524 288 triangles), P2, DG4 sponge + box-Ricker source
+  c5: Marmousi 383x121 squares, P3, per-cell (lambda, mu) from seigen_amd/data/marmhard.dat
+  c1: 2-D eigenmode 40x40, P1 (launch-overhead bound)
+Prints one JSON line per config: M DoF-updates/s and ms/step (device time, hipEvents)."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import seigen_amd  # noqa: E402
+from seigen_amd import (ElasticLF4, Expression, Function, FunctionSpace, RectangleMesh, Vp, cfl_dt)  # noqa: E402
+from seigen_amd.harness.eigenmode import Eigenmode2DLF4  # noqa: E402
+from seigen_amd.harness.explosive_source import ExplosiveSourceLF4  # noqa: E402
+
+seigen_amd.elastic.log = lambda s: None
+import seigen_amd.harness.eigenmode as _he  # noqa: E402
+import seigen_amd.harness.explosive_source as _hx  # noqa: E402
+_he.log = _hx.log = lambda s: None
+
+
+def timed(elastic, steps, warmup):
+    elastic.setup()
+    blk = elastic.block
+    if elastic.source:
+        times = [elastic.dt * (k + 1) for k in range(steps + warmup)]
+        nodes, values = elastic._source_table(times)
+        blk.set_source(nodes, values)
+    else:
+        blk.set_source([], None)
+    blk.step(warmup)
+    blk.sync()
+    t0 = time.perf_counter()
+    blk.step(steps)
+    blk.sync()
+    wall = time.perf_counter() - t0
+    dev_ms = blk.last_step_ms()
+    dofs = blk.u_dofs + blk.s_dofs
+    u = blk.get_field_range(0, 0, 4)
+    return dict(dofs=dofs, cells=blk.ncells, ms_per_step=dev_ms / steps, wall_ms_per_step=wall / steps * 1e3,
+                value=dofs * steps / (dev_ms * 1e-3) / 1e6, finite=bool(np.isfinite(u).all()))
+
+
+def config2(steps, warmup, n=512):
+    h = 2.5
+    ex = ExplosiveSourceLF4()
+    # Courant number 0.05 (default of the reference's tiling harness, tests/tiling/utils.py:51-52):
+    # the 0.5 of explosive_source_lf4.py:31 is unstable with the explicit sponge
+    el = ex.setup(Lx=n * h, Ly=n * h, h=h, degree=2, courant_number=0.05)
+    r = timed(el, steps, warmup)
+    r["config"] = "c2: 2D explosive source %dx%d squares, P2, sponge+source" % (n, n)
+    return r
+
+
+def config5(steps, warmup):
+    from seigen_amd.marmousi import cell_material, NX, NY, H
+    mesh = RectangleMesh(NX - 1, NY - 1, (NX - 1) * H, (NY - 1) * H)        # seigen/marmousi.py:18-21
+    el = ElasticLF4.create(mesh, "DG", 3, dimension=2, solver="explicit", output=False)
+    lam, mu, vp = cell_material(el.U)
+    el.density, el.l, el.mu = 1.0, lam, mu
+    el.dt = cfl_dt(H, float(vp.max()), 0.05)
+    # Ricker source near the surface, zero initial state
+    a = 159.42
+    sx, sy = 0.5 * (NX - 1) * H, (NY - 1) * H - 24.0
+    box = "x[0] >= %r && x[0] <= %r && x[1] >= %r && x[1] <= %r" % (sx - 12.0, sx + 12.0, sy - 12.0, sy + 12.0)
+    code = "%s ? (-1.0 + 2*a*pow(t - 0.3, 2))*exp(-a*pow(t - 0.3, 2)) : 0.0" % box
+    el.source_expression = Expression(((code, "0.0"), ("0.0", code)), a=a, t=0)
+    el.source_function = Function(el.S)
+    el.source = el.source_expression
+    r = timed(el, steps, warmup)
+    r["config"] = "c5: Marmousi %dx%d squares, P3, per-cell lambda/mu" % (NX - 1, NY - 1)
+    return r
+
+
+def config1(steps, warmup):
+    em = Eigenmode2DLF4(40, 1, 0.0125, output=False)
+    el = em.elastic
+    el.u0.assign(Function(el.U).interpolate(em._u(0)))
+    el.s0.assign(Function(el.S).interpolate(em._s(el.dt / 2)))
+    r = timed(el, steps, warmup)
+    r["config"] = "c1: 2D eigenmode 40x40 squares, P1"
+    return r
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=["c2", "c5", "c1"])
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    args = ap.parse_args()
+    for c in args.configs:
+        r = {"c1": config1, "c2": config2, "c5": config5}[c](args.steps, args.warmup)
+        r["algorithmic_GBps"] = r["value"] * 1e6 * 64 / 1e9
+        r["hbm_frac"] = r["algorithmic_GBps"] / 8000.0
+        print(json.dumps(r))
