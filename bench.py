@@ -67,29 +67,35 @@ def fill_initial_condition(elastic, dt):
         blk.set_field_range(_lib.FIELD_S, k * cells_per_layer, T)
 
 
-def cpu_baseline(degree, budget_s=20.0):
-    """The oracle (numpy/scipy restatement of the reference path) timed on this
-    host: 3-D P4 eigenmode on N=6 (1296 tets), single thread.  Baseline only."""
-    from oracle import harness
-    N = 6
-    em = harness.Eigenmode3D(N, degree, 0.5 / N / 2 ** (degree - 1))
-    el = em.elastic
-    X = el.node_coords()
-    el.u0 = em.u_exact(X, 0.0)
-    el.s0 = em.s_exact(X, el.dt / 2.0)
-    el.step(el.dt)                      # warm-up
-    dofs = em.mesh.ncells * el.E.nd * 12
+def cpu_baseline(degree, budget_s=15.0):
+    """The oracle's plain-C/OpenMP restatement of the reference path (oracle/c/seigen_oracle.c,
+    kind "port") timed on this host's cores: 3-D eigenmode, N=16 (24 576 tets), same P, FP64.
+    A bounded sample (~10-20 s of CPU work); baseline only."""
+    from oracle import mesh as omesh
+    from oracle import cport
+    try:
+        cport.build(arch="native", force=True)      # rebuild for this host's ISA
+    except Exception:
+        cport.build(force=True)
+    N = 16
+    m = omesh.UnitCubeMesh(N, N, N)
+    cp = cport.CPort(m, degree)
+    X = m.node_coords(degree)
+    dt = 0.5 / N / 2 ** (degree - 1)
+    u, T = eigenmode3d_fields(X, 0.0, dt / 2.0)
+    cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)           # warm-up
+    dofs = m.ncells * cp.nd * 12
     t0 = time.perf_counter()
     n = 0
     while True:
-        el.step((n + 2) * el.dt)
-        n += 1
-        if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
+        u, T = cp.step(u, T, 1.0, dt, 0.5, 0.25, 2)
+        n += 2
+        if time.perf_counter() - t0 > budget_s or n >= 400:
             break
-    dt = time.perf_counter() - t0
-    return {"value": dofs * n / dt / 1e6, "unit": "M DoF-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle (numpy/scipy CSR) 3D eigenmode N=%d P=%d, %d tets, %d steps in %.1f s"
-                      % (N, degree, em.mesh.ncells, n, dt)}
+    el = time.perf_counter() - t0
+    return {"value": dofs * n / el / 1e6, "unit": "M DoF-updates/s", "cores": cp.threads(), "kind": "port",
+            "sample": "oracle/c/seigen_oracle.c (plain C + OpenMP) 3D eigenmode N=%d P=%d, %d tets, %d steps in %.1f s, "
+                      "%d threads" % (N, degree, m.ncells, n, el, cp.threads())}
 
 
 def main():
