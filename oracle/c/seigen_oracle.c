@@ -167,3 +167,12 @@ int so_max_threads(void) {
   return 1;
 #endif
 }
+
+void so_set_threads(int n) {
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

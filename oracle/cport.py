@@ -86,6 +86,9 @@ class CPort(object):
     def threads(self):
         return int(self.lib.so_max_threads())
 
+    def set_threads(self, n):
+        self.lib.so_set_threads(C.c_int(int(n)))
+
     def apply_F(self, T):
         T = np.ascontiguousarray(T, dtype=np.float64)
         out = np.empty((self.mesh.ncells, self.nd, self.dim))
