@@ -34,6 +34,7 @@ struct sg_handle {
   double* fragG = nullptr;
   double* fragL = nullptr;
   double* staging = nullptr;  // host-layout staging buffer for layout conversion
+  unsigned long long* dbg = nullptr;  // SEIGEN_HIP_STAMPS=1 (diagnostic builds): [kind][8] cycle sums
   size_t staging_len = 0;
   int64_t ncells = 0;
   int ncls = 0;
@@ -101,6 +102,16 @@ void sg_destroy(sg_handle* h) {
   if (h->fragG) (void)hipFree(h->fragG);
   if (h->fragL) (void)hipFree(h->fragL);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->dbg) {
+    unsigned long long v[32];
+    if (hipMemcpy(v, h->dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
+      for (int k = 0; k < 4; ++k)
+        std::fprintf(stderr, "[seigen_hip stamps] %s mode %d: items %llu  cycles/item: setup %.0f volume %.0f lifts %.0f epilogue %.0f\n",
+                     k < 2 ? "F" : "G", k & 1, v[8 * k + 4], v[8 * k + 4] ? (double)v[8 * k + 0] / v[8 * k + 4] : 0.0,
+                     v[8 * k + 4] ? (double)v[8 * k + 1] / v[8 * k + 4] : 0.0, v[8 * k + 4] ? (double)v[8 * k + 2] / v[8 * k + 4] : 0.0,
+                     v[8 * k + 4] ? (double)v[8 * k + 3] / v[8 * k + 4] : 0.0);
+    (void)hipFree(h->dbg);
+  }
   if (h->lam_d) (void)hipFree(h->lam_d);
   if (h->mu_d) (void)hipFree(h->mu_d);
   if (h->sponge_slot) (void)hipFree(h->sponge_slot);
@@ -188,6 +199,10 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragF, fF.data(), fF.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (std::getenv("SEIGEN_HIP_STAMPS")) {
+    HIPCHECK(h, hipMalloc((void**)&h->dbg, 32 * sizeof(unsigned long long)));
+    HIPCHECK(h, hipMemset(h->dbg, 0, 32 * sizeof(unsigned long long)));
   }
   if (cfg->stream) {
     h->stream = (hipStream_t)cfg->stream;
@@ -544,6 +559,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.md = h->md_dev;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
+  a.dbg = h->dbg ? h->dbg + 8 * (kind * 2 + (mode ? 1 : 0)) : nullptr;
   a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
   a.sponge_B = h->sponge_B;
   a.lam = h->lam_d;

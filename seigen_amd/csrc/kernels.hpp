@@ -17,6 +17,7 @@ struct StageArgs {
   const MeshDev* md;       // device copy
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
+  unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null
   const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
   const double* sponge_B;      // [slot][nd(a)][nd(b)]
   const double* lam;           // per-cell (per_cell=1) or null

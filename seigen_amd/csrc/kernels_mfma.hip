@@ -40,6 +40,38 @@ struct MG {
 
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// Diagnostic build only (-DSG_STAMPS, SEIGEN_HIP_STAMPS=1): cycle stamps at the phase boundaries
+// of an item, summed per wave in scalars and added to A.dbg at the end.  Never in the shipped build.
+#ifdef SG_STAMPS
+#define STAMP(t)                                                                   \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#define STAMP_DECL unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sacc[4] = {0, 0, 0, 0}, sitems = 0
+#define STAMP_ACC                                                                  \
+  do {                                                                             \
+    sacc[0] += st1 - st0;                                                          \
+    sacc[1] += st2 - st1;                                                          \
+    sacc[2] += st3 - st2;                                                          \
+    sacc[3] += st4 - st3;                                                          \
+    sitems += 1;                                                                   \
+  } while (0)
+#define STAMP_FLUSH                                                                \
+  do {                                                                             \
+    if (A.dbg && lane == 0) {                                                      \
+      for (int z = 0; z < 4; ++z) atomicAdd(&A.dbg[z], sacc[z]);                   \
+      atomicAdd(&A.dbg[4], sitems);                                                \
+    }                                                                              \
+  } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#define STAMP_DECL
+#define STAMP_ACC do { } while (0)
+#define STAMP_FLUSH do { } while (0)
+#endif
+
 struct LaneGeo {
   long c;      // linear cube index of this lane's cell
   int cc[3];   // cube coordinates
@@ -143,7 +175,10 @@ template <int P, int MODE>
 __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL, S4 = M::S4, MTG = M::MTG;
-  constexpr int PF = 3;  // B-operand prefetch distance, in k-steps
+#ifndef SG_PF
+#define SG_PF 3
+#endif
+  constexpr int PF = SG_PF;  // B-operand prefetch distance, in k-steps
   __shared__ double sAV[M::NFRAG_G * 64];
   __shared__ double sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
@@ -165,7 +200,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 3 * 16;
 
+  STAMP_DECL;
   for (long item = ir.lo; item < ir.hi; item += ir.step) {
+    STAMP(st0);
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
@@ -192,6 +229,19 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
       for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = 0.0;
 
+    double nx[KSF][3];  // neighbour traces of the facet being requested
+    auto request = [&](int f, double (&dst)[KSF][3]) {
+      const NbrRef R = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
+#pragma unroll
+      for (int ks = 0; ks < KSF; ++ks) {
+        const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
+        const int on = sMd.fnode[f][bb];
+        const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dst[ks][i] = R.p[(nn * 3 + i) * R.cstride];
+      }
+    };
+    STAMP(st1);
     // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead
     {
       constexpr int NS = MTG * KS;
@@ -251,69 +301,43 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       }
     }
 
+    STAMP(st2);
     // ---- facet lifts.  u^ = avg(u) on interior facets, own trace on the boundary
     //      (elastic.py:213-216).  The own half of avg(u) is part of the volume tiles (E_r,
     //      mfma_tables.cpp), so the lift carries 1/2 u- on interior facets and the missing
     //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
     //      (a boundary lane's neighbour pointer is its own cell).
+    //      Register budget: the facet's KSF*3 B values stay resident while the row tiles are
+    //      accumulated one at a time (3 accumulators instead of 3*MTL); the next facet's values are
+    //      requested before the last tile pass.
     {
-      constexpr int PFL = 3;  // prefetch distance in facet k-steps
-      const double* np[4];
-      int nst[4];
-      int noff[4][KSF];  // (node*3)*stride offset of this lane's facet node per k-step
+      double flf[KSF][3];
+      request(0, nx);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const NbrRef R = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
-        np[f] = R.p;
-        nst[f] = R.cstride;
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
-          const int on = sMd.fnode[f][bb];
-          const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-          noff[f][ks] = nn * 3 * R.cstride;
-        }
-      }
-      constexpr int NS = 4 * KSF;
-      double nq[PFL][3];
+        for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
-      for (int s = 0; s < PFL; ++s)
+          for (int i = 0; i < 3; ++i) flf[ks][i] = 0.5 * nx[ks][i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) nq[s][i] = np[s / KSF][noff[s / KSF][s % KSF] + i * nst[s / KSF]];
+        for (int t = 0; t < MTL; ++t) {
+          if (t == MTL - 1 && f + 1 < 4) request(f + 1, nx);
+          d4 tmp[3];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        d4 tmp[3][MTL];
+          for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int t = 0; t < MTL; ++t) tmp[i][t] = d4{0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          const int s = f * KSF + ks;
-          double fl[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) fl[i] = 0.5 * nq[s % PFL][i];
-          if (s + PFL < NS) {
-            const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) nq[s % PFL][i] = np[f1][noff[f1][k1] + i * nst[f1]];
-          }
-#pragma unroll
-          for (int t = 0; t < MTL; ++t) {
+          for (int ks = 0; ks < KSF; ++ks) {
             const double a = sAL[((f * MTL + t) * KSF + ks) * 64 + lo];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) tmp[i][t] = MFMA64(a, fl[i], tmp[i][t]);
+            for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
           }
-        }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+          for (int reg = 0; reg < 4; ++reg) {
+            const int m = 4 * t + reg;
+            if (m < S4) {
 #pragma unroll
-          for (int t = 0; t < MTL; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int m = 4 * t + reg;
-              if (m < S4) {
-                const double v = tmp[i][t][reg];
+              for (int i = 0; i < 3; ++i) {
+                const double v = tmp[i][reg];
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
                   const double wv = cnf[f][kk] * v;
@@ -323,14 +347,15 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
                     So[i + kk - 1][m] += wv;
                 }
               }
+#pragma unroll
+              for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
             }
-#pragma unroll
-        for (int m = 0; m < S4; ++m)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+          }
+        }
       }
     }
 
+    STAMP(st3);
     // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
     {
       const long e = (L.valid ? L.c : 0) * 6 + k;
@@ -378,7 +403,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         }
       }
     }
+    STAMP(st4);
+    STAMP_ACC;
   }
+  STAMP_FLUSH;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -407,7 +435,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 9 * 16;
 
+  STAMP_DECL;
   for (long item = ir.lo; item < ir.hi; item += ir.step) {
+    STAMP(st0);
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
       for (int t = 0; t < MTL; ++t) acc[i][t] = d4{0, 0, 0, 0};
 
+    STAMP(st1);
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
     {
       double Tq[9];
@@ -461,32 +492,33 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       }
     }
 
+    STAMP(st2);
     // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary
     //      (elastic.py:206).  The own half of {T} is part of the volume tiles (E_r), so the lift
     //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
     //      cancels the folded half): wf * (c n).T of whatever np[f] points at.
-    {
-      constexpr int PFL = 2;
-      const double* np[4];
-      int nst[4];
-      double wf[4];
-      int noff[4][KSF];
+    constexpr int PFL = 2;  // facet k-steps of neighbour traces in flight
+    const double* np[4];
+    int nst[4];
+    double wf[4];
+    int noff[4][KSF];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
-        np[f] = R.p;
-        nst[f] = R.cstride;
-        wf[f] = R.physical ? -0.5 : 0.5;
+    for (int f = 0; f < 4; ++f) {
+      const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
+      np[f] = R.p;
+      nst[f] = R.cstride;
+      wf[f] = R.physical ? -0.5 : 0.5;
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
-          const int on = sMd.fnode[f][bb];
-          const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-          noff[f][ks] = nn * 9 * R.cstride;
-        }
+      for (int ks = 0; ks < KSF; ++ks) {
+        const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
+        const int on = sMd.fnode[f][bb];
+        const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
+        noff[f][ks] = nn * 9 * R.cstride;
       }
+    }
+    double nq[PFL][9];
+    {
       constexpr int NS = 4 * KSF;
-      double nq[PFL][9];
 #pragma unroll
       for (int s = 0; s < PFL; ++s)
 #pragma unroll
@@ -516,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       }
     }
 
+    STAMP(st3);
     // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
     // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
     // wave runs in program order, so all reads below precede the writes of the epilogue.
@@ -578,7 +611,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         }
       }
     }
+    STAMP(st4);
+    STAMP_ACC;
   }
+  STAMP_FLUSH;
 }
 
 template <int P>
