@@ -242,22 +242,29 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       }
     };
     STAMP(st1);
-    // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead
+    // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead.
+    //      Row tiles are processed in groups of TG with the k loop outside the tiles of a group:
+    //      one load of a B row feeds 3*TG MFMAs, and the cell data are re-read MTG/TG times
+    //      (through L2) instead of MTG times; 3*TG accumulator tiles are live next to Sd/So.
     {
-      constexpr int NS = MTG * KS;
+      constexpr int TG = 2;
+      constexpr int NGRP = (MTG + TG - 1) / TG;
+      constexpr int NS = NGRP * KS;
       double bq[PF][3];
 #pragma unroll
       for (int s = 0; s < PF; ++s)
 #pragma unroll
         for (int i = 0; i < 3; ++i) bq[s][i] = own[bnode[s % KS] + i * 16];
 #pragma unroll
-      for (int t = 0; t < MTG; ++t) {
-        d4 acc[3];
+      for (int grp = 0; grp < NGRP; ++grp) {
+        d4 acc[TG][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] = d4{0, 0, 0, 0};
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[tt][i] = d4{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const int s = t * KS + ks;
+          const int s = grp * KS + ks;
           double b[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) b[i] = bq[s % PF][i];
@@ -265,37 +272,43 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) bq[s % PF][i] = own[bnode[(s + PF) % KS] + i * 16];
           }
-          const double a = sAV[(t * KS + ks) * 64 + lo];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) acc[i] = MFMA64(a, b[i], acc[i]);
-        }
+          for (int tt = 0; tt < TG; ++tt) {
+            const int t = grp * TG + tt;
+            if (t < MTG) {
+              const double a = sAV[(t * KS + ks) * 64 + lo];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int rho4 = 4 * t + reg;
-          const int r = rho4 / S4, m = rho4 % S4;
-          if (r < 3) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const double v = acc[i][reg];
-#pragma unroll
-              for (int kk = 0; kk < 3; ++kk) {
-                const double wv = Jm[r][kk] * v;
-                if (i == kk)
-                  Sd[i][m] += wv;
-                else
-                  So[i + kk - 1][m] += wv;
-              }
+              for (int i = 0; i < 3; ++i) acc[tt][i] = MFMA64(a, b[i], acc[tt][i]);
             }
           }
         }
-        // pin the fold here: LLVM otherwise sinks these FMA chains down to the epilogue (their only
-        // use), which keeps every accumulator tile live and spills
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int m = (4 * t + reg) % S4;
-          if ((4 * t + reg) / S4 < 3) {
+        for (int tt = 0; tt < TG; ++tt) {
+          const int t = grp * TG + tt;
+          if (t < MTG) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+            for (int reg = 0; reg < 4; ++reg) {
+              const int rho4 = 4 * t + reg;
+              const int r = rho4 / S4, m = rho4 % S4;
+              if (r < 3) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                  const double v = acc[tt][i][reg];
+#pragma unroll
+                  for (int kk = 0; kk < 3; ++kk) {
+                    const double wv = Jm[r][kk] * v;
+                    if (i == kk)
+                      Sd[i][m] += wv;
+                    else
+                      So[i + kk - 1][m] += wv;
+                  }
+                }
+                // pin the fold here: LLVM otherwise sinks these FMA chains down to the epilogue
+                // (their only use), which keeps every accumulator tile live and spills
+#pragma unroll
+                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+              }
+            }
           }
         }
       }
