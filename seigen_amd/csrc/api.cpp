@@ -30,6 +30,7 @@ struct sg_handle {
   size_t field_len[4] = {0, 0, 0, 0};    // doubles, host layout (ncells * nd * comps)
   size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
   bool use_mfma = false;
+  bool use_lane = false;
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
@@ -159,8 +160,15 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->ncells = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2] * h->ncls;
   // kernel path: MFMA kernels (interleaved layout) where they exist, unless SEIGEN_HIP_PATH=generic
   const char* path_env = std::getenv("SEIGEN_HIP_PATH");
-  h->use_mfma = mfma_supported(cfg->dim, cfg->degree) && !(path_env && std::strcmp(path_env, "generic") == 0);
-  h->md.gw = h->use_mfma ? 16 : 1;
+  const bool force_generic = path_env && std::strcmp(path_env, "generic") == 0;
+  h->use_mfma = mfma_supported(cfg->dim, cfg->degree) && !force_generic;
+  // lane-per-cell kernels need enough 64-cell groups to fill the chip; below that the
+  // thread-per-node generic kernel has more parallelism (SEIGEN_HIP_PATH=lane forces them)
+  const bool force_lane = path_env && std::strcmp(path_env, "lane") == 0;
+  const int64_t ncube_all = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
+  h->use_lane = !h->use_mfma && lane_supported(cfg->dim, cfg->degree) && !force_generic &&
+                (force_lane || ncube_all * h->ncls >= 32768);
+  h->md.gw = h->use_mfma ? 16 : (h->use_lane ? 64 : 1);
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
   for (int f = 0; f < 4; ++f)
@@ -176,6 +184,24 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   for (int f = 0; f < nfaces; ++f)
     for (int a = 0; a < nd; ++a)
       for (int b = 0; b < nf; ++b) Lt[((size_t)f * nf + b) * nd + a] = h->re.L[((size_t)f * nd + a) * nf + b];
+  if (h->use_lane) {
+    // lane path: E_r = D_r - (L_0 R_0 - L_{r+1} R_{r+1}) / (2 (d-1)!) row-major (own-trace half of the
+    // central flux folded into the volume operator, see mfma_tables.cpp), and L_f row-major
+    double fact = 1.0;
+    for (int i = 2; i <= d - 1; ++i) fact *= i;
+    const double cfold = 1.0 / (2.0 * fact);
+    for (int r = 0; r < d; ++r)
+      for (int a = 0; a < nd; ++a)
+        for (int b = 0; b < nd; ++b) {
+          double v = h->re.D[((size_t)r * nd + a) * nd + b];
+          for (int bf = 0; bf < nf; ++bf) {
+            if (h->re.fnode[(size_t)0 * nf + bf] == b) v -= cfold * h->re.L[((size_t)0 * nd + a) * nf + bf];
+            if (h->re.fnode[(size_t)(r + 1) * nf + bf] == b) v += cfold * h->re.L[((size_t)(r + 1) * nd + a) * nf + bf];
+          }
+          Dt[((size_t)r * nd + a) * nd + b] = v;
+        }
+    for (size_t i = 0; i < Lt.size(); ++i) Lt[i] = h->re.L[i];
+  }
   HIPCHECK(h, hipMalloc((void**)&h->Dt, Dt.size() * sizeof(double)));
   HIPCHECK(h, hipMalloc((void**)&h->Lt, Lt.size() * sizeof(double)));
   HIPCHECK(h, hipMalloc((void**)&h->md_dev, sizeof(MeshDev)));
@@ -581,8 +607,13 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       empty = empty || (b.n[k] <= 0);
     }
     if (empty) continue;
-    int rc = h->use_mfma ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
-                         : launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
+    int rc;
+    if (h->use_mfma)
+      rc = launch_stage_mfma(kind, h->cfg.degree, a, h->stream);
+    else if (h->use_lane)
+      rc = launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
+    else
+      rc = launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
     if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
   }
   return SG_OK;

@@ -36,6 +36,11 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream);
 bool mfma_supported(int dim, int P);
 int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream);
 
+// lane-per-cell path (1-D / 2-D; fields in the gw = 64 interleaved layout; a.Dt = E[r][a][b],
+// a.Lt = L[f][a][b'] row-major)
+bool lane_supported(int dim, int P);
+int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream);
+
 // host layout [cell][node][comp] <-> device layout (MeshDev::gw) for `ncells` cells from `cell0`
 // dir = 0: staging -> field, 1: field -> staging
 int launch_layout(const MeshDev& md_host, int ncomp, int dir, double* field, double* staging, int64_t cell0,

@@ -1,0 +1,363 @@
+// Lane-per-cell stage kernels for small elements (1-D and 2-D, P1..P4; gfx950, FP64).
+//
+// With at most 15 nodes per cell the whole cell fits in one lane's registers, so the wavefront
+// is used as 64 independent cells: lane l owns cell (cube 64g + l, class k) of a group of 64
+// consecutive cubes.  Fields use the gw = 64 interleaved layout (mesh_tables.hpp): the 64 values
+// of one (node, component) are one contiguous 512-byte run, so every load and store of the
+// kernel is a full-width coalesced wave access, all of a cell's operands are requested up front
+// (maximum memory-level parallelism), and there is no LDS traffic for cell data at all.
+//
+// The reference operators are the same for all 64 lanes: they are read through the scalar
+// cache (s_load) and enter the FMAs as scalar operands.  E_r = D_r - C_r folds the own-trace
+// half of the central flux into the volume operator (mfma_tables.cpp), so the facet lifts carry
+// only the neighbour's half.  The path is HBM-bound: ~0.1 kflop per 64 bytes at 2-D P2.
+//
+//   F:  uh_i  = -sum_r E_r (Jinv_rj T_ij) + sum_f L_f [ w_f (c n)_f,j T(nbr)_ij ]  - sponge
+//   G:  W_ik  = -Jinv_rk (E_r u_i) + sum_f (c n)_f,k L_f [ 1/2 u(nbr)_i ];  sh = lam tr(W) I + mu (W + W^T)
+// (seigen/elastic.py:204-219 with the element mass inverse of :358-367 folded in.)
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace sg {
+
+template <int DIM, int P>
+struct LG {
+  static constexpr int ND = (DIM == 1) ? (P + 1) : (P + 1) * (P + 2) / 2;
+  static constexpr int NF = (DIM == 1) ? 1 : (P + 1);
+  static constexpr int NFACES = DIM + 1;
+  static constexpr int NCLS = (DIM == 1) ? 1 : 2;
+};
+
+struct LaneCell {
+  long c;
+  int cc[3];
+  bool valid, active;
+};
+
+__device__ __forceinline__ LaneCell lane_cell(const MeshDev* md, const StageArgs& A, long g, int lane) {
+  LaneCell L;
+  L.c = g * 64 + lane;
+  L.valid = L.c < md->ncube;
+  long cl = L.valid ? L.c : 0;
+  L.cc[0] = (int)(cl % md->n[0]);
+  long t = cl / md->n[0];
+  L.cc[1] = (int)(t % md->n[1]);
+  L.cc[2] = (int)(t / md->n[1]);
+  bool in = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) in = in && (L.cc[a] >= A.box_o[a]) && (L.cc[a] < A.box_o[a] + A.box_n[a]);
+  L.active = L.valid && in;
+  return L;
+}
+
+struct LaneNbr {
+  const double* p;
+  int cstride;    // 64 in a field, 1 in a packed ghost buffer
+  bool ghost, physical;
+};
+
+template <int DIM, int ND, int NF, int NC, int NCLS>
+__device__ __forceinline__ LaneNbr lane_nbr(const MeshDev* md, const StageArgs& A, const LaneCell& L, long g, int k, int f,
+                                            int lane, const double* own) {
+  LaneNbr R;
+  R.p = own;
+  R.cstride = 64;
+  R.ghost = false;
+  R.physical = false;
+  const int axis = md->nb_axis[k][f];
+  const int kn = md->nb_cls[k][f];
+  if (axis < 0) {
+    R.p = A.in + ((g * NCLS + kn) * (long)ND) * NC * 64 + lane;
+    return R;
+  }
+  const int dir = md->nb_dir[k][f];
+  const int cn = L.cc[axis] + dir;
+  const bool inside = L.valid && cn >= 0 && cn < md->n[axis];
+  const long stride = (axis == 0) ? 1 : (axis == 1) ? md->n[0] : (long)md->n[0] * md->n[1];
+  const long nc = inside ? L.c + dir * stride : L.c;
+  const double* pin = A.in + (((nc >> 6) * NCLS + (inside ? kn : k)) * (long)ND) * NC * 64 + (nc & 63);
+  const int side = 2 * axis + (dir > 0 ? 1 : 0);
+  if (!inside && L.valid && md->has_nbr[side]) {
+    long c2 = (axis == 0) ? (L.cc[1] + (long)md->n[1] * L.cc[2])
+                          : (axis == 1) ? (L.cc[0] + (long)md->n[0] * L.cc[2]) : (L.cc[0] + (long)md->n[0] * L.cc[1]);
+    long slot = c2 * md->halo_per_cube + md->face_ord[kn][md->nb_face[k][f]];
+    R.p = A.ghost[side] + slot * NF * NC;
+    R.cstride = 1;
+    R.ghost = true;
+    return R;
+  }
+  R.p = pin;
+  R.physical = !inside;
+  return R;
+}
+
+template <int DIM, int P, int KIND, int MODE>
+__global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
+  using G = LG<DIM, P>;
+  constexpr int ND = G::ND, NF = G::NF, NFACES = G::NFACES, NCLS = G::NCLS;
+  constexpr int NC = (KIND == 0) ? DIM * DIM : DIM;  // input components
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const MeshDev* md = A.md;                 // uniform: scalar loads
+  // operator tables are read-only and indexed uniformly: constant address space => s_load, and the
+  // values enter the FMAs as scalar operands (a plain global pointer out of the by-value argument
+  // struct carries no noalias/readonly information and hipcc would use per-lane vector loads)
+  typedef __attribute__((address_space(4))) const double cdouble;
+  const cdouble* Eop = (const cdouble*)(unsigned long long)A.Dt;  // [r][a][b]  E_r (row-major; lane path)
+  const cdouble* Lop = (const cdouble*)(unsigned long long)A.Lt;  // [f][a][b']
+  const double* __restrict__ in = A.in;
+  const double* __restrict__ aux = A.aux;
+  double* __restrict__ out = A.out;
+
+  const long ngroups = md->ncube_pad >> 6;
+  const long nitems = ngroups * NCLS;
+  // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2)
+  const long nblk = gridDim.x, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const long blocks_here = (nblk - xcd + 7) / 8, ipx = (nitems + 7) / 8;
+  const long lo = xcd * ipx, hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
+
+  for (long item = lo + slot * 4 + wave; item < hi; item += blocks_here * 4) {
+    const long g = item / NCLS;
+    const int k = (int)(item - g * NCLS);
+    const LaneCell L = lane_cell(md, A, g, lane);
+    if (!__any(L.active)) continue;
+    const double* own = in + ((g * NCLS + k) * (long)ND) * NC * 64 + lane;
+
+    double Jv[DIM][DIM], cnv[NFACES][DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) Jv[r][j] = md->Jinv[k][r][j];
+#pragma unroll
+    for (int f = 0; f < NFACES; ++f)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) cnv[f][j] = md->cn[k][f][j];
+
+    // where each facet's neighbour trace lives (a boundary lane's neighbour is its own cell)
+    const double* np[NFACES];
+    int nst[NFACES];
+    double wf[NFACES];
+    int nnode[NFACES][NF];
+#pragma unroll
+    for (int f = 0; f < NFACES; ++f) {
+      const LaneNbr R = lane_nbr<DIM, ND, NF, NC, NCLS>(md, A, L, g, k, f, lane, own);
+      np[f] = R.p;
+      nst[f] = R.cstride;
+      // F: +1/2 neighbour flux inside, -1/2 own flux on the boundary (cancels the folded half: T.n = 0);
+      // G: 1/2 of the neighbour, or the missing 1/2 of the own trace on the boundary
+      wf[f] = (KIND == 0 && R.physical) ? -0.5 : 0.5;
+#pragma unroll
+      for (int bp = 0; bp < NF; ++bp) {
+        const int on = md->fnode[f][bp];
+        nnode[f][bp] = (R.ghost ? md->nb_fnode[k][f][bp] : (R.physical ? on : md->nb_node[k][f][bp])) * NC * R.cstride;
+      }
+    }
+    const long e = (L.valid ? L.c : 0) * NCLS + k;
+
+    if (KIND == 0) {
+      // ---- F, one velocity component i at a time: only row i of the stress is needed, which
+      //      halves (2-D) the live registers and doubles the resident waves
+      int sslot = -1;
+      if (A.sponge_slot != nullptr && L.active) sslot = A.sponge_slot[e];
+      const bool any_sponge = __any(sslot >= 0);
+      const long ubase = ((g * NCLS + k) * (long)ND) * DIM * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        double q[ND][DIM];  // T_ij (j = 0..DIM-1) at every node, all requested at once
+#pragma unroll
+        for (int b = 0; b < ND; ++b)
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) q[b][j] = own[(b * NC + i * DIM + j) * 64];
+        double fl[NFACES][NF];  // w_f (c n)_f,j T(nbr)_ij
+#pragma unroll
+        for (int f = 0; f < NFACES; ++f)
+#pragma unroll
+          for (int bp = 0; bp < NF; ++bp) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) sacc += cnv[f][j] * np[f][nnode[f][bp] + (i * DIM + j) * nst[f]];
+            fl[f][bp] = wf[f] * sacc;
+          }
+        // sponge operand and in-place combine operands, read before this cell's u_i is written
+        double ua[ND];
+        if (any_sponge) {
+#pragma unroll
+          for (int b = 0; b < ND; ++b) ua[b] = A.uabs[ubase + (b * DIM + i) * 64];
+        }
+        double po[ND], pa[ND];
+        if (MODE == 1) {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            po[a] = out[ubase + (a * DIM + i) * 64];
+            pa[a] = aux[ubase + (a * DIM + i) * 64];
+          }
+        }
+        // T~_ir = Jinv_rj T_ij
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+          double t[DIM];
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) sacc += Jv[r][j] * q[b][j];
+            t[r] = sacc;
+          }
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) q[b][r] = t[r];
+        }
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          double acc = 0.0;
+#pragma unroll
+          for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int b = 0; b < ND; ++b) acc -= Eop[(r * ND + a) * ND + b] * q[b][r];
+#pragma unroll
+          for (int f = 0; f < NFACES; ++f)
+#pragma unroll
+            for (int bp = 0; bp < NF; ++bp) acc += Lop[(f * ND + a) * NF + bp] * fl[f][bp];
+          if (any_sponge && sslot >= 0) {
+            const double* B = A.sponge_B + ((long)sslot * ND + a) * ND;
+#pragma unroll
+            for (int b = 0; b < ND; ++b) acc -= B[b] * ua[b];
+          }
+          if (MODE == 1) acc = A.c_self * po[a] + A.c_aux * pa[a] + A.c_new * acc;
+          if (L.active) out[ubase + (a * DIM + i) * 64] = acc;
+        }
+      }
+    } else {
+      // ---- G: the cell's velocity and the halved neighbour traces, all requested at once
+      double q[ND][DIM];
+#pragma unroll
+      for (int b = 0; b < ND; ++b)
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) q[b][c] = own[(b * NC + c) * 64];
+      double fl[NFACES][NF][DIM];
+#pragma unroll
+      for (int f = 0; f < NFACES; ++f)
+#pragma unroll
+        for (int bp = 0; bp < NF; ++bp)
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) fl[f][bp][i] = wf[f] * np[f][nnode[f][bp] + i * nst[f]];
+      const double lam = A.per_cell ? A.lam[e] : A.lam0;
+      const double mu = A.per_cell ? A.mu[e] : A.mu0;
+      const long sbase = ((g * NCLS + k) * (long)ND) * DIM * DIM * 64 + lane;
+      double po[DIM * DIM], pa[DIM * DIM];   // in-place combine operands, one node ahead
+      if (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < DIM * DIM; ++c) {
+          po[c] = out[sbase + c * 64];
+          pa[c] = aux[sbase + c * 64];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        double R[DIM][DIM];  // (E_r u_i)_a
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) R[i][r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+          for (int b = 0; b < ND; ++b) {
+            const double ev = Eop[(r * ND + a) * ND + b];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) R[i][r] += ev * q[b][i];
+          }
+        double W[DIM][DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int kk = 0; kk < DIM; ++kk) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) sacc -= Jv[r][kk] * R[i][r];
+            W[i][kk] = sacc;
+          }
+#pragma unroll
+        for (int f = 0; f < NFACES; ++f) {
+          double lu[DIM];
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) lu[i] = 0.0;
+#pragma unroll
+          for (int bp = 0; bp < NF; ++bp) {
+            const double lv = Lop[(f * ND + a) * NF + bp];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) lu[i] += lv * fl[f][bp][i];
+          }
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+#pragma unroll
+            for (int kk = 0; kk < DIM; ++kk) W[i][kk] += cnv[f][kk] * lu[i];
+        }
+        double trc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < DIM; ++kk) trc += W[kk][kk];
+        double v[DIM * DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) {
+            v[i * DIM + j] = mu * (W[i][j] + W[j][i]) + ((i == j) ? lam * trc : 0.0);
+            if (MODE == 1) v[i * DIM + j] = A.c_self * po[i * DIM + j] + A.c_aux * pa[i * DIM + j] + A.c_new * v[i * DIM + j];
+          }
+        if (MODE == 1 && a + 1 < ND) {
+#pragma unroll
+          for (int c = 0; c < DIM * DIM; ++c) {
+            po[c] = out[sbase + ((a + 1) * DIM * DIM + c) * 64];
+            pa[c] = aux[sbase + ((a + 1) * DIM * DIM + c) * 64];
+          }
+        }
+        if (L.active) {
+#pragma unroll
+          for (int c = 0; c < DIM * DIM; ++c) out[sbase + (a * DIM * DIM + c) * 64] = v[c];
+        }
+      }
+    }
+  }
+}
+
+template <int DIM, int P>
+static int launch_lane_dp(int kind, const StageArgs& a, long nitems, hipStream_t s) {
+  long blocks = (nitems + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  blocks = (blocks + 7) / 8 * 8;  // every XCD label needs a block
+  const dim3 grid((unsigned)blocks), block(256);
+  if (kind == 0) {
+    if (a.mode == 0)
+      hipLaunchKernelGGL((lane_stage<DIM, P, 0, 0>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((lane_stage<DIM, P, 0, 1>), grid, block, 0, s, a);
+  } else {
+    if (a.mode == 0)
+      hipLaunchKernelGGL((lane_stage<DIM, P, 1, 0>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((lane_stage<DIM, P, 1, 1>), grid, block, 0, s, a);
+  }
+  return (int)hipGetLastError();
+}
+
+template <int DIM>
+static int launch_lane_d(int kind, int P, const StageArgs& a, long nitems, hipStream_t s) {
+  switch (P) {
+    case 1: return launch_lane_dp<DIM, 1>(kind, a, nitems, s);
+    case 2: return launch_lane_dp<DIM, 2>(kind, a, nitems, s);
+    case 3: return launch_lane_dp<DIM, 3>(kind, a, nitems, s);
+    case 4: return launch_lane_dp<DIM, 4>(kind, a, nitems, s);
+  }
+  return -1;
+}
+
+bool lane_supported(int dim, int P) { return (dim == 1 || dim == 2) && P >= 1 && P <= 4; }
+
+int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (dim == 1) return launch_lane_d<1>(kind, P, a, nitems, s);
+  if (dim == 2) return launch_lane_d<2>(kind, P, a, nitems, s);
+  return -1;
+}
+
+}  // namespace sg

@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, w = lane & 15;
-  const MeshDev* md = A.md;  // uniform reads of class constants go through the scalar cache
+  // uniform reads of class constants: constant address space => s_load (scalar cache)
+  typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
+  const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
   const double* __restrict__ in = A.in;
   const double* __restrict__ aux = A.aux;
   double* __restrict__ out = A.out;
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, w = lane & 15;
-  const MeshDev* md = A.md;
+  typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
+  const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
   const double* __restrict__ in = A.in;
   const double* __restrict__ aux = A.aux;
   double* __restrict__ out = A.out;
