@@ -31,6 +31,8 @@ struct sg_handle {
   size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
   bool use_mfma = false;
   bool use_lane = false;
+  bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
+  int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
@@ -103,6 +105,7 @@ void sg_destroy(sg_handle* h) {
   if (h->fragG) (void)hipFree(h->fragG);
   if (h->fragL) (void)hipFree(h->fragL);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->sym_flag) (void)hipFree(h->sym_flag);
   if (h->dbg) {
     unsigned long long v[32];
     if (hipMemcpy(v, h->dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
@@ -225,6 +228,14 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragF, fF.data(), fF.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (h->use_mfma) {
+    // symmetric-stress mode: fields start at zero, g only produces symmetric tensors;
+    // left for good as soon as the user uploads a non-symmetric stress or source (SEIGEN_HIP_SYM=0: never entered)
+    const char* sym_env = std::getenv("SEIGEN_HIP_SYM");
+    h->sym = !(sym_env && std::strcmp(sym_env, "0") == 0);
+    HIPCHECK(h, hipMalloc((void**)&h->sym_flag, sizeof(int)));
+    HIPCHECK(h, hipMemset(h->sym_flag, 0, sizeof(int)));
   }
   if (std::getenv("SEIGEN_HIP_STAMPS")) {
     HIPCHECK(h, hipMalloc((void**)&h->dbg, 32 * sizeof(unsigned long long)));
@@ -351,6 +362,16 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
   return SG_OK;
 }
 
+// Leave symmetric-stress mode: make the (i > j) lines of both stress buffers valid again.
+static int leave_sym_mode(sg_handle* h) {
+  if (!h->sym) return SG_OK;
+  for (int f : {SG_FIELD_S, SG_FIELD_SH})
+    if (launch_mirror(h->md, h->field[f], h->stream) != 0) return fail(h, SG_ERR_DEVICE, "mirror kernel launch failed");
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  h->sym = false;
+  return SG_OK;
+}
+
 // Copy `ncells` cells from `cell0` between a host array in the reference layout and the device
 // field.  gw == 1: the layouts coincide; otherwise go through a staging buffer + layout kernel.
 static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, bool to_device) {
@@ -378,14 +399,27 @@ static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, doub
     size_t nb = (size_t)n * per_cell * sizeof(double);
     if (to_device) {
       HIPCHECK(h, hipMemcpy(h->staging, host + (size_t)done * per_cell, nb, hipMemcpyHostToDevice));
-      if (launch_layout(h->md, comps, 0, h->field[field], h->staging, cell0 + done, n, h->stream) != 0)
+      int* flag = (h->sym && field_is_stress(field)) ? h->sym_flag : nullptr;
+      if (launch_layout(h->md, comps, 0, h->field[field], h->staging, cell0 + done, n, 0, flag, h->stream) != 0)
         return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
       HIPCHECK(h, hipStreamSynchronize(h->stream));
     } else {
-      if (launch_layout(h->md, comps, 1, h->field[field], h->staging, cell0 + done, n, h->stream) != 0)
+      const int symdl = (h->sym && field_is_stress(field)) ? 1 : 0;
+      if (launch_layout(h->md, comps, 1, h->field[field], h->staging, cell0 + done, n, symdl, nullptr, h->stream) != 0)
         return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
       HIPCHECK(h, hipStreamSynchronize(h->stream));
       HIPCHECK(h, hipMemcpy(host + (size_t)done * per_cell, h->staging, nb, hipMemcpyDeviceToHost));
+    }
+  }
+  if (to_device && h->sym && field_is_stress(field)) {
+    int flag = 0;
+    HIPCHECK(h, hipMemcpy(&flag, h->sym_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+      // a non-symmetric stress arrived: make every (i > j) line of both stress buffers valid (they
+      // are stale wherever kernels ran in symmetric mode), then repeat this upload in full mode
+      int rc = leave_sym_mode(h);
+      if (rc != SG_OK) return rc;
+      return transfer(h, field, cell0, ncells, host, true);
     }
   }
   return SG_OK;
@@ -493,6 +527,16 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   int64_t nscalar = h->ncells * h->re.nd;
   for (int64_t k = 0; k < nnz; ++k)
     if (nodes[k] < 0 || nodes[k] >= nscalar) return fail(h, SG_ERR_ARG, "sg_set_source: node index out of range");
+  if (h->sym) {
+    bool symmetric = true;
+    for (int64_t i = 0; i < nsteps * nnz && symmetric; ++i)
+      for (int a = 0; a < d; ++a)
+        for (int b = a + 1; b < d; ++b) symmetric = symmetric && values[i * d * d + a * d + b] == values[i * d * d + b * d + a];
+    if (!symmetric) {
+      int rc = leave_sym_mode(h);
+      if (rc != SG_OK) return rc;
+    }
+  }
   size_t vbytes = (size_t)nsteps * nnz * d * d * sizeof(double);
   HIPCHECK(h, hipMalloc((void**)&h->src_nodes, (size_t)nnz * sizeof(int64_t)));
   HIPCHECK(h, hipMalloc((void**)&h->src_values, vbytes));
@@ -585,6 +629,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.md = h->md_dev;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
+  a.sym = h->sym ? 1 : 0;
   a.dbg = h->dbg ? h->dbg + 8 * (kind * 2 + (mode ? 1 : 0)) : nullptr;
   a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
   a.sponge_B = h->sponge_B;
@@ -779,7 +824,8 @@ int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   const int d = h->cfg.dim;
   int comps = field_is_stress(field) ? d * d : d;
-  int rc = launch_pack(d, h->cfg.degree, h->md_dev, h->md, h->field[field], comps, side, (double*)dev_out, h->stream);
+  int rc = launch_pack(d, h->cfg.degree, h->md_dev, h->md, h->field[field], comps, side, (double*)dev_out,
+                       (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
   return SG_OK;
 }

@@ -325,7 +325,8 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
 }
 
 // ---- halo pack ------------------------------------------------------------------------
-__global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, int side, long nslots, double* out) {
+__global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, int side, long nslots, double* out,
+                            int sym) {
   const int nd = md->nd, nf = md->nf, ncls = md->ncls, nfaces = md->nfaces, hpc = md->halo_per_cube;
   const int axis = side >> 1, hi = side & 1;
   long total = nslots * nf * ncomp;
@@ -360,13 +361,18 @@ __global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, i
           f = ff;
         }
     const int gw = md->gw;
-    long off = ((((cube / gw) * ncls + cls) * (long)nd + md->fnode[f][b]) * ncomp + cpt) * gw + cube % gw;
+    int cs = cpt;
+    if (sym) {  // symmetric-mode stress field: the (i > j) lines are stale, read the mirror
+      const int d = md->dim, i = cpt / d, j = cpt % d;
+      if (i > j) cs = j * d + i;
+    }
+    long off = ((((cube / gw) * ncls + cls) * (long)nd + md->fnode[f][b]) * ncomp + cs) * gw + cube % gw;
     out[idx] = field[off];
   }
 }
 
 int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& mh, const double* field, int ncomp, int side,
-                double* out, void* stream) {
+                double* out, int sym, void* stream) {
   (void)dim;
   (void)P;
   int axis = side >> 1;
@@ -379,7 +385,7 @@ int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& mh, const 
   long grid = (total + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, field, ncomp, side,
-                     nslots, out);
+                     nslots, out, sym);
   return (int)hipGetLastError();
 }
 
@@ -403,8 +409,8 @@ int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* 
 }
 
 // ---- host <-> device layout ------------------------------------------------------------------
-__global__ void layout_kernel(int nd, int ncls, int gw, int ncomp, int dir, double* field, double* staging, long cell0,
-                              long ncells) {
+__global__ void layout_kernel(int dim, int nd, int ncls, int gw, int ncomp, int dir, double* field, double* staging,
+                              long cell0, long ncells, int sym, int* flag) {
   const long per_cell = (long)nd * ncomp;
   const long total = ncells * per_cell;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -412,22 +418,55 @@ __global__ void layout_kernel(int nd, int ncls, int gw, int ncomp, int dir, doub
     long rem = idx % per_cell;
     long cube = e / ncls;
     int cls = (int)(e % ncls);
-    long off = (((cube / gw) * ncls + cls) * per_cell + rem) * gw + cube % gw;
-    if (dir == 0)
-      field[off] = staging[idx];
-    else
+    if (dir == 0) {
+      long off = (((cube / gw) * ncls + cls) * per_cell + rem) * gw + cube % gw;
+      double v = staging[idx];
+      field[off] = v;
+      if (flag != nullptr && ncomp == dim * dim) {  // tensor upload: report any asymmetry
+        int cpt = (int)(rem % ncomp), i = cpt / dim, j = cpt % dim;
+        if (i < j && staging[idx - cpt + j * dim + i] != v) *flag = 1;
+      }
+    } else {
+      long r2 = rem;
+      if (sym) {  // lower-triangle lines are stale in symmetric mode: deliver the mirror
+        int cpt = (int)(rem % ncomp), i = cpt / dim, j = cpt % dim;
+        if (i > j) r2 = rem - cpt + j * dim + i;
+      }
+      long off = (((cube / gw) * ncls + cls) * per_cell + r2) * gw + cube % gw;
       staging[idx] = field[off];
+    }
   }
 }
 
 int launch_layout(const MeshDev& mh, int ncomp, int dir, double* field, double* staging, int64_t cell0, int64_t ncells,
-                  void* stream) {
+                  int sym, int* flag, void* stream) {
   if (ncells <= 0) return 0;
   long total = ncells * (long)mh.nd * ncomp;
   long grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(layout_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.nd, mh.ncls, mh.gw, ncomp,
-                     dir, field, staging, (long)cell0, (long)ncells);
+  hipLaunchKernelGGL(layout_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls, mh.gw,
+                     ncomp, dir, field, staging, (long)cell0, (long)ncells, sym, flag);
+  return (int)hipGetLastError();
+}
+
+__global__ void mirror_kernel(int dim, int nd, int ncls, int gw, double* field, long ncube_pad) {
+  const int nc = dim * dim;
+  const long total = ncube_pad * ncls * nd * nc;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long w = idx % gw;
+    long t = idx / gw;
+    int cpt = (int)(t % nc);
+    int i = cpt / dim, j = cpt % dim;
+    if (i > j) field[idx] = field[(t - cpt + j * dim + i) * gw + w];
+  }
+}
+
+int launch_mirror(const MeshDev& mh, double* field, void* stream) {
+  long total = mh.ncube_pad * mh.ncls * (long)mh.nd * mh.dim * mh.dim;
+  long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(mirror_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls, mh.gw,
+                     field, (long)mh.ncube_pad);
   return (int)hipGetLastError();
 }
 

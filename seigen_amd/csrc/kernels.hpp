@@ -27,6 +27,7 @@ struct StageArgs {
   int32_t mode;                 // 0: out = rhs
   int32_t per_cell;
   int32_t box_o[3], box_n[3];   // region of cubes covered by this launch
+  int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)
@@ -43,12 +44,17 @@ int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems,
 
 // host layout [cell][node][comp] <-> device layout (MeshDev::gw) for `ncells` cells from `cell0`
 // dir = 0: staging -> field, 1: field -> staging
+// sym = 1 (stress field in symmetric mode): a download mirrors the lower triangle from the upper;
+// flag (device int, may be null): set to 1 by an upload whose tensors are not exactly symmetric
 int launch_layout(const MeshDev& md_host, int ncomp, int dir, double* field, double* staging, int64_t cell0,
-                  int64_t ncells, void* stream);
+                  int64_t ncells, int sym, int* flag, void* stream);
+// copy the upper triangle over the lower one in a whole stress field (leaving symmetric mode)
+int launch_mirror(const MeshDev& md_host, double* field, void* stream);
 
 // facet traces of a field on one block side -> packed device buffer
+// (sym = 1: a stress field stored in symmetric mode; lower-triangle values come from their mirrors)
 int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& md_host, const double* field, int ncomp, int side,
-                double* out, void* stream);
+                double* out, int sym, void* stream);
 
 // field[off[k] + c*gw] += coef * values[k][c] at the sparse source nodes (off = device offset of comp 0)
 int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,

@@ -72,6 +72,29 @@ struct MG {
 #define STAMP_FLUSH do { } while (0)
 #endif
 
+// Symmetric-stress mode (SYM = 1): every stress field of the run is symmetric (g always produces
+// a symmetric tensor, elastic.py:211-219; api.cpp checks what the user uploads), so only the six
+// lines (i <= j) of each node are read and written; the other three keep their slots but are
+// never touched.  Same results, 1/3 less stress traffic.
+template <int SYM>
+__device__ __forceinline__ void load_tensor(const double* p, int stride, double (&T)[9]) {
+  if (SYM) {
+    T[0] = p[0];
+    T[1] = p[1 * stride];
+    T[2] = p[2 * stride];
+    T[4] = p[4 * stride];
+    T[5] = p[5 * stride];
+    T[8] = p[8 * stride];
+    T[3] = T[1];
+    T[6] = T[2];
+    T[7] = T[5];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) T[c] = p[c * stride];
+  }
+}
+__device__ __forceinline__ constexpr bool upper(int ij) { return (ij / 3) <= (ij % 3); }
+
 struct LaneGeo {
   long c;      // linear cube index of this lane's cell
   int cc[3];   // cube coordinates
@@ -171,7 +194,7 @@ __device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* s
 //  Volume rows are stacked rho = 4*S4*r + a (mfma_tables.cpp) so that the three D_r u_i of
 //  one node sit in the same lane; only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
 // --------------------------------------------------------------------------------------------
-template <int P, int MODE>
+template <int P, int MODE, int SYM>
 __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL, S4 = M::S4, MTG = M::MTG;
@@ -381,10 +404,11 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       if (MODE == 1) {
         const long o0 = obase + (long)q * 9 * 16;
 #pragma unroll
-        for (int ij = 0; ij < 9; ++ij) {
-          po[ij] = out[o0 + ij * 16];
-          pa[ij] = aux[o0 + ij * 16];
-        }
+        for (int ij = 0; ij < 9; ++ij)
+          if (!SYM || upper(ij)) {
+            po[ij] = out[o0 + ij * 16];
+            pa[ij] = aux[o0 + ij * 16];
+          }
       }
 #pragma unroll
       for (int m = 0; m < S4; ++m) {
@@ -401,20 +425,23 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         s[5] = s[7] = mu * So[2][m];
         if (MODE == 1) {
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij) s[ij] = A.c_self * po[ij] + A.c_aux * pa[ij] + A.c_new * s[ij];
+          for (int ij = 0; ij < 9; ++ij)
+            if (!SYM || upper(ij)) s[ij] = A.c_self * po[ij] + A.c_aux * pa[ij] + A.c_new * s[ij];
           if (m + 1 < S4) {
             const int a1 = 4 * (m + 1) + q;
             const long o1 = obase + (long)((a1 < ND) ? a1 : 0) * 9 * 16;
 #pragma unroll
-            for (int ij = 0; ij < 9; ++ij) {
-              po[ij] = out[o1 + ij * 16];
-              pa[ij] = aux[o1 + ij * 16];
-            }
+            for (int ij = 0; ij < 9; ++ij)
+              if (!SYM || upper(ij)) {
+                po[ij] = out[o1 + ij * 16];
+                pa[ij] = aux[o1 + ij * 16];
+              }
           }
         }
         if (st) {
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
+          for (int ij = 0; ij < 9; ++ij)
+            if (!SYM || upper(ij)) out[o + ij * 16] = s[ij];
         }
       }
     }
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 // --------------------------------------------------------------------------------------------
 //  F: uh_i = -sum_r D_r (Jinv_rj T_ij) + sum_f L_f [ (c n)_j {T_ij} ] - sponge
 // --------------------------------------------------------------------------------------------
-template <int P, int MODE>
+template <int P, int MODE, int SYM>
 __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL;
@@ -482,16 +509,14 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
     {
       double Tq[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) Tq[c] = own[bnode[0] + c * 16];
+      load_tensor<SYM>(own + bnode[0], 16, Tq);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         double T[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) T[c] = Tq[c];
         if (ks + 1 < KS) {
-#pragma unroll
-          for (int c = 0; c < 9; ++c) Tq[c] = own[bnode[ks + 1] + c * 16];
+          load_tensor<SYM>(own + bnode[ks + 1], 16, Tq);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -537,8 +562,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       constexpr int NS = 4 * KSF;
 #pragma unroll
       for (int s = 0; s < PFL; ++s)
-#pragma unroll
-        for (int c = 0; c < 9; ++c) nq[s][c] = np[s / KSF][noff[s / KSF][s % KSF] + c * nst[s / KSF]];
+        load_tensor<SYM>(np[s / KSF] + noff[s / KSF][s % KSF], nst[s / KSF], nq[s]);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -551,8 +575,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
                              cnf[f][2] * nq[s % PFL][i * 3 + 2]);
           if (s + PFL < NS) {
             const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) nq[s % PFL][c] = np[f1][noff[f1][k1] + c * nst[f1]];
+            load_tensor<SYM>(np[f1] + noff[f1][k1], nst[f1], nq[s % PFL]);
           }
 #pragma unroll
           for (int t = 0; t < MTL; ++t) {
@@ -633,21 +656,26 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   STAMP_FLUSH;
 }
 
-template <int P>
-static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
+template <int P, int SYM>
+static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
   const dim3 grid(512), block(256);  // 2 blocks per CU; a multiple of 8 (one item range per XCD label)
   if (kind == 0) {
     if (a.mode == 0)
-      hipLaunchKernelGGL((mfma_stage_F<P, 0>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM>), grid, block, 0, s, a);
     else
-      hipLaunchKernelGGL((mfma_stage_F<P, 1>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((mfma_stage_F<P, 1, SYM>), grid, block, 0, s, a);
   } else {
     if (a.mode == 0)
-      hipLaunchKernelGGL((mfma_stage_G<P, 0>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((mfma_stage_G<P, 0, SYM>), grid, block, 0, s, a);
     else
-      hipLaunchKernelGGL((mfma_stage_G<P, 1>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((mfma_stage_G<P, 1, SYM>), grid, block, 0, s, a);
   }
   return (int)hipGetLastError();
+}
+
+template <int P>
+static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
+  return a.sym ? launch_ps<P, 1>(kind, a, s) : launch_ps<P, 0>(kind, a, s);
 }
 
 bool mfma_supported(int dim, int P) { return dim == 3 && (P == 3 || P == 4); }

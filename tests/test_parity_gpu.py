@@ -139,3 +139,42 @@ def test_against_committed_golden_vectors(gpu):
         blk.step(9)
         assert rel_err(blk.get_field(_lib.FIELD_U), d[key + "_u_step10"]) < 100 * TOL
         assert rel_err(blk.get_field(_lib.FIELD_S), d[key + "_s_step10"]) < 100 * TOL
+
+
+def test_symmetric_stress_mode_and_fallback(gpu):
+    """3-D P3/P4 run in symmetric-stress mode (only the i <= j lines of stress fields are touched).
+    A non-symmetric upload must leave that mode: F then sees the antisymmetric part exactly as the
+    reference's full TensorFunctionSpace does (elastic.py:81)."""
+    from seigen_amd import _lib
+    dim, degree, n, L = 3, 4, (2, 2, 3), (1.0, 1.0, 1.0)
+    m = oracle_mesh(dim, n, L)
+    for symmetric in (True, False):
+        blk = make_block(dim, degree, n, L, "left")
+        orc = OracleLF4(m, degree)
+        orc.dt, orc.l, orc.mu, orc.density = 1e-3, 0.5, 0.25, 1.0
+        orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 21)
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 22)
+        if symmetric:
+            s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        orc.s0 = s0.copy()
+        blk.set_params(1.0, orc.dt, orc.l, orc.mu)
+        blk.set_field(_lib.FIELD_U, orc.u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        # what comes back is what went in, mirrored lines included
+        np.testing.assert_array_equal(blk.get_field(_lib.FIELD_S), s0)
+        blk.step(2)
+        orc.step(orc.dt)
+        orc.step(2 * orc.dt)
+        assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
+        assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+        assert rel_err(blk.get_field(_lib.FIELD_SH), orc.last["sh1"]) < 10 * TOL
+        if symmetric:
+            # switch mid-run: upload a non-symmetric stress now and keep stepping
+            s_now = blk.get_field(_lib.FIELD_S)
+            s_now[..., 0, 1] += 0.125
+            blk.set_field(_lib.FIELD_S, s_now)
+            orc.s0 = s_now.copy()
+            orc.step(3 * orc.dt)
+            blk.step(1)
+            assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
+            assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
