@@ -202,8 +202,9 @@ def main():
     words = [d * d + d, d + d * d, d * d + 3 * d, d + d * d, d * d + d, 3 * d * d + d]   # per node per launch
     mfma = P >= 3 and os.environ.get("SEIGEN_HIP_PATH", "") != "generic"
     if mfma:
-        names = (("sg::mfma_stage_F<%d, 0>" % P, (0, 4)), ("sg::mfma_stage_F<%d, 1>" % P, (2,)),
-                 ("sg::mfma_stage_G<%d, 0>" % P, (1, 3)), ("sg::mfma_stage_G<%d, 1>" % P, (5,)))
+        sym = 0 if os.environ.get("SEIGEN_HIP_SYM", "") == "0" else 1     # symmetric-stress mode (default)
+        names = (("sg::mfma_stage_F<%d, 0, %d>" % (P, sym), (0, 4)), ("sg::mfma_stage_F<%d, 1, %d>" % (P, sym), (2,)),
+                 ("sg::mfma_stage_G<%d, 0, %d>" % (P, sym), (1, 3)), ("sg::mfma_stage_G<%d, 1, %d>" % (P, sym), (5,)))
     else:
         names = (("sg::stage_kernel<3, %d, 0>" % P, (0, 2, 4)), ("sg::stage_kernel<3, %d, 1>" % P, (1, 3, 5)))
     kern = {}
