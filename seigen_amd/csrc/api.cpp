@@ -229,7 +229,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  if (h->use_mfma) {
+  if (h->use_mfma || h->use_lane) {
     // symmetric-stress mode: fields start at zero, g only produces symmetric tensors;
     // left for good as soon as the user uploads a non-symmetric stress or source (SEIGEN_HIP_SYM=0: never entered)
     const char* sym_env = std::getenv("SEIGEN_HIP_SYM");

@@ -92,7 +92,14 @@ __device__ __forceinline__ LaneNbr lane_nbr(const MeshDev* md, const StageArgs& 
   return R;
 }
 
-template <int DIM, int P, int KIND, int MODE>
+// SYM = 1: symmetric-stress mode (kernels_mfma.hip): only the i <= j lines of a stress field are
+// read or written; component (i, j) with i > j is taken from its mirror (j, i).
+template <int DIM, int SYM>
+__device__ __forceinline__ constexpr int cidx(int i, int j) {
+  return (SYM && i > j) ? j * DIM + i : i * DIM + j;
+}
+
+template <int DIM, int P, int KIND, int MODE, int SYM>
 __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
   using G = LG<DIM, P>;
   constexpr int ND = G::ND, NF = G::NF, NFACES = G::NFACES, NCLS = G::NCLS;
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
 #pragma unroll
         for (int b = 0; b < ND; ++b)
 #pragma unroll
-          for (int j = 0; j < DIM; ++j) q[b][j] = own[(b * NC + i * DIM + j) * 64];
+          for (int j = 0; j < DIM; ++j) q[b][j] = own[(b * NC + cidx<DIM, SYM>(i, j)) * 64];
         double fl[NFACES][NF];  // w_f (c n)_f,j T(nbr)_ij
 #pragma unroll
         for (int f = 0; f < NFACES; ++f)
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
           for (int bp = 0; bp < NF; ++bp) {
             double sacc = 0.0;
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) sacc += cnv[f][j] * np[f][nnode[f][bp] + (i * DIM + j) * nst[f]];
+            for (int j = 0; j < DIM; ++j) sacc += cnv[f][j] * np[f][nnode[f][bp] + cidx<DIM, SYM>(i, j) * nst[f]];
             fl[f][bp] = wf[f] * sacc;
           }
         // sponge operand and in-place combine operands, read before this cell's u_i is written
@@ -247,10 +254,11 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       double po[DIM * DIM], pa[DIM * DIM];   // in-place combine operands, one node ahead
       if (MODE == 1) {
 #pragma unroll
-        for (int c = 0; c < DIM * DIM; ++c) {
-          po[c] = out[sbase + c * 64];
-          pa[c] = aux[sbase + c * 64];
-        }
+        for (int c = 0; c < DIM * DIM; ++c)
+          if (!SYM || (c / DIM) <= (c % DIM)) {
+            po[c] = out[sbase + c * 64];
+            pa[c] = aux[sbase + c * 64];
+          }
       }
 #pragma unroll
       for (int a = 0; a < ND; ++a) {
@@ -302,18 +310,21 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
 #pragma unroll
           for (int j = 0; j < DIM; ++j) {
             v[i * DIM + j] = mu * (W[i][j] + W[j][i]) + ((i == j) ? lam * trc : 0.0);
-            if (MODE == 1) v[i * DIM + j] = A.c_self * po[i * DIM + j] + A.c_aux * pa[i * DIM + j] + A.c_new * v[i * DIM + j];
+            if (MODE == 1 && (!SYM || i <= j))
+              v[i * DIM + j] = A.c_self * po[i * DIM + j] + A.c_aux * pa[i * DIM + j] + A.c_new * v[i * DIM + j];
           }
         if (MODE == 1 && a + 1 < ND) {
 #pragma unroll
-          for (int c = 0; c < DIM * DIM; ++c) {
-            po[c] = out[sbase + ((a + 1) * DIM * DIM + c) * 64];
-            pa[c] = aux[sbase + ((a + 1) * DIM * DIM + c) * 64];
-          }
+          for (int c = 0; c < DIM * DIM; ++c)
+            if (!SYM || (c / DIM) <= (c % DIM)) {
+              po[c] = out[sbase + ((a + 1) * DIM * DIM + c) * 64];
+              pa[c] = aux[sbase + ((a + 1) * DIM * DIM + c) * 64];
+            }
         }
         if (L.active) {
 #pragma unroll
-          for (int c = 0; c < DIM * DIM; ++c) out[sbase + (a * DIM * DIM + c) * 64] = v[c];
+          for (int c = 0; c < DIM * DIM; ++c)
+            if (!SYM || (c / DIM) <= (c % DIM)) out[sbase + (a * DIM * DIM + c) * 64] = v[c];
         }
       }
     }
@@ -326,17 +337,25 @@ static int launch_lane_dp(int kind, const StageArgs& a, long nitems, hipStream_t
   if (blocks > 2048) blocks = 2048;
   blocks = (blocks + 7) / 8 * 8;  // every XCD label needs a block
   const dim3 grid((unsigned)blocks), block(256);
+#define SG_LANE_LAUNCH(K, M)                                                            \
+  do {                                                                                  \
+    if (a.sym)                                                                          \
+      hipLaunchKernelGGL((lane_stage<DIM, P, K, M, 1>), grid, block, 0, s, a);          \
+    else                                                                                \
+      hipLaunchKernelGGL((lane_stage<DIM, P, K, M, 0>), grid, block, 0, s, a);          \
+  } while (0)
   if (kind == 0) {
     if (a.mode == 0)
-      hipLaunchKernelGGL((lane_stage<DIM, P, 0, 0>), grid, block, 0, s, a);
+      SG_LANE_LAUNCH(0, 0);
     else
-      hipLaunchKernelGGL((lane_stage<DIM, P, 0, 1>), grid, block, 0, s, a);
+      SG_LANE_LAUNCH(0, 1);
   } else {
     if (a.mode == 0)
-      hipLaunchKernelGGL((lane_stage<DIM, P, 1, 0>), grid, block, 0, s, a);
+      SG_LANE_LAUNCH(1, 0);
     else
-      hipLaunchKernelGGL((lane_stage<DIM, P, 1, 1>), grid, block, 0, s, a);
+      SG_LANE_LAUNCH(1, 1);
   }
+#undef SG_LANE_LAUNCH
   return (int)hipGetLastError();
 }
 

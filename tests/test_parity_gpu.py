@@ -178,3 +178,30 @@ def test_symmetric_stress_mode_and_fallback(gpu):
             blk.step(1)
             assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
             assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+
+
+def test_symmetric_mode_lane_path_2d(gpu, monkeypatch):
+    """The lane-per-cell kernels (forced here on a small mesh) in symmetric-stress mode, and their
+    exact fallback for a non-symmetric stress."""
+    from seigen_amd import _lib
+    monkeypatch.setenv("SEIGEN_HIP_PATH", "lane")
+    dim, degree, n, L = 2, 3, (5, 4), (1.0, 1.25)
+    m = oracle_mesh(dim, n, L)
+    for symmetric in (True, False):
+        blk = make_block(dim, degree, n, L, "left")
+        orc = OracleLF4(m, degree)
+        orc.dt, orc.l, orc.mu, orc.density = 1e-3, 0.5, 0.25, 1.0
+        orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 31)
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 32)
+        if symmetric:
+            s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        orc.s0 = s0.copy()
+        blk.set_params(1.0, orc.dt, orc.l, orc.mu)
+        blk.set_field(_lib.FIELD_U, orc.u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        np.testing.assert_array_equal(blk.get_field(_lib.FIELD_S), s0)
+        blk.step(3)
+        for k in range(3):
+            orc.step((k + 1) * orc.dt)
+        assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
+        assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
