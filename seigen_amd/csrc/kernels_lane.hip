@@ -1,4 +1,4 @@
-// Lane-per-cell stage kernels for small elements (1-D and 2-D, P1..P4; gfx950, FP64).
+// Lane-per-cell stage kernels for small elements (1-D and 2-D P1..P4, 3-D P1/P2; gfx950, FP64).
 //
 // With at most 15 nodes per cell the whole cell fits in one lane's registers, so the wavefront
 // is used as 64 independent cells: lane l owns cell (cube 64g + l, class k) of a group of 64
@@ -23,10 +23,10 @@ namespace sg {
 
 template <int DIM, int P>
 struct LG {
-  static constexpr int ND = (DIM == 1) ? (P + 1) : (P + 1) * (P + 2) / 2;
-  static constexpr int NF = (DIM == 1) ? 1 : (P + 1);
+  static constexpr int ND = (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
+  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
   static constexpr int NFACES = DIM + 1;
-  static constexpr int NCLS = (DIM == 1) ? 1 : 2;
+  static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
 };
 
 struct LaneCell {
@@ -370,12 +370,15 @@ static int launch_lane_d(int kind, int P, const StageArgs& a, long nitems, hipSt
   return -1;
 }
 
-bool lane_supported(int dim, int P) { return (dim == 1 || dim == 2) && P >= 1 && P <= 4; }
+// 3-D: only P1/P2 fit a lane's registers (P3/P4 take the MFMA path)
+bool lane_supported(int dim, int P) { return ((dim == 1 || dim == 2) && P >= 1 && P <= 4) || (dim == 3 && (P == 1 || P == 2)); }
 
 int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (dim == 1) return launch_lane_d<1>(kind, P, a, nitems, s);
   if (dim == 2) return launch_lane_d<2>(kind, P, a, nitems, s);
+  if (dim == 3 && P == 1) return launch_lane_dp<3, 1>(kind, a, nitems, s);
+  if (dim == 3 && P == 2) return launch_lane_dp<3, 2>(kind, a, nitems, s);
   return -1;
 }
 
