@@ -205,3 +205,34 @@ def test_symmetric_mode_lane_path_2d(gpu, monkeypatch):
             orc.step((k + 1) * orc.dt)
         assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
         assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+
+
+@pytest.mark.parametrize("path", ["generic", "lane"])
+@pytest.mark.parametrize("dim,degree,n,L,diagonal", [
+    (1, 2, (9,), (1.0,), "left"),
+    (2, 1, (5, 3), (1.0, 1.0), "left"),
+    (2, 4, (3, 4), (1.5, 1.0), "right"),
+    (3, 1, (3, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 2, (2, 3, 2), (1.0, 1.5, 0.5), "left"),
+])
+def test_every_kernel_family(gpu, monkeypatch, path, dim, degree, n, L, diagonal):
+    """The size-based choice between the generic and the lane-per-cell kernels must not matter:
+    both families, forced through SEIGEN_HIP_PATH, against the oracle (3-D P3/P4 have the MFMA
+    kernels, covered by the default runs above)."""
+    from seigen_amd import _lib
+    monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+    blk = make_block(dim, degree, n, L, diagonal)
+    m = oracle_mesh(dim, n, L, diagonal)
+    orc = OracleLF4(m, degree)
+    orc.dt = 0.05 * min(L[a] / n[a] for a in range(dim)) / degree ** 2
+    orc.l, orc.mu, orc.density = 0.5, 0.25, 1.0
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 41)
+    orc.s0 = seeded(blk.field_shape(_lib.FIELD_S), 42)
+    blk.set_params(orc.density, orc.dt, orc.l, orc.mu)
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(2)
+    orc.step(orc.dt)
+    orc.step(2 * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
