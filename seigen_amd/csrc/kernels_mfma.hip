@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           for (int i = 0; i < 3; ++i) flf[ks][i] = 0.5 * nx[ks][i];
 #pragma unroll
         for (int t = 0; t < MTL; ++t) {
-          if (t == MTL - 1 && f + 1 < 4) request(f + 1, nx);
+          // next facet's traces: asked for a whole facet ahead (nx and flf are both live in the last
+          // tile pass anyway, so the longer live range does not raise the register peak)
+          if (t == 0 && f + 1 < 4) request(f + 1, nx);
           d4 tmp[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
@@ -538,7 +540,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     //      (elastic.py:206).  The own half of {T} is part of the volume tiles (E_r), so the lift
     //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
     //      cancels the folded half): wf * (c n).T of whatever np[f] points at.
-    constexpr int PFL = 2;  // facet k-steps of neighbour traces in flight
+#ifndef SG_PFLF
+#define SG_PFLF 2
+#endif
+    constexpr int PFL = SG_PFLF;  // facet k-steps of neighbour traces in flight
     const double* np[4];
     int nst[4];
     double wf[4];
