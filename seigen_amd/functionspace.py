@@ -170,10 +170,12 @@ class Function(object):
         if callable(expression) and not isinstance(expression, Expression):
             vals = np.asarray(expression(self._space.node_coords()), dtype=np.float64)
         else:
-            if expression.value_shape != self._space.value_shape:
+            scalar_ok = expression.value_shape == () and self._space.value_size == 1   # 1-D vector/tensor spaces
+            if expression.value_shape != self._space.value_shape and not scalar_ok:
                 raise ValueError("Expression shape %r does not match the function space %r"
                                  % (expression.value_shape, self._space.value_shape))
             vals = expression.evaluate(self._space.node_coords())
+            vals = vals.reshape(vals.shape[:2] + self._space.value_shape)
         self._set(vals)
         return self
 

@@ -238,3 +238,24 @@ def test_receiver_traces_full_run_vs_oracle_and_ref_c(gpu):
     uy = -tr[:, 0, 1]
     k, kr = uy.argmin(), ref[:, 2].argmin()
     assert abs(t[k] - ref[kr, 0]) <= 0.0051 and abs(uy[k] / ref[kr, 2] - 1.0) < 0.08
+
+
+def test_pulse_1d(gpu):
+    """tests/pulse/pulse_1d_lf4.py (1-D DG1, Gaussian pulse, DG1 sponge at both ends, T = 2: 800 steps)."""
+    from seigen_amd.harness.pulse import pulse_1d_lf4
+    el, u1, s1 = pulse_1d_lf4(T=2.0)
+    m = omesh.IntervalMesh(400, 4.0)
+    orc = OracleLF4(m, 1)
+    orc.density, orc.dt, orc.mu, orc.l = 1.0, 0.0025, 0.25, 0.5
+    X = m.node_coords(1)
+    orc.E.set_absorption(np.where((X[..., 0] >= 3.5) | (X[..., 0] <= 0.5), 100.0, 0.0), 1)
+    g = np.exp(-50 * (X[..., 0] - 1) ** 2)
+    orc.u0 = g[..., None].copy()
+    orc.s0 = -g[..., None, None].copy()
+    ou, os_ = orc.run(2.0)
+    assert orc.nsteps == 800
+    assert rel_err(u1.dat.data_cells, ou) < 1e-9
+    assert rel_err(s1.dat.data_cells, os_) < 1e-9
+    # a right-going pulse (u = -s) travels at Vp = 1: from x = 1 to x = 3 in T = 2
+    k = np.unravel_index(np.abs(ou).argmax(), ou.shape)
+    assert abs(X[k[0], k[1], 0] - 3.0) < 0.05 and abs(np.abs(ou).max() - 1.0) < 0.02

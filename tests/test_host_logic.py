@@ -267,3 +267,21 @@ def test_helpers():
     from seigen_amd import Vp, Vs, cfl_dt
     assert Vp(0.25, 0.5, 1.0) == 1.0 and Vs(0.25, 1.0) == 0.5
     assert abs(cfl_dt(2.5, Vp(3600.0, 3599.3664, 1.0), 0.5) - 0.012028483448806774) < 1e-15
+
+
+def test_marmousi_lookup():
+    """seigen/marmousi.py:4-14: 384 x 122 nearest-cell lookup in marmhard.dat (depth counted from the
+    surface, with the reference's j = 0 slip fixed), and the derived per-cell Lame parameters."""
+    from seigen_amd import marmousi
+    data = marmousi.load_model()
+    assert data.shape == (384, 122) and data.min() == 1500.0 and data.max() == 5500.0
+    H = marmousi.H
+    # a point in cell (i, j) from the bottom maps to data[i][121 - j]
+    assert marmousi.vp_at(data, 3.5 * H, 0.5 * H) == data[3, 121]
+    assert marmousi.vp_at(data, 100.2 * H, 121.9 * H) == data[100, 0]
+    mesh = RectangleMesh(383, 121, 383 * H, 121 * H)
+    V = VectorFunctionSpace(mesh, "DG", 1)
+    lam, mu, vp = marmousi.cell_material(V, data)
+    assert lam.shape == (383 * 121 * 2,)
+    np.testing.assert_allclose(lam + 2 * mu, vp ** 2, rtol=1e-14)
+    np.testing.assert_allclose(mu, vp ** 2 / 3.0, rtol=1e-14)
