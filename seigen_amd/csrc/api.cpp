@@ -33,6 +33,8 @@ struct sg_handle {
   bool use_lane = false;
   bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
   int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
+  int32_t* shell_items = nullptr;  // active (cell group, class) items of the boundary shell (MFMA / lane paths)
+  int32_t shell_nitems = -1;       // -1: not built yet
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
@@ -106,6 +108,7 @@ void sg_destroy(sg_handle* h) {
   if (h->fragL) (void)hipFree(h->fragL);
   if (h->staging) (void)hipFree(h->staging);
   if (h->sym_flag) (void)hipFree(h->sym_flag);
+  if (h->shell_items) (void)hipFree(h->shell_items);
   if (h->dbg) {
     unsigned long long v[32];
     if (hipMemcpy(v, h->dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
@@ -644,6 +647,50 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.c_new = c_new;
   std::vector<Box> boxes;
   region_boxes(h, region, boxes);
+  if (h->use_mfma || h->use_lane) {
+    // one launch for the whole region: the kernels scan all cell groups and mask lanes by box
+    a.nbox = 0;
+    for (const Box& b : boxes) {
+      if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;
+      for (int k = 0; k < 3; ++k) {
+        a.boxes_o[a.nbox][k] = b.o[k];
+        a.boxes_n[a.nbox][k] = b.n[k];
+      }
+      a.nbox += 1;
+    }
+    if (a.nbox == 0) return SG_OK;
+    a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
+    a.item_list = nullptr;
+    a.nlist = 0;
+    if (a.spread) {
+      if (h->shell_nitems < 0) {  // the shell is static: list its cell groups once
+        const int64_t gw = h->md.gw, ngroups = h->md.ncube_pad / gw;
+        std::vector<char> hit((size_t)ngroups, 0);
+        for (int bx = 0; bx < a.nbox; ++bx)
+          for (int ck = a.boxes_o[bx][2]; ck < a.boxes_o[bx][2] + a.boxes_n[bx][2]; ++ck)
+            for (int cj = a.boxes_o[bx][1]; cj < a.boxes_o[bx][1] + a.boxes_n[bx][1]; ++cj)
+              for (int ci = a.boxes_o[bx][0]; ci < a.boxes_o[bx][0] + a.boxes_n[bx][0]; ++ci) {
+                int64_t cube = ci + (int64_t)h->cfg.n[0] * (cj + (int64_t)h->cfg.n[1] * ck);
+                hit[(size_t)(cube / gw)] = 1;
+              }
+        std::vector<int32_t> items;
+        for (int64_t g = 0; g < ngroups; ++g)
+          if (hit[(size_t)g])
+            for (int k = 0; k < h->ncls; ++k) items.push_back((int32_t)(g * h->ncls + k));
+        h->shell_nitems = (int32_t)items.size();
+        if (!items.empty()) {
+          HIPCHECK(h, hipMalloc((void**)&h->shell_items, items.size() * sizeof(int32_t)));
+          HIPCHECK(h, hipMemcpy(h->shell_items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+      }
+      a.item_list = h->shell_items;
+      a.nlist = h->shell_nitems;
+    }
+    int rc = h->use_mfma ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
+                         : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
+    if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return SG_OK;
+  }
   for (const Box& b : boxes) {
     bool empty = false;
     for (int k = 0; k < 3; ++k) {
@@ -652,13 +699,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       empty = empty || (b.n[k] <= 0);
     }
     if (empty) continue;
-    int rc;
-    if (h->use_mfma)
-      rc = launch_stage_mfma(kind, h->cfg.degree, a, h->stream);
-    else if (h->use_lane)
-      rc = launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
-    else
-      rc = launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
+    int rc = launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
     if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
   }
   return SG_OK;

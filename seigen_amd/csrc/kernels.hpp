@@ -26,7 +26,15 @@ struct StageArgs {
   double c_self, c_aux, c_new;  // mode 1: out = c_self*out + c_aux*aux + c_new*rhs
   int32_t mode;                 // 0: out = rhs
   int32_t per_cell;
-  int32_t box_o[3], box_n[3];   // region of cubes covered by this launch
+  int32_t box_o[3], box_n[3];   // region of cubes covered by this launch (generic kernel: one box per launch)
+  // MFMA / lane kernels: one launch covers up to 6 disjoint boxes (a boundary shell); `spread` deals
+  // the items round-robin over all waves instead of one contiguous range per XCD, because a shell's
+  // active items are a few contiguous runs that would otherwise land on one XCD
+  int32_t nbox;
+  int32_t boxes_o[6][3], boxes_n[6][3];
+  int32_t spread;
+  const int32_t* item_list;  // spread = 1: the active items (cell group * ncls + class) of the shell, or null
+  int32_t nlist;
   int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
 };
 

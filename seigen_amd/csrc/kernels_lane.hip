@@ -44,9 +44,13 @@ __device__ __forceinline__ LaneCell lane_cell(const MeshDev* md, const StageArgs
   long t = cl / md->n[0];
   L.cc[1] = (int)(t % md->n[1]);
   L.cc[2] = (int)(t / md->n[1]);
-  bool in = true;
+  bool in = false;
+  for (int bx = 0; bx < A.nbox; ++bx) {
+    bool ib = true;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) in = in && (L.cc[a] >= A.box_o[a]) && (L.cc[a] < A.box_o[a] + A.box_n[a]);
+    for (int a = 0; a < 3; ++a) ib = ib && (L.cc[a] >= A.boxes_o[bx][a]) && (L.cc[a] < A.boxes_o[bx][a] + A.boxes_n[bx][a]);
+    in = in || ib;
+  }
   L.active = L.valid && in;
   return L;
 }
@@ -124,7 +128,12 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
   const long blocks_here = (nblk - xcd + 7) / 8, ipx = (nitems + 7) / 8;
   const long lo = xcd * ipx, hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
 
-  for (long item = lo + slot * 4 + wave; item < hi; item += blocks_here * 4) {
+  const long i0 = A.spread ? (long)blockIdx.x * 4 + wave : lo + slot * 4 + wave;
+  const bool listed = A.spread && A.item_list != nullptr;
+  const long i1 = listed ? (long)A.nlist : (A.spread ? nitems : hi);
+  const long istep = A.spread ? (long)gridDim.x * 4 : blocks_here * 4;
+  for (long it = i0; it < i1; it += istep) {
+    const long item = listed ? (long)A.item_list[it] : it;
     const long g = item / NCLS;
     const int k = (int)(item - g * NCLS);
     const LaneCell L = lane_cell(md, A, g, lane);

@@ -111,9 +111,13 @@ __device__ __forceinline__ LaneGeo lane_geo(const MeshDev& md, const StageArgs& 
   long t = cl / md.n[0];
   L.cc[1] = (int)(t % md.n[1]);
   L.cc[2] = (int)(t / md.n[1]);
-  bool in = true;
+  bool in = false;
+  for (int bx = 0; bx < A.nbox; ++bx) {
+    bool ib = true;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) in = in && (L.cc[a] >= A.box_o[a]) && (L.cc[a] < A.box_o[a] + A.box_n[a]);
+    for (int a = 0; a < 3; ++a) ib = ib && (L.cc[a] >= A.boxes_o[bx][a]) && (L.cc[a] < A.boxes_o[bx][a] + A.boxes_n[bx][a]);
+    in = in || ib;
+  }
   L.active = L.valid && in;
   return L;
 }
@@ -166,7 +170,14 @@ __device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A,
 struct ItemRange {
   long lo, hi, step;
 };
-__device__ __forceinline__ ItemRange item_range(long nitems, int wave) {
+__device__ __forceinline__ ItemRange item_range(long nitems, int wave, int spread) {
+  if (spread) {  // boundary shells: round-robin over every wave of the grid (over the item list if given)
+    ItemRange r;
+    r.lo = (long)blockIdx.x * 4 + wave;
+    r.hi = nitems;
+    r.step = (long)gridDim.x * 4;
+    return r;
+  }
   const long nblk = gridDim.x;
   const long xcd = blockIdx.x % 8;
   const long slot = blockIdx.x / 8;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   const double* __restrict__ aux = A.aux;
   double* __restrict__ out = A.out;
   const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range(ngroups * 6, wave);
+  const ItemRange ir = item_range((A.spread && A.item_list) ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
   // node index of this lane's B row per k-step; rows past ND meet all-zero operator columns,
   // so any finite value will do there: clamp instead of branching
@@ -226,8 +237,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 3 * 16;
 
   STAMP_DECL;
-  for (long item = ir.lo; item < ir.hi; item += ir.step) {
+  for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
+    const long item = (A.spread && A.item_list) ? (long)A.item_list[it] : it;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
@@ -474,15 +486,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   const double* __restrict__ aux = A.aux;
   double* __restrict__ out = A.out;
   const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range(ngroups * 6, wave);
+  const ItemRange ir = item_range((A.spread && A.item_list) ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
   int bnode[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 9 * 16;
 
   STAMP_DECL;
-  for (long item = ir.lo; item < ir.hi; item += ir.step) {
+  for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
+    const long item = (A.spread && A.item_list) ? (long)A.item_list[it] : it;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);

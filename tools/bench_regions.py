@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Cost of the multi-GPU launch structure on ONE device (no transport): a 64^3 P4 block that
+pretends to have neighbours on some sides runs every stage as pack + INTERIOR + BOUNDARY launches,
+compared with the single REGION_ALL launch.  Tells how much of the scaling loss is launch
+structure rather than RCCL."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from seigen_amd import _lib  # noqa: E402
+from seigen_amd.backend import HipBlock  # noqa: E402
+from seigen_amd.parallel import STAGE_INPUT  # noqa: E402
+
+
+def run(mask, n=(64, 64, 64), degree=4, steps=10):
+    h = [1.0 / 64] * 3
+    blk = HipBlock(3, degree, n, h, [0.0] * 3, "left", mask)
+    blk.set_params(1.0, 0.5 / 64 / 8, 0.5, 0.25)
+    rng = np.random.default_rng(0)
+    sides = [s for s in range(6) if mask >> s & 1]
+    bufs = {}
+    for kind, field in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S)):
+        for s in sides:
+            nb = blk.halo_bytes(field, s) // 8
+            bufs[(kind, s)] = (torch.zeros(nb, dtype=torch.float64, device="cuda"),
+                               torch.zeros(nb, dtype=torch.float64, device="cuda"))
+    for field in range(4):
+        kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+        for s in sides:
+            blk.halo_attach(field, s, bufs[(kind, s)][1].data_ptr())
+
+    def step():
+        for stage in range(6):
+            if not sides:
+                blk.run_stage(stage, _lib.REGION_ALL)
+                continue
+            field = STAGE_INPUT[stage]
+            kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+            for s in sides:
+                blk.halo_pack(field, s, bufs[(kind, s)][0].data_ptr())
+            blk.run_stage(stage, _lib.REGION_INTERIOR)
+            blk.run_stage(stage, _lib.REGION_BOUNDARY)
+        blk.end_step()
+
+    for _ in range(2):
+        step()
+    blk.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    blk.sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+if __name__ == "__main__":
+    for name, mask in (("no neighbours (REGION_ALL)", 0), ("z- and z+", 0b110000), ("y+, z-, z+", 0b111000),
+                       ("x+, y+, z+", 0b101010)):
+        print("%-28s %.3f ms/step" % (name, run(mask)))
