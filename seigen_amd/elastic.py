@@ -123,11 +123,17 @@ class ElasticLF4(object):
     def _create_block(self):
         part = self.mesh.partition
         stream = None
+        self._torch_stream = None
         if part.world > 1:
+            # one process per GPU: kernels and the RCCL point-to-point traffic must be ordered on ONE
+            # stream.  A dedicated torch stream (never the null stream, whose handle is 0 and would
+            # make the library create a stream of its own) is handed to the library and made current
+            # around every torch.distributed call (seigen_amd/parallel.py).
             import torch
             if torch.cuda.is_available():
                 torch.cuda.set_device(_device_for_rank())
-                stream = torch.cuda.current_stream().cuda_stream
+                self._torch_stream = torch.cuda.Stream(device=_device_for_rank())
+                stream = self._torch_stream.cuda_stream
         origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
         return HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin, self.mesh.diagonal,
                         part.nbr_mask, device=_device_for_rank(), stream=stream)
@@ -210,7 +216,7 @@ class ElasticLF4(object):
             if self.mesh.partition.world > 1 and self._exchanger is None:
                 import torch
                 dev = torch.device("cuda", _device_for_rank())
-                self._exchanger = HaloExchanger(self._block, self.mesh.partition, dev)
+                self._exchanger = HaloExchanger(self._block, self.mesh.partition, dev, stream=self._torch_stream)
 
     @property
     def loop_context(self):

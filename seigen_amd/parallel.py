@@ -50,13 +50,14 @@ class HaloExchanger(object):
     Buffers are torch tensors on `device` so the same object serves RCCL
     (device tensors) and gloo (CPU tensors)."""
 
-    def __init__(self, block, partition, device, group=None):
+    def __init__(self, block, partition, device, group=None, stream=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.block = block
         self.part = partition
         self.group = group
+        self.stream = stream      # torch.cuda.Stream the block launches on (None: CPU tensors / gloo)
         self.sides = [s for s in range(2 * partition.dim) if partition.neighbour(s) is not None]
         self.send, self.recv = {}, {}
         for kind, field in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S)):
@@ -84,10 +85,17 @@ class HaloExchanger(object):
             self.bytes_sent += self.send[(kind, s)].numel() * 8
         if not ops:
             return []
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):   # RCCL orders itself against the CURRENT stream
+                return self.dist.batch_isend_irecv(ops)
         return self.dist.batch_isend_irecv(ops)
 
-    @staticmethod
-    def finish(reqs):
+    def finish(self, reqs):
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                for r in reqs:
+                    r.wait()
+            return
         for r in reqs:
             r.wait()
 
