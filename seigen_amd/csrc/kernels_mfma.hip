@@ -13,6 +13,7 @@
 // rows are exactly the 128-byte lines of the layout, so operands are loaded
 // from and results stored to HBM/L2 directly in fragment form - no LDS staging
 // of cell data.  The operator tiles live in LDS in lane order (mfma_tables.cpp).
+// The nd % 16 rows left over by the 16-row tiles use v_mfma_f64_4x4x4_4b_f64 (MFMA4 below).
 //
 // Loads are software-pipelined by hand (PF k-steps ahead): hipcc otherwise issues
 // each B operand right before the MFMA that consumes it and waits for it.
@@ -30,15 +31,20 @@ struct MG {
   static constexpr int NF = (P + 1) * (P + 2) / 2;
   static constexpr int KS = (ND + 3) / 4;
   static constexpr int KSF = (NF + 3) / 4;
-  static constexpr int MTL = (ND + 15) / 16;
+  static constexpr int MTF = ND / 16;                // full 16-row tiles over the nodes
+  static constexpr int NSM = (ND % 16 + 3) / 4;      // 4-row tiles (4x4x4 MFMA) over the remaining rows
+  static constexpr int MTT = MTF + NSM;
   static constexpr int S4 = (ND + 3) / 4;
   static constexpr int MTG = (12 * S4 + 15) / 16;
-  static constexpr int NFRAG_F = MTL * 3 * KS;
+  static constexpr int NFRAG_F = MTT * 3 * KS;
   static constexpr int NFRAG_G = MTG * KS;
-  static constexpr int NFRAG_L = 4 * MTL * KSF;
+  static constexpr int NFRAG_L = 4 * MTT * KSF;
 };
 
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// 4 rows x 16 cells (four 4x4 blocks), same B register as MFMA64; lane l of the result holds
+// row (l >> 4) of cell (l & 15).  About 1/6 of the issue time of MFMA64 (mfma_tables.hpp).
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 // Diagnostic build only (-DSG_STAMPS, SEIGEN_HIP_STAMPS=1): cycle stamps at the phase boundaries
 // of an item, summed per wave in scalars and added to A.dbg at the end.  Never in the shipped build.
@@ -208,7 +214,7 @@ __device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* s
 template <int P, int MODE, int SYM>
 __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   using M = MG<P>;
-  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL, S4 = M::S4, MTG = M::MTG;
+  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, MTT = M::MTT, S4 = M::S4, MTG = M::MTG;
 #ifndef SG_PF
 #define SG_PF 3
 #endif
@@ -358,8 +364,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
     //      (a boundary lane's neighbour pointer is its own cell).
     //      Register budget: the facet's KSF*3 B values stay resident while the row tiles are
-    //      accumulated one at a time (3 accumulators instead of 3*MTL); the next facet's values are
-    //      requested before the last tile pass.
+    //      accumulated one at a time (3 accumulators instead of 3*MTT); the next facet's values are
+    //      requested before the last tile pass.  Row tile t covers the row-quads m = 4t .. 4t+3
+    //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
     {
       double flf[KSF][3];
       request(0, nx);
@@ -370,38 +377,47 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) flf[ks][i] = 0.5 * nx[ks][i];
 #pragma unroll
-        for (int t = 0; t < MTL; ++t) {
+        for (int t = 0; t < MTT; ++t) {
           // next facet's traces: asked for a whole facet ahead (nx and flf are both live in the last
           // tile pass anyway, so the longer live range does not raise the register peak)
           if (t == 0 && f + 1 < 4) request(f + 1, nx);
-          d4 tmp[3];
+          auto fold = [&](int m, double v0, double v1, double v2) {
+            const double v[3] = {v0, v1, v2};
 #pragma unroll
-          for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
+            for (int i = 0; i < 3; ++i) {
 #pragma unroll
-          for (int ks = 0; ks < KSF; ++ks) {
-            const double a = sAL[((f * MTL + t) * KSF + ks) * 64 + lo];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
-          }
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int m = 4 * t + reg;
-            if (m < S4) {
-#pragma unroll
-              for (int i = 0; i < 3; ++i) {
-                const double v = tmp[i][reg];
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                  const double wv = cnf[f][kk] * v;
-                  if (i == kk)
-                    Sd[i][m] += wv;
-                  else
-                    So[i + kk - 1][m] += wv;
-                }
+              for (int kk = 0; kk < 3; ++kk) {
+                const double wv = cnf[f][kk] * v[i];
+                if (i == kk)
+                  Sd[i][m] += wv;
+                else
+                  So[i + kk - 1][m] += wv;
               }
-#pragma unroll
-              for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
             }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+          };
+          if (t < MTF) {
+            d4 tmp[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSF; ++ks) {
+              const double a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) fold(4 * t + reg, tmp[0][reg], tmp[1][reg], tmp[2][reg]);
+          } else {
+            double tmp[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KSF; ++ks) {
+              const double a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) tmp[i] = MFMA4(a, flf[ks][i], tmp[i]);
+            }
+            fold(4 * MTF + (t - MTF), tmp[0], tmp[1], tmp[2]);
           }
         }
       }
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 template <int P, int MODE, int SYM>
 __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   using M = MG<P>;
-  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTL = M::MTL;
+  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
   __shared__ double sAV[M::NFRAG_F * 64];
   __shared__ double sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
@@ -514,11 +530,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) cnf[f][j] = md->cn[k][f][j];
 
-    d4 acc[3][MTL];
+    // rows 16t + 4reg + q in acc[i][t][reg] (large tiles), row 16*MTF + 4s + q in accs[i][s] (small)
+    d4 acc[3][MTF];
+    double accs[3][NSM];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int t = 0; t < MTL; ++t) acc[i][t] = d4{0, 0, 0, 0};
+      for (int t = 0; t < MTF; ++t) acc[i][t] = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) accs[i][t] = 0.0;
+    }
 
     STAMP(st1);
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
@@ -539,10 +560,15 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
 #pragma unroll
-          for (int t = 0; t < MTL; ++t) {
+          for (int t = 0; t < MTT; ++t) {
             const double a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i][t] = MFMA64(a, Tt[i], acc[i][t]);
+            for (int i = 0; i < 3; ++i) {
+              if (t < MTF)
+                acc[i][t < MTF ? t : 0] = MFMA64(a, Tt[i], acc[i][t < MTF ? t : 0]);
+              else
+                accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, Tt[i], accs[i][t < MTF ? 0 : t - MTF]);
+            }
           }
         }
       }
@@ -596,10 +622,15 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
             load_tensor<SYM>(np[f1] + noff[f1][k1], nst[f1], nq[s % PFL]);
           }
 #pragma unroll
-          for (int t = 0; t < MTL; ++t) {
-            const double a = sAL[((f * MTL + t) * KSF + ks) * 64 + lo];
+          for (int t = 0; t < MTT; ++t) {
+            const double a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i][t] = MFMA64(a, fl[i], acc[i][t]);
+            for (int i = 0; i < 3; ++i) {
+              if (t < MTF)
+                acc[i][t < MTF ? t : 0] = MFMA64(a, fl[i], acc[i][t < MTF ? t : 0]);
+              else
+                accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, fl[i], accs[i][t < MTF ? 0 : t - MTF]);
+            }
           }
         }
       }
@@ -615,38 +646,45 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       const int slot = L.active ? A.sponge_slot[e] : -1;
       if (__any(slot >= 0)) {
         if (slot >= 0) {
+          auto damp = [&](int a, double& r0, double& r1, double& r2) {
+            if (a < ND) {
+              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
+              double s0 = 0, s1 = 0, s2 = 0;
+              for (int b = 0; b < ND; ++b) {
+                const double bb = B[b];
+                s0 += bb * A.uabs[ubase + (b * 3 + 0) * 16];
+                s1 += bb * A.uabs[ubase + (b * 3 + 1) * 16];
+                s2 += bb * A.uabs[ubase + (b * 3 + 2) * 16];
+              }
+              r0 -= s0;
+              r1 -= s1;
+              r2 -= s2;
+            }
+          };
 #pragma unroll
-          for (int t = 0; t < MTL; ++t)
+          for (int t = 0; t < MTF; ++t)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-              const int a = 16 * t + 4 * reg + q;
-              if (a < ND) {
-                const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
-                double s0 = 0, s1 = 0, s2 = 0;
-                for (int b = 0; b < ND; ++b) {
-                  const double bb = B[b];
-                  s0 += bb * A.uabs[ubase + (b * 3 + 0) * 16];
-                  s1 += bb * A.uabs[ubase + (b * 3 + 1) * 16];
-                  s2 += bb * A.uabs[ubase + (b * 3 + 2) * 16];
-                }
-                acc[0][t][reg] -= s0;
-                acc[1][t][reg] -= s1;
-                acc[2][t][reg] -= s2;
-              }
+              double r0 = acc[0][t][reg], r1 = acc[1][t][reg], r2 = acc[2][t][reg];
+              damp(16 * t + 4 * reg + q, r0, r1, r2);
+              acc[0][t][reg] = r0;
+              acc[1][t][reg] = r1;
+              acc[2][t][reg] = r2;
             }
+#pragma unroll
+          for (int t = 0; t < NSM; ++t) damp(16 * MTF + 4 * t + q, accs[0][t], accs[1][t], accs[2][t]);
         }
       }
     }
 
     // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345)
 #pragma unroll
-    for (int t = 0; t < MTL; ++t) {
+    for (int t = 0; t < MTF; ++t) {
       double po[4][3], pa[4][3];
       if (MODE == 1) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int a = 16 * t + 4 * reg + q;
-          const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
+          const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             po[reg][i] = out[o + i * 16];
@@ -656,15 +694,35 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int a = 16 * t + 4 * reg + q;
-        const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
-        if (L.active && a < ND) {
+        const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
+        if (L.active) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             double v = acc[i][t][reg];
             if (MODE == 1) v = A.c_self * po[reg][i] + A.c_aux * pa[reg][i] + A.c_new * v;
             out[o + i * 16] = v;
           }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NSM; ++t) {
+      const int a = 16 * MTF + 4 * t + q;
+      const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
+      double po[3], pa[3];
+      if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          po[i] = out[o + i * 16];
+          pa[i] = aux[o + i * 16];
+        }
+      }
+      if (L.active && a < ND) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          double v = accs[i][t];
+          if (MODE == 1) v = A.c_self * po[i] + A.c_aux * pa[i] + A.c_new * v;
+          out[o + i * 16] = v;
         }
       }
     }

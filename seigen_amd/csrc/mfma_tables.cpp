@@ -11,7 +11,9 @@ MfmaGeom mfma_geom(const RefElem& re) {
   g.nf = re.nf;
   g.ks = (re.nd + 3) / 4;
   g.ksf = (re.nf + 3) / 4;
-  g.mtl = (re.nd + 15) / 16;
+  g.mtf = re.nd / 16;
+  g.nsm = (re.nd % 16 + 3) / 4;
+  g.mtt = g.mtf + g.nsm;
   g.s4 = (re.nd + 3) / 4;
   g.mtg = (3 * 4 * g.s4 + 15) / 16;
   return g;
@@ -34,14 +36,19 @@ static inline double Eval(const RefElem& re, int r, int a, int b) {
   return v;
 }
 
+// node row that lane l of row tile t holds in the A operand
+static inline int tile_row(const MfmaGeom& g, int t, int l) {
+  return (t < g.mtf) ? 16 * t + (l & 15) : 16 * g.mtf + 4 * (t - g.mtf) + (l & 3);
+}
+
 std::vector<double> mfma_frags_F(const RefElem& re) {
   MfmaGeom g = mfma_geom(re);
-  std::vector<double> out((size_t)g.mtl * 3 * g.ks * 64, 0.0);
-  for (int t = 0; t < g.mtl; ++t)
+  std::vector<double> out((size_t)g.mtt * 3 * g.ks * 64, 0.0);
+  for (int t = 0; t < g.mtt; ++t)
     for (int r = 0; r < 3; ++r)
       for (int k0 = 0; k0 < g.ks; ++k0) {
         size_t frag = (size_t)t * 3 * g.ks + (size_t)g.ks * r + k0;
-        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = -Eval(re, r, 16 * t + (l & 15), 4 * k0 + (l >> 4));
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = -Eval(re, r, tile_row(g, t, l), 4 * k0 + (l >> 4));
       }
   return out;
 }
@@ -64,13 +71,13 @@ std::vector<double> mfma_frags_G(const RefElem& re) {
 
 std::vector<double> mfma_frags_L(const RefElem& re) {
   MfmaGeom g = mfma_geom(re);
-  std::vector<double> out((size_t)re.nfaces * g.mtl * g.ksf * 64, 0.0);
+  std::vector<double> out((size_t)re.nfaces * g.mtt * g.ksf * 64, 0.0);
   for (int f = 0; f < re.nfaces; ++f)
-    for (int t = 0; t < g.mtl; ++t)
+    for (int t = 0; t < g.mtt; ++t)
       for (int k0 = 0; k0 < g.ksf; ++k0) {
-        size_t frag = ((size_t)f * g.mtl + t) * g.ksf + k0;
+        size_t frag = ((size_t)f * g.mtt + t) * g.ksf + k0;
         for (int l = 0; l < 64; ++l) {
-          int a = 16 * t + (l & 15), b = 4 * k0 + (l >> 4);
+          int a = tile_row(g, t, l), b = 4 * k0 + (l >> 4);
           out[frag * 64 + l] = (a < re.nd && b < re.nf) ? re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
         }
       }

@@ -5,6 +5,15 @@
 // A[row = l & 15][k = l >> 4].  A table is a list of 16x4 tiles ("fragments"),
 // each stored as 64 consecutive doubles in lane order, so a wave fetches a
 // fragment with one conflict-free ds_read_b64.
+//
+// The node rows are covered by floor(nd / 16) such tiles; the remaining nd % 16 rows
+// (3 of 35 at degree 4, 4 of 20 at degree 3) go through v_mfma_f64_4x4x4_4b_f64, which
+// costs about 1/6 of a 16x16x4 issue slot (tools/ubench_mfma4.hip) instead of a full,
+// mostly padded, 16-row tile.  Its four 4x4 blocks are the four 4-cell groups of the 16
+// cells, so B is the same register as for the large shape (k = l >> 4, cell = l & 15), A is
+// the 4x4 tile replicated per block: lane l holds A[row = l & 3][k = l >> 4], and lane l
+// of the result holds row (l >> 4) of cell (l & 15).  "Small" fragments are stored in
+// that lane order.
 #pragma once
 #include <vector>
 
@@ -16,7 +25,9 @@ struct MfmaGeom {
   int nd, nf;
   int ks;    // k-steps over the element nodes  = ceil(nd / 4)
   int ksf;   // k-steps over the facet nodes    = ceil(nf / 4)
-  int mtl;   // 16-row tiles over the nodes     = ceil(nd / 16)
+  int mtf;   // full 16-row tiles over the nodes = floor(nd / 16)
+  int nsm;   // 4-row tiles over the remaining rows = ceil((nd % 16) / 4)
+  int mtt;   // row tiles of either kind = mtf + nsm (large ones first)
   int s4;    // row-quads per stacked D_r block = ceil(nd / 4)
   int mtg;   // 16-row tiles of the stacked [D_0; D_1; D_2] (stride 4*s4 rows per block)
 };
@@ -24,13 +35,14 @@ struct MfmaGeom {
 MfmaGeom mfma_geom(const RefElem& re);
 
 // F volume: out = sum_r (-D_r) T~_r  as one product with K = 3 * (4*ks):
-//   frag (t, kk), kk = ks*r + k0:  A[row][col] = -E_r[16 t + row][4 k0 + col]
+//   frag (t, kk), kk = ks*r + k0:  A[row][col] = -E_r[row0(t) + row][4 k0 + col]
+// where row tile t < mtf is large (row0 = 16 t) and t >= mtf small (row0 = 16 mtf + 4 (t - mtf))
 // (E_r = D_r minus the own-trace half of the central flux, see mfma_tables.cpp)
 std::vector<double> mfma_frags_F(const RefElem& re);
 // G volume: rows stacked rho = 4*s4*r + a:
 //   frag (t, k0): A[row][col] = E_r[a][4 k0 + col],  rho = 16 t + row
 std::vector<double> mfma_frags_G(const RefElem& re);
-// facet lifts (shared by F and G): frag ((f*mtl + t)*ksf + k0): A[row][col] = L_f[16 t + row][4 k0 + col]
+// facet lifts (shared by F and G): frag ((f*mtt + t)*ksf + k0): A[row][col] = L_f[row0(t) + row][4 k0 + col]
 std::vector<double> mfma_frags_L(const RefElem& re);
 
 }  // namespace sg
