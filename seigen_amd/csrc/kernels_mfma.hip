@@ -236,12 +236,6 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range((A.spread && A.item_list) ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
-  // node index of this lane's B row per k-step; rows past ND meet all-zero operator columns,
-  // so any finite value will do there: clamp instead of branching
-  int bnode[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 3 * 16;
-
   STAMP_DECL;
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
@@ -251,6 +245,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
     const double* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    // B row of this lane at k-step ks = node 4 ks + q: one pointer per item plus compile-time
+    // offsets (a table of per-k-step offsets is item-invariant, gets hoisted out of the item loop
+    // as 64-bit values and spilled; every reload then waits for ALL loads in flight).  Only the last
+    // k-step can run past ND; those rows meet all-zero operator columns, so any finite value will
+    // do there: clamp instead of branching.
+    int qo = q * 3 * 16;
+    asm volatile("" : "+v"(qo));
+    const double* ownq = own + qo;
+    const double* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 3 * 16 : own;
+    auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 3 * 16; };
     // operator tiles are item-invariant: an opaque lane offset keeps the compiler from hoisting
     // all of them into registers (and, unlike a laundered pointer, keeps the reads ds_read_b64)
     int lo = lane;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
       for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = 0.0;
 
-    double nx[KSF][3];  // neighbour traces of the facet being requested
+    double nx[2][KSF][3];  // neighbour traces: facet f in nx[f & 1], facet f + 1 on its way into the other
     auto request = [&](int f, double (&dst)[KSF][3]) {
       const NbrRef R = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
 #pragma unroll
@@ -290,14 +294,17 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     //      one load of a B row feeds 3*TG MFMAs, and the cell data are re-read MTG/TG times
     //      (through L2) instead of MTG times; 3*TG accumulator tiles are live next to Sd/So.
     {
-      constexpr int TG = 2;
+#ifndef SG_TG
+#define SG_TG 2
+#endif
+      constexpr int TG = SG_TG;
       constexpr int NGRP = (MTG + TG - 1) / TG;
       constexpr int NS = NGRP * KS;
       double bq[PF][3];
 #pragma unroll
       for (int s = 0; s < PF; ++s)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) bq[s][i] = own[bnode[s % KS] + i * 16];
+        for (int i = 0; i < 3; ++i) bq[s][i] = brow(s % KS)[i * 16];
 #pragma unroll
       for (int grp = 0; grp < NGRP; ++grp) {
         d4 acc[TG][3];
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           for (int i = 0; i < 3; ++i) b[i] = bq[s % PF][i];
           if (s + PF < NS) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) bq[s % PF][i] = own[bnode[(s + PF) % KS] + i * 16];
+            for (int i = 0; i < 3; ++i) bq[s % PF][i] = brow((s + PF) % KS)[i * 16];
           }
 #pragma unroll
           for (int tt = 0; tt < TG; ++tt) {
@@ -362,25 +369,20 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     //      (elastic.py:213-216).  The own half of avg(u) is part of the volume tiles (E_r,
     //      mfma_tables.cpp), so the lift carries 1/2 u- on interior facets and the missing
     //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
-    //      (a boundary lane's neighbour pointer is its own cell).
+    //      (a boundary lane's neighbour pointer is its own cell); the 1/2 is in the lift tiles.
     //      Register budget: the facet's KSF*3 B values stay resident while the row tiles are
     //      accumulated one at a time (3 accumulators instead of 3*MTT); the next facet's values are
     //      requested before the last tile pass.  Row tile t covers the row-quads m = 4t .. 4t+3
     //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
     {
-      double flf[KSF][3];
-      request(0, nx);
+      request(0, nx[0]);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-#pragma unroll
-        for (int ks = 0; ks < KSF; ++ks)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) flf[ks][i] = 0.5 * nx[ks][i];
+        double(&flf)[KSF][3] = nx[f & 1];
 #pragma unroll
         for (int t = 0; t < MTT; ++t) {
-          // next facet's traces: asked for a whole facet ahead (nx and flf are both live in the last
-          // tile pass anyway, so the longer live range does not raise the register peak)
-          if (t == 0 && f + 1 < 4) request(f + 1, nx);
+          // next facet's traces: asked for a whole facet ahead
+          if (t == 0 && f + 1 < 4) request(f + 1, nx[(f + 1) & 1]);
           auto fold = [&](int m, double v0, double v1, double v2) {
             const double v[3] = {v0, v1, v2};
 #pragma unroll
@@ -425,53 +427,93 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 
     STAMP(st3);
     // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
+    //      vmcnt counts loads and stores together and the two kinds complete out of order with
+    //      each other, so any wait for a load (or a scratch reload) with stores in flight becomes a
+    //      wait for every store's acknowledgement.  Hence: finish ALL loads first, building the
+    //      results in place in Sd/So, and issue the item's stores back to back at the very end.
     {
       const long e = (L.valid ? L.c : 0) * 6 + k;
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
       const long obase = ((g * 6 + k) * (long)ND) * 9 * 16 + w;
-      double po[9], pa[9];
-      if (MODE == 1) {
-        const long o0 = obase + (long)q * 9 * 16;
+      if constexpr (SYM || MODE == 0) {
+        constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+        constexpr int PDE = 2;           // row-quads of old values in flight (MODE 1)
+        double po[PDE][6], pa[PDE][6];
+        auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
+        auto fetch_old = [&](int m) {
+          const int a1 = 4 * m + q;
+          const long o1 = obase + (long)((a1 < ND) ? a1 : 0) * 9 * 16;
 #pragma unroll
-        for (int ij = 0; ij < 9; ++ij)
-          if (!SYM || upper(ij)) {
-            po[ij] = out[o0 + ij * 16];
-            pa[ij] = aux[o0 + ij * 16];
+          for (int c = 0; c < 6; ++c) {
+            po[m % PDE][c] = out[o1 + line(c) * 16];
+            pa[m % PDE][c] = aux[o1 + line(c) * 16];
           }
-      }
-#pragma unroll
-      for (int m = 0; m < S4; ++m) {
-        const int a = 4 * m + q;
-        const bool st = L.active && a < ND;
-        const long o = obase + (long)((a < ND) ? a : 0) * 9 * 16;
-        const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
-        double s[9];
-        s[0] = 2.0 * mu * Sd[0][m] + tr;
-        s[4] = 2.0 * mu * Sd[1][m] + tr;
-        s[8] = 2.0 * mu * Sd[2][m] + tr;
-        s[1] = s[3] = mu * So[0][m];
-        s[2] = s[6] = mu * So[1][m];
-        s[5] = s[7] = mu * So[2][m];
+        };
         if (MODE == 1) {
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij)
-            if (!SYM || upper(ij)) s[ij] = A.c_self * po[ij] + A.c_aux * pa[ij] + A.c_new * s[ij];
-          if (m + 1 < S4) {
-            const int a1 = 4 * (m + 1) + q;
-            const long o1 = obase + (long)((a1 < ND) ? a1 : 0) * 9 * 16;
+          for (int m = 0; m < PDE && m < S4; ++m) fetch_old(m);
+        }
 #pragma unroll
-            for (int ij = 0; ij < 9; ++ij)
-              if (!SYM || upper(ij)) {
-                po[ij] = out[o1 + ij * 16];
-                pa[ij] = aux[o1 + ij * 16];
-              }
+        for (int m = 0; m < S4; ++m) {
+          const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            Sd[i][m] = 2.0 * mu * Sd[i][m] + tr;
+            So[i][m] = mu * So[i][m];
+          }
+          if (MODE == 1) {
+            // line order of the six slots: Sd0 So0 So1 Sd1 So2 Sd2
+            Sd[0][m] = A.c_self * po[m % PDE][0] + A.c_aux * pa[m % PDE][0] + A.c_new * Sd[0][m];
+            So[0][m] = A.c_self * po[m % PDE][1] + A.c_aux * pa[m % PDE][1] + A.c_new * So[0][m];
+            So[1][m] = A.c_self * po[m % PDE][2] + A.c_aux * pa[m % PDE][2] + A.c_new * So[1][m];
+            Sd[1][m] = A.c_self * po[m % PDE][3] + A.c_aux * pa[m % PDE][3] + A.c_new * Sd[1][m];
+            So[2][m] = A.c_self * po[m % PDE][4] + A.c_aux * pa[m % PDE][4] + A.c_new * So[2][m];
+            Sd[2][m] = A.c_self * po[m % PDE][5] + A.c_aux * pa[m % PDE][5] + A.c_new * Sd[2][m];
+            if (m + PDE < S4) fetch_old(m + PDE);
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+        }
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          const int a = 4 * m + q;
+          const long o = obase + (long)((a < ND) ? a : 0) * 9 * 16;
+          if (L.active && a < ND) {
+            out[o + 0 * 16] = Sd[0][m];
+            out[o + 1 * 16] = So[0][m];
+            out[o + 2 * 16] = So[1][m];
+            out[o + 4 * 16] = Sd[1][m];
+            out[o + 5 * 16] = So[2][m];
+            out[o + 8 * 16] = Sd[2][m];
+            if (!SYM) {
+              out[o + 3 * 16] = So[0][m];
+              out[o + 6 * 16] = So[1][m];
+              out[o + 7 * 16] = So[2][m];
+            }
           }
         }
-        if (st) {
+        (void)NL;
+      } else {
+        // full-tensor in-place combine (asymmetric user data, rare): nine results per node
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij)
-            if (!SYM || upper(ij)) out[o + ij * 16] = s[ij];
+        for (int m = 0; m < S4; ++m) {
+          const int a = 4 * m + q;
+          const long o = obase + (long)((a < ND) ? a : 0) * 9 * 16;
+          const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+          double s[9];
+          s[0] = 2.0 * mu * Sd[0][m] + tr;
+          s[4] = 2.0 * mu * Sd[1][m] + tr;
+          s[8] = 2.0 * mu * Sd[2][m] + tr;
+          s[1] = s[3] = mu * So[0][m];
+          s[2] = s[6] = mu * So[1][m];
+          s[5] = s[7] = mu * So[2][m];
+#pragma unroll
+          for (int ij = 0; ij < 9; ++ij) s[ij] = A.c_self * out[o + ij * 16] + A.c_aux * aux[o + ij * 16] + A.c_new * s[ij];
+          if (L.active && a < ND) {
+#pragma unroll
+            for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
+          }
         }
       }
     }
@@ -504,10 +546,6 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range((A.spread && A.item_list) ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
-  int bnode[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) bnode[ks] = ((4 * ks + q < ND) ? 4 * ks + q : 0) * 9 * 16;
-
   STAMP_DECL;
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
@@ -517,6 +555,11 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
     const double* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+    int qo = q * 9 * 16;  // B rows: see mfma_stage_G
+    asm volatile("" : "+v"(qo));
+    const double* ownq = own + qo;
+    const double* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 9 * 16 : own;
+    auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 9 * 16; };
     int lo = lane;
     asm volatile("" : "+v"(lo));
 
@@ -545,14 +588,14 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
     {
       double Tq[9];
-      load_tensor<SYM>(own + bnode[0], 16, Tq);
+      load_tensor<SYM>(brow(0), 16, Tq);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         double T[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) T[c] = Tq[c];
         if (ks + 1 < KS) {
-          load_tensor<SYM>(own + bnode[ks + 1], 16, Tq);
+          load_tensor<SYM>(brow(ks + 1), 16, Tq);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -578,7 +621,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary
     //      (elastic.py:206).  The own half of {T} is part of the volume tiles (E_r), so the lift
     //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
-    //      cancels the folded half): wf * (c n).T of whatever np[f] points at.
+    //      cancels the folded half): wf * (c n).T of whatever np[f] points at, the 1/2 being part
+    //      of the lift tiles.
 #ifndef SG_PFLF
 #define SG_PFLF 2
 #endif
@@ -592,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
       np[f] = R.p;
       nst[f] = R.cstride;
-      wf[f] = R.physical ? -0.5 : 0.5;
+      wf[f] = R.physical ? -1.0 : 1.0;
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
         const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
@@ -677,11 +721,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       }
     }
 
-    // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345)
+    // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345).
+    //      All loads first (results built in place in the accumulators), all stores last: see G.
+    if (MODE == 1) {
 #pragma unroll
-    for (int t = 0; t < MTF; ++t) {
-      double po[4][3], pa[4][3];
-      if (MODE == 1) {
+      for (int t = 0; t < MTF; ++t) {
+        double po[4][3], pa[4][3];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
@@ -691,38 +736,42 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
             pa[reg][i] = aux[o + i * 16];
           }
         }
-      }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
-        if (L.active) {
+        for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            double v = acc[i][t][reg];
-            if (MODE == 1) v = A.c_self * po[reg][i] + A.c_aux * pa[reg][i] + A.c_new * v;
-            out[o + i * 16] = v;
+            double v = A.c_self * po[reg][i] + A.c_aux * pa[reg][i] + A.c_new * acc[i][t][reg];
+            asm volatile("" : "+v"(v));
+            acc[i][t][reg] = v;
           }
+      }
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) {
+        const int a = 16 * MTF + 4 * t + q;
+        const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          accs[i][t] = A.c_self * out[o + i * 16] + A.c_aux * aux[o + i * 16] + A.c_new * accs[i][t];
+          asm volatile("" : "+v"(accs[i][t]));
         }
       }
     }
+    if (L.active) {
 #pragma unroll
-    for (int t = 0; t < NSM; ++t) {
-      const int a = 16 * MTF + 4 * t + q;
-      const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
-      double po[3], pa[3];
-      if (MODE == 1) {
+      for (int t = 0; t < MTF; ++t)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          po[i] = out[o + i * 16];
-          pa[i] = aux[o + i * 16];
+        for (int reg = 0; reg < 4; ++reg) {
+          const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) out[o + i * 16] = acc[i][t][reg];
         }
-      }
-      if (L.active && a < ND) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          double v = accs[i][t];
-          if (MODE == 1) v = A.c_self * po[i] + A.c_aux * pa[i] + A.c_new * v;
-          out[o + i * 16] = v;
+      for (int t = 0; t < NSM; ++t) {
+        const int a = 16 * MTF + 4 * t + q;
+        if (a < ND) {
+          const long o = ubase + (long)a * 3 * 16;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) out[o + i * 16] = accs[i][t];
         }
       }
     }

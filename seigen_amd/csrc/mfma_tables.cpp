@@ -78,7 +78,7 @@ std::vector<double> mfma_frags_L(const RefElem& re) {
         size_t frag = ((size_t)f * g.mtt + t) * g.ksf + k0;
         for (int l = 0; l < 64; ++l) {
           int a = tile_row(g, t, l), b = 4 * k0 + (l >> 4);
-          out[frag * 64 + l] = (a < re.nd && b < re.nf) ? re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
+          out[frag * 64 + l] = (a < re.nd && b < re.nf) ? 0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
         }
       }
   return out;

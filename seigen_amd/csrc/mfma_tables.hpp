@@ -42,7 +42,8 @@ std::vector<double> mfma_frags_F(const RefElem& re);
 // G volume: rows stacked rho = 4*s4*r + a:
 //   frag (t, k0): A[row][col] = E_r[a][4 k0 + col],  rho = 16 t + row
 std::vector<double> mfma_frags_G(const RefElem& re);
-// facet lifts (shared by F and G): frag ((f*mtt + t)*ksf + k0): A[row][col] = L_f[row0(t) + row][4 k0 + col]
+// facet lifts (shared by F and G): frag ((f*mtt + t)*ksf + k0): A[row][col] = 1/2 L_f[row0(t) + row][4 k0 + col]
+// (the 1/2 of the central flux average: both kernels lift +-1/2 of a neighbour trace)
 std::vector<double> mfma_frags_L(const RefElem& re);
 
 }  // namespace sg
