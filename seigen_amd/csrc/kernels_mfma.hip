@@ -35,9 +35,8 @@ struct MG {
   static constexpr int NSM = (ND % 16 + 3) / 4;      // 4-row tiles (4x4x4 MFMA) over the remaining rows
   static constexpr int MTT = MTF + NSM;
   static constexpr int S4 = (ND + 3) / 4;
-  static constexpr int MTG = (12 * S4 + 15) / 16;
   static constexpr int NFRAG_F = MTT * 3 * KS;
-  static constexpr int NFRAG_G = MTG * KS;
+  static constexpr int NFRAG_G = 3 * MTT * KS;
   static constexpr int NFRAG_L = 4 * MTT * KSF;
 };
 
@@ -144,6 +143,10 @@ __device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A,
   R.cstride = 16;
   R.ghost = false;
   R.physical = false;
+#ifdef SG_EXP_NOTRACE  // timing experiment only (wrong results): every trace read hits the own cell
+  R.physical = true;
+  return R;
+#endif
   const int axis = md.nb_axis[k][f];
   const int kn = md.nb_cls[k][f];
   if (axis < 0) {
@@ -208,13 +211,14 @@ __device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* s
 
 // --------------------------------------------------------------------------------------------
 //  G: sh_ij = lam d_ij W_kk + mu (W_ij + W_ji),  W_ik = -Jinv_rk (D_r u_i) + sum_f (c n)_k L_f u^_i
-//  Volume rows are stacked rho = 4*S4*r + a (mfma_tables.cpp) so that the three D_r u_i of
-//  one node sit in the same lane; only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
+//  Row tile t of every D_r leaves node a = 4 m + q in lane-group q (m = 4 t + reg for a large
+//  tile, m = 4*MTF + s for small tile s), so the three D_r u_i of one node meet in the same lane;
+//  only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
 // --------------------------------------------------------------------------------------------
 template <int P, int MODE, int SYM>
 __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   using M = MG<P>;
-  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, MTT = M::MTT, S4 = M::S4, MTG = M::MTG;
+  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
 #ifndef SG_PF
 #define SG_PF 3
 #endif
@@ -290,31 +294,30 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     };
     STAMP(st1);
     // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead.
-    //      Row tiles are processed in groups of TG with the k loop outside the tiles of a group:
-    //      one load of a B row feeds 3*TG MFMAs, and the cell data are re-read MTG/TG times
-    //      (through L2) instead of MTG times; 3*TG accumulator tiles are live next to Sd/So.
+    //      One pass over the k-steps per reference direction r with all row tiles of D_r live:
+    //      one load of a B row feeds 3*MTT MFMAs, and the cell data are read three times (twice
+    //      through L1/L2); 3*MTF accumulator tiles + 3*NSM values are live next to Sd/So.
     {
-#ifndef SG_TG
-#define SG_TG 2
-#endif
-      constexpr int TG = SG_TG;
-      constexpr int NGRP = (MTG + TG - 1) / TG;
-      constexpr int NS = NGRP * KS;
+      constexpr int NS = 3 * KS;
       double bq[PF][3];
 #pragma unroll
       for (int s = 0; s < PF; ++s)
 #pragma unroll
         for (int i = 0; i < 3; ++i) bq[s][i] = brow(s % KS)[i * 16];
 #pragma unroll
-      for (int grp = 0; grp < NGRP; ++grp) {
-        d4 acc[TG][3];
+      for (int r = 0; r < 3; ++r) {
+        d4 acc[MTF][3];
+        double accs[NSM][3];
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt)
+        for (int i = 0; i < 3; ++i) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) acc[tt][i] = d4{0, 0, 0, 0};
+          for (int t = 0; t < MTF; ++t) acc[t][i] = d4{0, 0, 0, 0};
+#pragma unroll
+          for (int t = 0; t < NSM; ++t) accs[t][i] = 0.0;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const int s = grp * KS + ks;
+          const int s = r * KS + ks;
           double b[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) b[i] = bq[s % PF][i];
@@ -323,44 +326,41 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
             for (int i = 0; i < 3; ++i) bq[s % PF][i] = brow((s + PF) % KS)[i * 16];
           }
 #pragma unroll
-          for (int tt = 0; tt < TG; ++tt) {
-            const int t = grp * TG + tt;
-            if (t < MTG) {
-              const double a = sAV[(t * KS + ks) * 64 + lo];
+          for (int t = 0; t < MTT; ++t) {
+            const double a = sAV[((r * MTT + t) * KS + ks) * 64 + lo];
 #pragma unroll
-              for (int i = 0; i < 3; ++i) acc[tt][i] = MFMA64(a, b[i], acc[tt][i]);
+            for (int i = 0; i < 3; ++i) {
+              if (t < MTF)
+                acc[t < MTF ? t : 0][i] = MFMA64(a, b[i], acc[t < MTF ? t : 0][i]);
+              else
+                accs[t < MTF ? 0 : t - MTF][i] = MFMA4(a, b[i], accs[t < MTF ? 0 : t - MTF][i]);
             }
           }
         }
+        auto fold = [&](int m, double v0, double v1, double v2) {
+          const double v[3] = {v0, v1, v2};
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) {
-          const int t = grp * TG + tt;
-          if (t < MTG) {
+          for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int rho4 = 4 * t + reg;
-              const int r = rho4 / S4, m = rho4 % S4;
-              if (r < 3) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                  const double v = acc[tt][i][reg];
-#pragma unroll
-                  for (int kk = 0; kk < 3; ++kk) {
-                    const double wv = Jm[r][kk] * v;
-                    if (i == kk)
-                      Sd[i][m] += wv;
-                    else
-                      So[i + kk - 1][m] += wv;
-                  }
-                }
-                // pin the fold here: LLVM otherwise sinks these FMA chains down to the epilogue
-                // (their only use), which keeps every accumulator tile live and spills
-#pragma unroll
-                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
-              }
+            for (int kk = 0; kk < 3; ++kk) {
+              const double wv = Jm[r][kk] * v[i];
+              if (i == kk)
+                Sd[i][m] += wv;
+              else
+                So[i + kk - 1][m] += wv;
             }
           }
-        }
+          // pin the fold here: LLVM otherwise sinks these FMA chains down to the epilogue
+          // (their only use), which keeps every accumulator tile live and spills
+#pragma unroll
+          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+        };
+#pragma unroll
+        for (int t = 0; t < MTF; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) fold(4 * t + reg, acc[t][0][reg], acc[t][1][reg], acc[t][2][reg]);
+#pragma unroll
+        for (int t = 0; t < NSM; ++t) fold(4 * MTF + t, accs[t][0], accs[t][1], accs[t][2]);
       }
     }
 
@@ -436,14 +436,19 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
       const long obase = ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+      // row-quad m of this lane = node 4 m + q: per-item base + compile-time offsets (see brow)
+      int qo9 = q * 9 * 16;
+      asm volatile("" : "+v"(qo9));
+      const long ob_q = obase + qo9;
+      const long ob_l = (4 * (S4 - 1) + q < ND) ? ob_q + (long)(S4 - 1) * 4 * 9 * 16 : obase;
+      auto orow = [&](int m) { return (m == S4 - 1) ? ob_l : ob_q + (long)m * 4 * 9 * 16; };
       if constexpr (SYM || MODE == 0) {
         constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
         constexpr int PDE = 2;           // row-quads of old values in flight (MODE 1)
         double po[PDE][6], pa[PDE][6];
         auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
         auto fetch_old = [&](int m) {
-          const int a1 = 4 * m + q;
-          const long o1 = obase + (long)((a1 < ND) ? a1 : 0) * 9 * 16;
+          const long o1 = orow(m);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             po[m % PDE][c] = out[o1 + line(c) * 16];
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
           const int a = 4 * m + q;
-          const long o = obase + (long)((a < ND) ? a : 0) * 9 * 16;
+          const long o = orow(m);
           if (L.active && a < ND) {
             out[o + 0 * 16] = Sd[0][m];
             out[o + 1 * 16] = So[0][m];
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
           const int a = 4 * m + q;
-          const long o = obase + (long)((a < ND) ? a : 0) * 9 * 16;
+          const long o = orow(m);
           const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
           double s[9];
           s[0] = 2.0 * mu * Sd[0][m] + tr;
@@ -686,6 +691,9 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // wave runs in program order, so all reads below precede the writes of the epilogue.
     const long e = (L.valid ? L.c : 0) * 6 + k;
     const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    int qo3 = q * 3 * 16;  // output rows: per-item base + compile-time offsets (see brow)
+    asm volatile("" : "+v"(qo3));
+    const long ub_q = ubase + qo3;
     if (A.sponge_slot != nullptr) {
       const int slot = L.active ? A.sponge_slot[e] : -1;
       if (__any(slot >= 0)) {
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         double po[4][3], pa[4][3];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
+          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             po[reg][i] = out[o + i * 16];
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
       for (int t = 0; t < NSM; ++t) {
         const int a = 16 * MTF + 4 * t + q;
-        const long o = ubase + (long)((a < ND) ? a : 0) * 3 * 16;
+        const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           accs[i][t] = A.c_self * out[o + i * 16] + A.c_aux * aux[o + i * 16] + A.c_new * accs[i][t];
@@ -761,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       for (int t = 0; t < MTF; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const long o = ubase + (long)(16 * t + 4 * reg + q) * 3 * 16;
+          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
 #pragma unroll
           for (int i = 0; i < 3; ++i) out[o + i * 16] = acc[i][t][reg];
         }
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       for (int t = 0; t < NSM; ++t) {
         const int a = 16 * MTF + 4 * t + q;
         if (a < ND) {
-          const long o = ubase + (long)a * 3 * 16;
+          const long o = ub_q + (long)(16 * MTF + 4 * t) * 3 * 16;
 #pragma unroll
           for (int i = 0; i < 3; ++i) out[o + i * 16] = accs[i][t];
         }

@@ -15,7 +15,6 @@ MfmaGeom mfma_geom(const RefElem& re) {
   g.nsm = (re.nd % 16 + 3) / 4;
   g.mtt = g.mtf + g.nsm;
   g.s4 = (re.nd + 3) / 4;
-  g.mtg = (3 * 4 * g.s4 + 15) / 16;
   return g;
 }
 
@@ -55,17 +54,13 @@ std::vector<double> mfma_frags_F(const RefElem& re) {
 
 std::vector<double> mfma_frags_G(const RefElem& re) {
   MfmaGeom g = mfma_geom(re);
-  const int S = 4 * g.s4;
-  std::vector<double> out((size_t)g.mtg * g.ks * 64, 0.0);
-  for (int t = 0; t < g.mtg; ++t)
-    for (int k0 = 0; k0 < g.ks; ++k0) {
-      size_t frag = (size_t)t * g.ks + k0;
-      for (int l = 0; l < 64; ++l) {
-        int rho = 16 * t + (l & 15);
-        int r = rho / S, a = rho % S;
-        out[frag * 64 + l] = (r < 3) ? Eval(re, r, a, 4 * k0 + (l >> 4)) : 0.0;
+  std::vector<double> out((size_t)3 * g.mtt * g.ks * 64, 0.0);
+  for (int r = 0; r < 3; ++r)
+    for (int t = 0; t < g.mtt; ++t)
+      for (int k0 = 0; k0 < g.ks; ++k0) {
+        size_t frag = ((size_t)r * g.mtt + t) * g.ks + k0;
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = Eval(re, r, tile_row(g, t, l), 4 * k0 + (l >> 4));
       }
-    }
   return out;
 }
 

@@ -28,8 +28,7 @@ struct MfmaGeom {
   int mtf;   // full 16-row tiles over the nodes = floor(nd / 16)
   int nsm;   // 4-row tiles over the remaining rows = ceil((nd % 16) / 4)
   int mtt;   // row tiles of either kind = mtf + nsm (large ones first)
-  int s4;    // row-quads per stacked D_r block = ceil(nd / 4)
-  int mtg;   // 16-row tiles of the stacked [D_0; D_1; D_2] (stride 4*s4 rows per block)
+  int s4;    // row-quads over the nodes = ceil(nd / 4)
 };
 
 MfmaGeom mfma_geom(const RefElem& re);
@@ -39,8 +38,8 @@ MfmaGeom mfma_geom(const RefElem& re);
 // where row tile t < mtf is large (row0 = 16 t) and t >= mtf small (row0 = 16 mtf + 4 (t - mtf))
 // (E_r = D_r minus the own-trace half of the central flux, see mfma_tables.cpp)
 std::vector<double> mfma_frags_F(const RefElem& re);
-// G volume: rows stacked rho = 4*s4*r + a:
-//   frag (t, k0): A[row][col] = E_r[a][4 k0 + col],  rho = 16 t + row
+// G volume: the row tiles of E_0, E_1, E_2 one after the other:
+//   frag ((r*mtt + t)*ks + k0): A[row][col] = E_r[row0(t) + row][4 k0 + col]
 std::vector<double> mfma_frags_G(const RefElem& re);
 // facet lifts (shared by F and G): frag ((f*mtt + t)*ksf + k0): A[row][col] = 1/2 L_f[row0(t) + row][4 k0 + col]
 // (the 1/2 of the central flux average: both kernels lift +-1/2 of a neighbour trace)
