@@ -25,6 +25,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 matrix peak (256 CUs x 128 flop/clk x 2.4 GHz)
+FP64_MFMA_SUSTAINED_TFLOPS = 52.4   # v_mfma_f64_16x16x4_f64 back to back, measured: the package sits at its
+                                    # 1.4 kW power cap and clocks down (tools/ubench_fp64_mix.hip, profiles/r01)
 
 
 def eigenmode3d_fields(X, t_u, t_s):
@@ -231,6 +234,15 @@ def main():
             "kernels": {k: {"avg_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"]} for k, v in kern.items()},
             "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9),
             "stage_avg_ms": [ms[i] / max(nl[i], 1) for i in range(6)]}
+    if mfma:
+        # second view of the same kernel: the dense element-local products on the FP64 matrix pipe.
+        # Algorithmic flop per cell and launch: 2 * (9 nd^2 + 12 nd nf), F and G alike.
+        nf = (P + 1) * (P + 2) // 2
+        flop = 2.0 * (9 * blk.nd ** 2 + 12 * blk.nd * nf) * blk.ncells
+        tf = flop / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+        roof["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                        "sustained_measured": FP64_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": tf / FP64_MFMA_SUSTAINED_TFLOPS,
+                        "algorithmic_flop_per_launch": flop}
 
     if rank == 0:
         out = {
