@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=64, help="cubes per axis per GPU (64 = BASELINE config 3)")
+    ap.add_argument("--n", "--cubes", type=int, default=64, help="cubes per axis per GPU (64 = BASELINE config 3)")
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -135,11 +135,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # RCCL over xGMI, one rank per GPU.  SEIGEN_DIST_BACKEND=gloo (+ SEIGEN_HIP_DEVICE) runs the same
+    # multi-process path with host-staged halos, e.g. two ranks on one GPU (tests/test_dist_gpu.py).
+    backend = os.environ.get("SEIGEN_DIST_BACKEND", "nccl")
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = int(os.environ.get("SEIGEN_HIP_DEVICE", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -184,7 +191,7 @@ def main():
     elapsed = t1 - t0
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 

@@ -48,7 +48,11 @@ class HaloExchanger(object):
     `block` needs: halo_bytes(field, side), halo_pack(field, side, ptr),
     halo_attach(field, side, ptr), run_stage(stage, region), end_step().
     Buffers are torch tensors on `device` so the same object serves RCCL
-    (device tensors) and gloo (CPU tensors)."""
+    (device tensors) and gloo (CPU tensors).  A process group without
+    device-to-device transport (gloo) under a block that lives on a GPU is
+    served through pinned host mirrors of the buffers ("host-staged": pack on
+    the device, copy out, send, copy in) - the transport for machines without
+    a GPU-aware fabric and for exercising the multi-process path on one GPU."""
 
     def __init__(self, block, partition, device, group=None, stream=None):
         import torch
@@ -58,6 +62,9 @@ class HaloExchanger(object):
         self.part = partition
         self.group = group
         self.stream = stream      # torch.cuda.Stream the block launches on (None: CPU tensors / gloo)
+        on_gpu = torch.device(device).type == "cuda"
+        self.staged = on_gpu and dist.get_backend(group) != "nccl"
+        self.hsend, self.hrecv = {}, {}
         self.sides = [s for s in range(2 * partition.dim) if partition.neighbour(s) is not None]
         self.send, self.recv = {}, {}
         for kind, field in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S)):
@@ -65,6 +72,9 @@ class HaloExchanger(object):
                 n = block.halo_bytes(field, s) // 8
                 self.send[(kind, s)] = torch.zeros(n, dtype=torch.float64, device=device)
                 self.recv[(kind, s)] = torch.zeros(n, dtype=torch.float64, device=device)
+                if self.staged:
+                    self.hsend[(kind, s)] = torch.zeros(n, dtype=torch.float64).pin_memory()
+                    self.hrecv[(kind, s)] = torch.zeros(n, dtype=torch.float64).pin_memory()
         # both fields of a kind read the same ghost buffer: a buffer is consumed by the stage
         # that follows its exchange before the next exchange of that kind starts
         for field in (_lib.FIELD_U, _lib.FIELD_UH, _lib.FIELD_S, _lib.FIELD_SH):
@@ -76,28 +86,40 @@ class HaloExchanger(object):
     def start(self, field):
         """Pack the block-side traces of `field` and post the sends / receives."""
         kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+        for s in self.sides:
+            self.block.halo_pack(field, s, self.send[(kind, s)].data_ptr())
+            self.bytes_sent += self.send[(kind, s)].numel() * 8
+        if not self.sides:
+            return (kind, [])
+        wire_out, wire_in = (self.hsend, self.hrecv) if self.staged else (self.send, self.recv)
+        if self.staged:
+            with self.torch.cuda.stream(self.stream):
+                for s in self.sides:
+                    self.hsend[(kind, s)].copy_(self.send[(kind, s)], non_blocking=True)
+            (self.stream.synchronize if self.stream is not None else self.torch.cuda.synchronize)()
         ops = []
         for s in self.sides:
             peer = self.part.neighbour(s)
-            self.block.halo_pack(field, s, self.send[(kind, s)].data_ptr())
-            ops.append(self.dist.P2POp(self.dist.isend, self.send[(kind, s)], peer, self.group))
-            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[(kind, s)], peer, self.group))
-            self.bytes_sent += self.send[(kind, s)].numel() * 8
-        if not ops:
-            return []
-        if self.stream is not None:
+            ops.append(self.dist.P2POp(self.dist.isend, wire_out[(kind, s)], peer, self.group))
+            ops.append(self.dist.P2POp(self.dist.irecv, wire_in[(kind, s)], peer, self.group))
+        if self.stream is not None and not self.staged:
             with self.torch.cuda.stream(self.stream):   # RCCL orders itself against the CURRENT stream
-                return self.dist.batch_isend_irecv(ops)
-        return self.dist.batch_isend_irecv(ops)
+                return (kind, self.dist.batch_isend_irecv(ops))
+        return (kind, self.dist.batch_isend_irecv(ops))
 
-    def finish(self, reqs):
-        if self.stream is not None:
+    def finish(self, pending):
+        kind, reqs = pending
+        if self.stream is not None and not self.staged:
             with self.torch.cuda.stream(self.stream):
                 for r in reqs:
                     r.wait()
             return
         for r in reqs:
             r.wait()
+        if self.staged:
+            with self.torch.cuda.stream(self.stream):
+                for s in self.sides:
+                    self.recv[(kind, s)].copy_(self.hrecv[(kind, s)], non_blocking=True)
 
     def step(self, nsteps=1):
         """`nsteps` LF4 steps: per stage exchange || interior, then the boundary shell."""

@@ -1,0 +1,69 @@
+"""Worker of tests/test_dist_gpu.py: one rank of a multi-process eigenmode run (launched by
+torch.distributed.run).  Every rank saves its block's final fields; the test process repeats the run
+on the whole mesh with a single block (`run_case(..., None)`) for the bitwise comparison of SURVEY 8(e)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    if os.environ.get("SEIGEN_TEST_HANG_DUMP"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SEIGEN_TEST_HANG_DUMP"]), exit=True)
+    out, degree, nsteps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    n = tuple(int(x) for x in sys.argv[4].split(","))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(int(os.environ.get("SEIGEN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    dist.init_process_group(os.environ.get("SEIGEN_DIST_BACKEND", "gloo"))
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    from seigen_amd.mesh import Partition
+    grid = tuple(int(x) for x in sys.argv[5].split(","))
+    part = Partition(n, rank, world, grid)
+    el, u, s = run_case(n, degree, nsteps, part)
+    np.savez(os.path.join(out, "rank%d.npz" % rank), u=u, s=s, start=np.array(part.start), n=np.array(part.n),
+             bytes_sent=el._exchanger.bytes_sent, staged=int(el._exchanger.staged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def case_fields(X):
+    """Smooth, asymmetric-looking but symmetric-stress initial data as a function of position."""
+    u0 = np.stack([np.sin(3 * X[..., 0]) * np.cos(2 * X[..., 1] + X[..., 2]),
+                   np.cos(X[..., 0] - 2 * X[..., 2]), np.sin(X[..., 1] * X[..., 2] + X[..., 0])], axis=-1)
+    t = np.cos(2 * X[..., 0] + X[..., 1]) * np.sin(X[..., 2] - X[..., 1])
+    s0 = np.zeros(X.shape[:-1] + (3, 3))
+    for i in range(3):
+        for j in range(3):
+            s0[..., i, j] = (1 + i + j) * t + 0.1 * (i + j) * X[..., (i + j) % 3]
+    return u0, s0
+
+
+def run_case(n, degree, nsteps, part):
+    """`nsteps` LF4 steps of the case on the block `part` (None: the whole mesh, no process group)."""
+    import seigen_amd
+    from seigen_amd import ElasticLF4, BoxMesh
+    import seigen_amd.helpers as helpers
+    helpers.log = lambda s: None
+    seigen_amd.elastic.log = lambda s: None
+    mesh = BoxMesh(n[0], n[1], n[2], 1.0, 1.0, 1.0)
+    if part is not None:
+        mesh.set_partition(part)
+    el = ElasticLF4.create(mesh, "DG", degree, dimension=3, solver="explicit", output=False)
+    el.density, el.mu, el.l = 1.0, 0.25, 0.5
+    el.dt = 0.5 * (1.0 / max(n)) / 2 ** (degree - 1)
+    u0, s0 = case_fields(el.U.node_coords())      # this block's nodes, global coordinates
+    el.u0.dat.data = u0.reshape(-1, 3)
+    el.s0.dat.data = s0.reshape(-1, 3, 3)
+    el.setup()
+    el._advance(nsteps)
+    el.block.sync()
+    return el, np.array(el.u1.dat.data_cells), np.array(el.s1.dat.data_cells)
+
+
+if __name__ == "__main__":
+    main()

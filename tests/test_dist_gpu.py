@@ -1,0 +1,74 @@
+"""The multi-process path on hardware: two ranks (torch.distributed.run) sharing ONE MI355X, gloo
+process group with host-staged halos (seigen_amd/parallel.py), through the public solver class.
+Everything of the N > 1 path except the RCCL transport itself runs here: process-group set-up,
+partition, exchanger, interior/boundary launches, bench.py's timing and reduction.  The result
+must equal the single-block run bitwise."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch(nproc, script_args, timeout=240):
+    env = dict(os.environ, SEIGEN_DIST_BACKEND="gloo", SEIGEN_HIP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2", SEIGEN_TEST_HANG_DUMP="200")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("degree,n,grid,world", [
+    (4, (16, 4, 4), (1, 1, 2), 2),      # MFMA path, z split
+    (3, (16, 4, 2), (1, 2, 1), 2),      # MFMA path, y split
+    (2, (4, 4, 4), (2, 1, 1), 2),       # generic path, x split
+    (4, (16, 4, 4), (1, 2, 2), 4),      # four ranks on one device
+])
+def test_two_processes_one_gpu_bitwise(gpu, tmp_path, degree, n, grid, world):
+    r = _launch(world, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(degree), "3",
+                        ",".join(map(str, n)), ",".join(map(str, grid))])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import run_case
+    _, us, ss = run_case(n, degree, 3, None)
+    single = {"u": us, "s": ss}
+    for rank in range(world):
+        d = np.load(tmp_path / ("rank%d.npz" % rank))
+        assert int(d["staged"]) == 1 and int(d["bytes_sent"]) > 0
+        start, bn = d["start"], d["n"]
+        idx = []
+        for kz in range(start[2], start[2] + bn[2]):
+            for j in range(start[1], start[1] + bn[1]):
+                for i in range(start[0], start[0] + bn[0]):
+                    cube = i + n[0] * (j + n[1] * kz)
+                    idx.extend(cube * 6 + k for k in range(6))
+        idx = np.array(idx)
+        assert np.isfinite(d["u"]).all() and np.abs(d["u"]).max() > 0
+        assert np.array_equal(d["u"], single["u"][idx]), "velocity differs from the single-block run (rank %d)" % rank
+        assert np.array_equal(d["s"], single["s"][idx]), "stress differs from the single-block run (rank %d)" % rank
+
+
+def test_bench_two_ranks_one_gpu(gpu):
+    """bench.py as the driver launches it for N > 1 (here: 2 ranks on one device, gloo)."""
+    r = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cubes", "16"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["cells"] == 2 * 16 ** 3 * 6
+    assert "cpu_baseline" not in out
