@@ -106,6 +106,10 @@ void sg_destroy(sg_handle* h);
 const char* sg_last_error(const sg_handle* h); /* h may be NULL: error of the last failed sg_create */
 int sg_get_info(const sg_handle* h, sg_info_t* out);
 int sg_sync(sg_handle* h);
+/* the hipStream_t the handle launches on (its own or the one given in sg_config): the host layer
+ * makes it the current stream around its torch.distributed calls, which order themselves against
+ * the current stream (the role PyOP2's implicit halo/compute ordering has, elastic.py:404-436) */
+int sg_get_stream(const sg_handle* h, void** stream);
 
 /* physical coordinates of the DG nodes, [cell][node][dim]; `degree` may differ
  * from the solver's (e.g. 4 for the DG4 sponge space of

@@ -38,6 +38,12 @@ class HipBlock(object):
         self.halo_faces = [int(x) for x in info.halo_faces]
         self.nbr_mask = int(nbr_mask)
 
+    def stream_ptr(self):
+        """hipStream_t (as an integer) the block launches on."""
+        p = C.c_void_p()
+        check(self.lib.sg_get_stream(self.h, C.byref(p)), self.h)
+        return p.value or 0
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.sg_destroy(self.h)

@@ -63,6 +63,7 @@ struct sg_handle {
   // execution
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  int grid_blocks = 0;  // persistent grid of the MFMA stage kernels
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
   bool timing = false;
@@ -244,6 +245,18 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMalloc((void**)&h->dbg, 32 * sizeof(unsigned long long)));
     HIPCHECK(h, hipMemset(h->dbg, 0, 32 * sizeof(unsigned long long)));
   }
+  {
+    // Persistent grid of the MFMA stage kernels: two blocks per CU fill every CU (registers and
+    // LDS allow exactly two).  A block with halo neighbours leaves 1/16 of those slots empty, so
+    // that RCCL's send/receive kernels can start WHILE an interior launch runs: behind a full
+    // grid they only start when it drains (tools/overlap_probe.py), and a stage kernel that found
+    // some of its own slots taken would run the late blocks' static shares one after the other.
+    hipDeviceProp_t prop;
+    HIPCHECK(h, hipGetDeviceProperties(&prop, cfg->device));
+    const int slots = 2 * prop.multiProcessorCount;
+    h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
+    if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
+  }
   if (cfg->stream) {
     h->stream = (hipStream_t)cfg->stream;
   } else {
@@ -270,6 +283,12 @@ int sg_create(const sg_config* cfg, sg_handle** out) {
     return rc;
   }
   *out = h;
+  return SG_OK;
+}
+
+int sg_get_stream(const sg_handle* h, void** stream) {
+  if (!h || !stream) return SG_ERR_ARG;
+  *stream = (void*)h->stream;
   return SG_OK;
 }
 
@@ -660,6 +679,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     }
     if (a.nbox == 0) return SG_OK;
     a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
+    a.grid_blocks = h->grid_blocks;
     a.item_list = nullptr;
     a.nlist = 0;
     if (a.spread) {

@@ -36,6 +36,7 @@ struct StageArgs {
   const int32_t* item_list;  // spread = 1: the active items (cell group * ncls + class) of the shell, or null
   int32_t nlist;
   int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
+  int32_t grid_blocks;          // MFMA path: size of the persistent grid (a multiple of 8)
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)

@@ -791,7 +791,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 
 template <int P, int SYM>
 static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
-  const dim3 grid(512), block(256);  // 2 blocks per CU; a multiple of 8 (one item range per XCD label)
+  // persistent grid, at most 2 blocks per CU; a multiple of 8 (one item range per XCD label)
+  const dim3 grid((unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512)), block(256);
   if (kind == 0) {
     if (a.mode == 0)
       hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM>), grid, block, 0, s, a);

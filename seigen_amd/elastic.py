@@ -122,21 +122,19 @@ class ElasticLF4(object):
     # ---- device block ---------------------------------------------------------------------
     def _create_block(self):
         part = self.mesh.partition
-        stream = None
+        origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
+        block = HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin, self.mesh.diagonal,
+                         part.nbr_mask, device=_device_for_rank())
         self._torch_stream = None
         if part.world > 1:
-            # one process per GPU: kernels and the RCCL point-to-point traffic must be ordered on ONE
-            # stream.  A dedicated torch stream (never the null stream, whose handle is 0 and would
-            # make the library create a stream of its own) is handed to the library and made current
-            # around every torch.distributed call (seigen_amd/parallel.py).
+            # One process per GPU: the library's launch stream, wrapped for torch, is made current
+            # around every torch.distributed call (seigen_amd/parallel.py), so packs, exchanges and
+            # the boundary launches are ordered on it.
             import torch
             if torch.cuda.is_available():
                 torch.cuda.set_device(_device_for_rank())
-                self._torch_stream = torch.cuda.Stream(device=_device_for_rank())
-                stream = self._torch_stream.cuda_stream
-        origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
-        return HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin, self.mesh.diagonal,
-                        part.nbr_mask, device=_device_for_rank(), stream=stream)
+                self._torch_stream = torch.cuda.ExternalStream(block.stream_ptr(), device=_device_for_rank())
+        return block
 
     @property
     def block(self):
