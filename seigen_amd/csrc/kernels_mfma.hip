@@ -40,6 +40,17 @@ struct MG {
   static constexpr int NFRAG_L = 4 * MTT * KSF;
 };
 
+// Streaming accesses (SG_STREAM_HINT): old values of the fused combine and all results are touched
+// once per launch; the non-temporal hint keeps them from displacing the cell data that the
+// neighbours' lift phases are about to ask the L2 for: fabric reads -4 % (F) to -23 % (G<4,0>), step
+// time -2 %.  (The same hint on the trace loads themselves changes no traffic and costs time.)
+#ifndef SG_NO_STREAM_HINT
+#define LD_STREAM(p) __builtin_nontemporal_load(p)
+#define ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define LD_STREAM(p) (*(p))
+#define ST_STREAM(p, v) (*(p) = (v))
+#endif
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 // 4 rows x 16 cells (four 4x4 blocks), same B register as MFMA64; lane l of the result holds
 // row (l >> 4) of cell (l & 15).  About 1/6 of the issue time of MFMA64 (mfma_tables.hpp).
@@ -451,8 +462,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           const long o1 = orow(m);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
-            po[m % PDE][c] = out[o1 + line(c) * 16];
-            pa[m % PDE][c] = aux[o1 + line(c) * 16];
+            po[m % PDE][c] = LD_STREAM(&out[o1 + line(c) * 16]);
+            pa[m % PDE][c] = LD_STREAM(&aux[o1 + line(c) * 16]);
           }
         };
         if (MODE == 1) {
@@ -485,16 +496,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           const int a = 4 * m + q;
           const long o = orow(m);
           if (L.active && a < ND) {
-            out[o + 0 * 16] = Sd[0][m];
-            out[o + 1 * 16] = So[0][m];
-            out[o + 2 * 16] = So[1][m];
-            out[o + 4 * 16] = Sd[1][m];
-            out[o + 5 * 16] = So[2][m];
-            out[o + 8 * 16] = Sd[2][m];
+            ST_STREAM(&out[o + 0 * 16], Sd[0][m]);
+            ST_STREAM(&out[o + 1 * 16], So[0][m]);
+            ST_STREAM(&out[o + 2 * 16], So[1][m]);
+            ST_STREAM(&out[o + 4 * 16], Sd[1][m]);
+            ST_STREAM(&out[o + 5 * 16], So[2][m]);
+            ST_STREAM(&out[o + 8 * 16], Sd[2][m]);
             if (!SYM) {
-              out[o + 3 * 16] = So[0][m];
-              out[o + 6 * 16] = So[1][m];
-              out[o + 7 * 16] = So[2][m];
+              ST_STREAM(&out[o + 3 * 16], So[0][m]);
+              ST_STREAM(&out[o + 6 * 16], So[1][m]);
+              ST_STREAM(&out[o + 7 * 16], So[2][m]);
             }
           }
         }
@@ -740,8 +751,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
           const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            po[reg][i] = out[o + i * 16];
-            pa[reg][i] = aux[o + i * 16];
+            po[reg][i] = LD_STREAM(&out[o + i * 16]);
+            pa[reg][i] = LD_STREAM(&aux[o + i * 16]);
           }
         }
 #pragma unroll
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          accs[i][t] = A.c_self * out[o + i * 16] + A.c_aux * aux[o + i * 16] + A.c_new * accs[i][t];
+          accs[i][t] = A.c_self * LD_STREAM(&out[o + i * 16]) + A.c_aux * LD_STREAM(&aux[o + i * 16]) + A.c_new * accs[i][t];
           asm volatile("" : "+v"(accs[i][t]));
         }
       }
@@ -771,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         for (int reg = 0; reg < 4; ++reg) {
           const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) out[o + i * 16] = acc[i][t][reg];
+          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], acc[i][t][reg]);
         }
 #pragma unroll
       for (int t = 0; t < NSM; ++t) {
@@ -779,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         if (a < ND) {
           const long o = ub_q + (long)(16 * MTF + 4 * t) * 3 * 16;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) out[o + i * 16] = accs[i][t];
+          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], accs[i][t]);
         }
       }
     }
