@@ -1,0 +1,146 @@
+"""BASELINE's full-size configurations on the GPU, checked through size-independent properties
+(the oracle cannot run these sizes in seconds):
+
+* the analytic eigenmode (tests/eigenmode/eigenmode_3d.py:30-40) sampled all over the mesh,
+* exact time reversal of the LF4 update: with central fluxes and no sponge the scheme
+  (seigen/elastic.py:291-304, :340-352) is reversible; undoing a step is the stress update run
+  with -dt followed by the velocity update with -dt, so K steps forward and K steps backward must
+  return the initial state to round-off.  Every launch of the step (plain and fused kernels,
+  interior and domain-boundary facets) takes part at the full size,
+* polynomial reproduction: g of a linear velocity field is the constant Hooke stress everywhere,
+  domain boundary included (own-trace boundary flux, elastic.py:216).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FORWARD = (0, 1, 2, 3, 4, 5)
+BACKWARD = (3, 4, 5, 0, 1, 2)     # with dt negated: undo the stress update, then the velocity update
+
+
+def _quiet():
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    helpers.log = lambda s: None
+    seigen_amd.elastic.log = lambda s: None
+
+
+def _sample_ranges(ncells, per=96, count=7):
+    """(cell0, ncells) pieces spread over the whole block, first and last cells included."""
+    starts = np.linspace(0, ncells - per, count).astype(np.int64)
+    return [(int(s), per) for s in starts]
+
+
+def _advance(blk, order, nsteps):
+    for _ in range(nsteps):
+        for stage in order:
+            blk.run_stage(stage)
+        blk.end_step()
+
+
+def test_config3_eigenmode_and_time_reversal_full_size(gpu):
+    """BASELINE config 3: 64^3 cubes x 6 tets, P4 (1 572 864 cells, 660.6 M DoF)."""
+    _quiet()
+    import bench
+    from seigen_amd import ElasticLF4, BoxMesh, _lib
+    from seigen_amd.functionspace import block_config
+    import ctypes as C
+    n, P = 64, 4
+    mesh = BoxMesh(n, n, n, 1.0, 1.0, 1.0)
+    el = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False)
+    el.density, el.mu, el.l = 1.0, 0.25, 0.5
+    el.dt = dt = 0.5 * (1.0 / n) / 2 ** (P - 1)
+    bench.fill_initial_condition(el, dt)
+    el.setup()
+    blk = el.block
+    blk.set_source([], None)
+    assert blk.ncells == 6 * n ** 3
+    # node coordinates of the sampled cells: whole z-layers of cubes, as bench.py builds them
+    lib = _lib.load()
+    layer_cells = n * n * 6
+    layers = (0, 21, 42, 63)
+
+    def layer_coords(k):
+        cfg = block_config(mesh, P)
+        cfg.n[2] = 1
+        cfg.origin[2] = k * mesh.h[2]
+        X = np.empty((layer_cells, blk.nd, 3))
+        _lib.check(lib.sg_block_node_coords(C.byref(cfg), P, X.ctypes.data, X.nbytes))
+        return X
+
+    pieces = [(k, c0, 192) for k in layers for c0 in (0, layer_cells // 2 - 96, layer_cells - 192)]
+    u_ic = {p: blk.get_field_range(_lib.FIELD_U, p[0] * layer_cells + p[1], p[2]) for p in pieces}
+    s_ic = {p: blk.get_field_range(_lib.FIELD_S, p[0] * layer_cells + p[1], p[2]) for p in pieces}
+
+    K = 4
+    _advance(blk, FORWARD, K)
+    blk.sync()
+    # analytic solution: u at t = K dt, s at t = K dt + dt/2 (staggered, eigenmode_3d.py:32-38)
+    worst_u = worst_s = 0.0
+    for p in pieces:
+        X = layer_coords(p[0])[p[1]:p[1] + p[2]]
+        ue, se = bench.eigenmode3d_fields(X, K * dt, K * dt + dt / 2)
+        worst_u = max(worst_u, np.abs(blk.get_field_range(_lib.FIELD_U, p[0] * layer_cells + p[1], p[2]) - ue).max())
+        worst_s = max(worst_s, np.abs(blk.get_field_range(_lib.FIELD_S, p[0] * layer_cells + p[1], p[2]) - se).max())
+    # P4 at h = 1/64: interpolation-level errors (fields are O(1)); any indexing slip would give O(1)
+    assert worst_u < 1e-7 and worst_s < 1e-7, (worst_u, worst_s)
+
+    blk.set_params(1.0, -dt, 0.5, 0.25)
+    _advance(blk, BACKWARD, K)
+    blk.sync()
+    for p in pieces:
+        du = np.abs(blk.get_field_range(_lib.FIELD_U, p[0] * layer_cells + p[1], p[2]) - u_ic[p]).max()
+        ds = np.abs(blk.get_field_range(_lib.FIELD_S, p[0] * layer_cells + p[1], p[2]) - s_ic[p]).max()
+        assert du < 1e-12 and ds < 1e-12, (p, du, ds)
+
+
+@pytest.mark.parametrize("dim,degree,n,steps", [
+    (2, 2, (512, 512), 6),        # BASELINE config 2's mesh and order (lane kernels)
+    (2, 3, (383, 121), 6),        # BASELINE config 5's mesh and order (generic kernels)
+    (3, 3, (48, 40, 36), 3),      # MFMA P3, ragged sizes (layout padding in x)
+    (3, 2, (48, 48, 48), 3),      # 3-D lane kernels
+])
+def test_time_reversal_and_linear_reproduction(gpu, dim, degree, n, steps):
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    h = tuple(1.0 / max(n) for _ in n)
+    blk = HipBlock(dim, degree, n, h, (0.0,) * dim)
+    lam, mu = 0.5, 0.25
+    dt = 0.25 * h[0] / degree ** 2
+    blk.set_params(1.0, dt, lam, mu)
+    X = blk.node_coords(degree)                       # [cells, nd, dim]
+    # ---- g of a linear velocity field = constant Hooke stress, everywhere
+    A = np.arange(1, dim * dim + 1, dtype=np.float64).reshape(dim, dim) / 7.0 - 0.4
+    u_lin = np.einsum("ij,cnj->cni", A, X) + 0.3
+    blk.set_field(_lib.FIELD_U, u_lin)
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    hooke = lam * np.trace(A) * np.eye(dim) + mu * (A + A.T)
+    for c0, nc in _sample_ranges(blk.ncells):
+        got = blk.get_field_range(_lib.FIELD_SH, c0, nc)
+        assert np.abs(got - hooke).max() < 1e-10 * max(n), (c0, np.abs(got - hooke).max())
+    # ---- time reversal from smooth, non-trivial data
+    rng = np.random.default_rng(5)
+    k = rng.uniform(1.0, 4.0, size=(dim, dim))
+    u0 = np.stack([np.sin(X @ k[i]) for i in range(dim)], axis=-1)
+    s0 = np.zeros(X.shape[:-1] + (dim, dim))
+    for i in range(dim):
+        for j in range(i, dim):
+            s0[..., i, j] = s0[..., j, i] = np.cos(X @ k[(i + j) % dim] + i - j)
+    blk.set_field(_lib.FIELD_U, u0)
+    blk.set_field(_lib.FIELD_S, s0)
+    _advance(blk, FORWARD, steps)
+    moved = np.abs(blk.get_field_range(_lib.FIELD_U, 0, 64) - u0[:64]).max()
+    assert moved > 1e-6, "the forward steps must change the state"
+    blk.set_params(1.0, -dt, lam, mu)
+    _advance(blk, BACKWARD, steps)
+    for c0, nc in _sample_ranges(blk.ncells):
+        du = np.abs(blk.get_field_range(_lib.FIELD_U, c0, nc) - u0[c0:c0 + nc]).max()
+        ds = np.abs(blk.get_field_range(_lib.FIELD_S, c0, nc) - s0[c0:c0 + nc]).max()
+        assert du < 1e-11 and ds < 1e-11, (c0, du, ds)
+    blk.close()
