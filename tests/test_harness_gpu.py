@@ -259,3 +259,59 @@ def test_pulse_1d(gpu):
     # a right-going pulse (u = -s) travels at Vp = 1: from x = 1 to x = 3 in T = 2
     k = np.unravel_index(np.abs(ou).argmax(), ou.shape)
     assert abs(X[k[0], k[1], 0] - 3.0) < 0.05 and abs(np.abs(ou).max() - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("degree,n", [(4, (5, 3, 2)), (3, (4, 2, 3)), (2, (3, 3, 2))])
+def test_3d_source_and_sponge(gpu, degree, n):
+    """The ingredients of BASELINE config 4 (3-D explosive source: a time-dependent diagonal stress
+    source in a box, elastic.py:217-218 / :285-288, and a DG4 sponge, :207-208) through the 3-D
+    kernels (MFMA for P3/P4, generic for P2), HIP vs oracle over 6 steps."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    L = (1.0, 0.6, 0.4)
+    h = [L[a] / n[a] for a in range(3)]
+    blk = HipBlock(3, degree, n, h, [0.0] * 3)
+    m = omesh.structured(3, n, L)
+    orc = OracleLF4(m, degree)
+    dt = 0.02 * min(h) / degree ** 2
+    orc.dt, orc.l, orc.mu, orc.density = dt, 0.5, 0.25, 1.0
+    blk.set_params(1.0, dt, 0.5, 0.25)
+    # sponge: sigma = 40 for x >= 0.7, interpolated into DG4 (explosive_source_lf4.py:43-45)
+    Xs = m.node_coords(4)
+    sig = np.where(Xs[..., 0] >= 0.7, 40.0, 0.0)
+    orc.E.set_absorption(sig, 4)
+    blk.set_absorption(sig, 4)
+    # source: indicator of a box times a Ricker-like pulse, on the diagonal
+    X = m.node_coords(degree)
+    mask = (np.abs(X[..., 0] - 0.3) <= 0.2) & (np.abs(X[..., 1] - 0.3) <= 0.2) & (np.abs(X[..., 2] - 0.2) <= 0.15)
+    assert mask.any()
+    pattern = np.zeros(X.shape[:-1] + (3, 3))
+    for i in range(3):
+        pattern[mask, i, i] = 1.0 + 0.5 * i
+
+    def pulse(t):
+        a = 4000.0
+        return (-1.0 + 2.0 * a * (t - 2.5 * dt) ** 2) * np.exp(-a * (t - 2.5 * dt) ** 2)
+
+    orc.source = lambda t: pulse(t) * pattern
+    nsteps = 6
+    nodes = np.nonzero(mask.ravel())[0]
+    vals = np.stack([pulse((k + 1) * dt) * pattern.reshape(-1, 3, 3)[nodes] for k in range(nsteps)])
+    blk.set_source(nodes, vals)
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 21)
+    s0 = seeded(blk.field_shape(_lib.FIELD_S), 22)
+    orc.s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(nsteps)
+    for k in range(nsteps):
+        orc.step((k + 1) * dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 1e-10
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
+    # both ingredients must matter: without them the result is different
+    plain = HipBlock(3, degree, n, h, [0.0] * 3)
+    plain.set_params(1.0, dt, 0.5, 0.25)
+    plain.set_field(_lib.FIELD_U, seeded(blk.field_shape(_lib.FIELD_U), 21))
+    plain.set_field(_lib.FIELD_S, 0.5 * (s0 + np.swapaxes(s0, -1, -2)))
+    plain.step(nsteps)
+    assert rel_err(plain.get_field(_lib.FIELD_U), orc.u1) > 1e-6
