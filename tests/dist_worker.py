@@ -23,8 +23,9 @@ def main():
 
     from seigen_amd.mesh import Partition
     grid = tuple(int(x) for x in sys.argv[5].split(","))
+    source = len(sys.argv) > 6 and sys.argv[6] == "source"
     part = Partition(n, rank, world, grid)
-    el, u, s = run_case(n, degree, nsteps, part)
+    el, u, s = run_case(n, degree, nsteps, part, source)
     np.savez(os.path.join(out, "rank%d.npz" % rank), u=u, s=s, start=np.array(part.start), n=np.array(part.n),
              bytes_sent=el._exchanger.bytes_sent, staged=int(el._exchanger.staged))
     dist.barrier()
@@ -43,10 +44,11 @@ def case_fields(X):
     return u0, s0
 
 
-def run_case(n, degree, nsteps, part):
-    """`nsteps` LF4 steps of the case on the block `part` (None: the whole mesh, no process group)."""
+def run_case(n, degree, nsteps, part, source=False):
+    """`nsteps` LF4 steps of the case on the block `part` (None: the whole mesh, no process group).
+    source: add a box-Ricker diagonal stress source and a DG4 sponge (3-D explosive source)."""
     import seigen_amd
-    from seigen_amd import ElasticLF4, BoxMesh
+    from seigen_amd import ElasticLF4, BoxMesh, Expression, Function, FunctionSpace
     import seigen_amd.helpers as helpers
     helpers.log = lambda s: None
     seigen_amd.elastic.log = lambda s: None
@@ -59,6 +61,16 @@ def run_case(n, degree, nsteps, part):
     u0, s0 = case_fields(el.U.node_coords())      # this block's nodes, global coordinates
     el.u0.dat.data = u0.reshape(-1, 3)
     el.s0.dat.data = s0.reshape(-1, 3, 3)
+    if source:
+        # the box straddles the block boundaries of every grid the tests use; the sponge too
+        box = "x[0] >= 0.2 && x[0] <= 0.7 && x[1] >= 0.3 && x[1] <= 0.8 && x[2] >= 0.3 && x[2] <= 0.8"
+        code = "%s ? (-1.0 + 2*a*pow(t - 2.5*dt, 2))*exp(-a*pow(t - 2.5*dt, 2)) : 0.0" % box
+        z = "0.0"
+        el.source_expression = Expression(((code, z, z), (z, code, z), (z, z, code)), a=4000.0, dt=el.dt, t=0)
+        el.source_function = Function(el.S)
+        el.source = el.source_expression
+        el.absorption_function = Function(FunctionSpace(mesh, "DG", 4))
+        el.absorption = Expression("x[1] >= 0.6 || x[2] <= 0.3 ? 30 : 0")
     el.setup()
     el._advance(nsteps)
     el.block.sync()

@@ -32,19 +32,21 @@ def _launch(nproc, script_args, timeout=240):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("degree,n,grid,world", [
-    (4, (16, 4, 4), (1, 1, 2), 2),      # MFMA path, z split
-    (3, (16, 4, 2), (1, 2, 1), 2),      # MFMA path, y split
-    (2, (4, 4, 4), (2, 1, 1), 2),       # generic path, x split
-    (4, (16, 4, 4), (1, 2, 2), 4),      # four ranks on one device
+@pytest.mark.parametrize("degree,n,grid,world,source", [
+    (4, (16, 4, 4), (1, 1, 2), 2, False),      # MFMA path, z split
+    (3, (16, 4, 2), (1, 2, 1), 2, False),      # MFMA path, y split
+    (2, (4, 4, 4), (2, 1, 1), 2, False),       # generic path, x split
+    (4, (16, 4, 4), (1, 2, 2), 4, False),      # four ranks on one device
+    (4, (16, 4, 4), (1, 2, 2), 4, True),       # config 4's shape: 3-D source + sponge across blocks
+    (2, (6, 4, 4), (2, 1, 2), 4, True),
 ])
-def test_two_processes_one_gpu_bitwise(gpu, tmp_path, degree, n, grid, world):
+def test_two_processes_one_gpu_bitwise(gpu, tmp_path, degree, n, grid, world, source):
     r = _launch(world, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(degree), "3",
-                        ",".join(map(str, n)), ",".join(map(str, grid))])
+                        ",".join(map(str, n)), ",".join(map(str, grid))] + (["source"] if source else []))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from dist_worker import run_case
-    _, us, ss = run_case(n, degree, 3, None)
+    _, us, ss = run_case(n, degree, 3, None, source)
     single = {"u": us, "s": ss}
     for rank in range(world):
         d = np.load(tmp_path / ("rank%d.npz" % rank))
