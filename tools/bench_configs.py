@@ -3,6 +3,8 @@
   c2: 2-D explosive source, 512x512 squares (524 288 triangles), P2, DG4 sponge + box-Ricker source
   c5: Marmousi 383x121 squares, P3, per-cell (lambda, mu) from seigen_amd/data/marmhard.dat
   c1: 2-D eigenmode 40x40, P1 (launch-overhead bound)
+  c4s: one rank's share of config 4 (3-D explosive source 256^3 on 8 GPUs): a 128^3-cube block, P4,
+       box-Ricker stress source, zero initial state - 85 GB resident on one device
 Prints one JSON line per config: M DoF-updates/s and ms/step (device time, hipEvents)."""
 import argparse
 import json
@@ -87,6 +89,25 @@ def config5(steps, warmup):
     return r
 
 
+def config4_share(steps, warmup, n=128):
+    from seigen_amd import BoxMesh
+    h = 2.5
+    mesh = BoxMesh(n, n, n, n * h, n * h, n * h)
+    el = ElasticLF4.create(mesh, "DG", 4, dimension=3, solver="explicit", output=False)
+    el.density, el.mu, el.l = 1.0, 3600.0, 3599.3664            # explosive_source_lf4.py:21-23
+    el.dt = cfl_dt(h, Vp(el.mu, el.l, el.density), 0.05) / 8   # 2^(P-1) as in eigenmode_3d.py's dt rule
+    c = 0.5 * n * h
+    box = " && ".join("x[%d] >= %r && x[%d] <= %r" % (a, c - 2 * h, a, c + 2 * h) for a in range(3))
+    code = "%s ? (-1.0 + 2*a*pow(t - 0.3, 2))*exp(-a*pow(t - 0.3, 2)) : 0.0" % box
+    z = "0.0"
+    el.source_expression = Expression(((code, z, z), (z, code, z), (z, z, code)), a=159.42, t=0)
+    el.source_function = Function(el.S)
+    el.source = el.source_expression
+    r = timed(el, steps, warmup)
+    r["config"] = "c4s: one rank's share of config 4: %d^3 cubes x 6 tets, P4, box-Ricker source" % n
+    return r
+
+
 def config1(steps, warmup):
     em = Eigenmode2DLF4(40, 1, 0.0125, output=False)
     el = em.elastic
@@ -104,7 +125,7 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=5)
     args = ap.parse_args()
     for c in args.configs:
-        r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large}[c](args.steps, args.warmup)
+        r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share}[c](args.steps, args.warmup)
         r["algorithmic_GBps"] = r["value"] * 1e6 * 64 / 1e9
         r["hbm_frac"] = r["algorithmic_GBps"] / 8000.0
         print(json.dumps(r))
