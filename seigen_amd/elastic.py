@@ -240,14 +240,17 @@ class ElasticLF4(object):
             v = vals.reshape(-1, self.dimension, self.dimension)[nz]
             return nz, np.broadcast_to(v, (nsteps,) + v.shape)
         t_keep = expr.t
-        sample = set(range(0, nsteps, max(1, nsteps // 64))) | {0, nsteps - 1}
-        support = np.zeros(X.shape[0] * X.shape[1], dtype=bool)
-        for k in sorted(sample):
-            expr.t = times[k]
-            v = expr.evaluate(X)
-            support |= np.abs(v).reshape(support.size, -1).max(axis=1) > 0
-        nz = np.nonzero(support)[0]
-        Xs = X.reshape(-1, X.shape[-1])[nz]
+        sample = sorted(set(range(0, nsteps, max(1, nsteps // 5))) | {0, nsteps - 1})
+        nz, Xs = [], []
+        for cell0, X in self.S.node_coords_chunks():      # slab by slab: bounded host memory
+            support = np.zeros(X.shape[0] * X.shape[1], dtype=bool)
+            for k in sample:
+                expr.t = times[k]
+                support |= expr.nonzero_mask(X).reshape(-1)
+            idx = np.nonzero(support)[0]
+            nz.append(idx + cell0 * X.shape[1])
+            Xs.append(X.reshape(-1, X.shape[-1])[idx])
+        nz, Xs = np.concatenate(nz), np.concatenate(Xs)
         values = np.zeros((nsteps, len(nz), self.dimension, self.dimension))
         for k in range(nsteps):
             expr.t = times[k]

@@ -192,10 +192,18 @@ def _eval(node, env):
     if k == "not":
         return np.where(_truth(_eval(node[1], env)), 0.0, 1.0)
     if k == "?:":
+        # each branch is evaluated only at the points that take it (a box-limited source is then
+        # nearly free outside its box: explosive_source_lf4.py:36-40 on 10^8 nodes)
         c = _truth(_eval(node[1], env))
-        a = _eval(node[2], env)
-        b = _eval(node[3], env)
-        return np.where(c, a, b)
+        if c.ndim == 0:
+            return _eval(node[2] if bool(c) else node[3], env)
+        out = np.empty(c.shape)
+        for mask, branch in ((c, node[2]), (~c, node[3])):
+            if mask.any():
+                sub = dict(env)
+                sub["x"] = [np.broadcast_to(xi, c.shape)[mask] for xi in env["x"]]
+                out[mask] = _eval(branch, sub)
+        return out
     a = _eval(node[1], env)
     b = _eval(node[2], env)
     if k == "+":
@@ -236,6 +244,9 @@ class Expression(object):
         flat = [code] if isinstance(code, str) else \
             ([c for row in code for c in row] if len(self.value_shape) == 2 else list(code))
         self._asts = [_Parser(str(c)).parse() for c in flat]
+        # components with the same source text are evaluated once (a diagonal source tensor has
+        # three equal entries and six zeros: explosive_source_lf4.py:36-40)
+        self._keys = [str(c).strip() for c in flat]
 
     def __getattr__(self, name):
         params = object.__getattribute__(self, "_params")
@@ -256,7 +267,27 @@ class Expression(object):
         """X: [..., dim] coordinates -> [..., *value_shape]."""
         X = np.asarray(X, dtype=np.float64)
         env = dict(self._params)
-        env["x"] = [X[..., i] for i in range(X.shape[-1])]
-        vals = [np.broadcast_to(np.asarray(_eval(a, env), dtype=np.float64), X.shape[:-1]) for a in self._asts]
-        out = np.stack(vals, axis=-1)
-        return out.reshape(X.shape[:-1] + self.value_shape)
+        env["x"] = [np.ascontiguousarray(X[..., i]) for i in range(X.shape[-1])]
+        done = {}
+        npts = int(np.prod(X.shape[:-1], dtype=np.int64))
+        out = np.empty((len(self._asts), npts))              # component-major: contiguous writes
+        for i, (key, ast) in enumerate(zip(self._keys, self._asts)):
+            if key not in done:
+                done[key] = np.broadcast_to(np.asarray(_eval(ast, env), dtype=np.float64), X.shape[:-1]).reshape(-1)
+            out[i] = done[key]
+        return np.ascontiguousarray(out.T).reshape(X.shape[:-1] + self.value_shape)
+
+    def nonzero_mask(self, X):
+        """X: [..., dim] -> bool [...]: some component is non-zero there (no value tensor is built)."""
+        X = np.asarray(X, dtype=np.float64)
+        env = dict(self._params)
+        env["x"] = [np.ascontiguousarray(X[..., i]) for i in range(X.shape[-1])]
+        mask = np.zeros(X.shape[:-1], dtype=bool)
+        for key in set(self._keys):
+            v = np.asarray(_eval(self._asts[self._keys.index(key)], env))
+            if v.ndim == 0:
+                if v != 0:
+                    mask[...] = True
+            else:
+                mask |= np.broadcast_to(v, mask.shape) != 0
+        return mask

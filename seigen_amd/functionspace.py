@@ -86,6 +86,25 @@ class FunctionSpace(object):
         return self._coords
 
 
+    def node_coords_chunks(self, max_nodes=1 << 22):
+        """Yields (cell0, X[cells, nd, dim]) over slabs of the block's last axis, at most about
+        `max_nodes` nodes at a time (a 128^3-cube P4 block has 440 M nodes = 10.6 GB of coordinates)."""
+        mesh, part = self.mesh, self.mesh.partition
+        d = self.dim
+        ncls = {1: 1, 2: 2, 3: 6}[d]
+        per_layer = int(np.prod(part.n[:d - 1])) * ncls if d > 1 else ncls
+        layers = max(1, int(max_nodes // max(1, per_layer * self.nd)))
+        lib = _lib.load()
+        for k0 in range(0, part.n[d - 1], layers):
+            nl = min(layers, part.n[d - 1] - k0)
+            cfg = block_config(mesh, min(self.degree, 4))
+            cfg.n[d - 1] = nl
+            cfg.origin[d - 1] = mesh.origin[d - 1] + (part.start[d - 1] + k0) * mesh.h[d - 1]
+            X = np.empty((per_layer * nl, self.nd, d))
+            _lib.check(lib.sg_block_node_coords(C.byref(cfg), self.degree, X.ctypes.data, X.nbytes))
+            yield k0 * per_layer, X
+
+
 class VectorFunctionSpace(FunctionSpace):
     def __init__(self, mesh, family, degree, name=None):
         super(VectorFunctionSpace, self).__init__(mesh, family, degree, name)
