@@ -35,6 +35,8 @@ struct sg_handle {
   int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
   int32_t* shell_items = nullptr;  // active (cell group, class) items of the boundary shell (MFMA / lane paths)
   int32_t shell_nitems = -1;       // -1: not built yet
+  int32_t* interior_items = nullptr;  // the same for the interior region of a block with halo neighbours
+  int32_t interior_nitems = -1;
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
@@ -110,6 +112,7 @@ void sg_destroy(sg_handle* h) {
   if (h->staging) (void)hipFree(h->staging);
   if (h->sym_flag) (void)hipFree(h->sym_flag);
   if (h->shell_items) (void)hipFree(h->shell_items);
+  if (h->interior_items) (void)hipFree(h->interior_items);
   if (h->dbg) {
     unsigned long long v[32];
     if (hipMemcpy(v, h->dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
@@ -682,8 +685,15 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     a.grid_blocks = h->grid_blocks;
     a.item_list = nullptr;
     a.nlist = 0;
-    if (a.spread) {
-      if (h->shell_nitems < 0) {  // the shell is static: list its cell groups once
+    if (region != SG_REGION_ALL) {
+      // Both regions of a split stage are static: list the (cell group, class) items that have
+      // an active cube once.  The interior launch then splits ACTIVE items evenly over the XCDs
+      // (a shell is whole z-layers of groups, i.e. the first items of XCD 0 and the last of XCD 7:
+      // skipping them inside an even split of all items would leave the launch as long as before);
+      // the shell launch deals its few items round-robin over all waves.
+      int32_t*& list = a.spread ? h->shell_items : h->interior_items;
+      int32_t& nlist = a.spread ? h->shell_nitems : h->interior_nitems;
+      if (nlist < 0) {
         const int64_t gw = h->md.gw, ngroups = h->md.ncube_pad / gw;
         std::vector<char> hit((size_t)ngroups, 0);
         for (int bx = 0; bx < a.nbox; ++bx)
@@ -697,14 +707,14 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
         for (int64_t g = 0; g < ngroups; ++g)
           if (hit[(size_t)g])
             for (int k = 0; k < h->ncls; ++k) items.push_back((int32_t)(g * h->ncls + k));
-        h->shell_nitems = (int32_t)items.size();
+        nlist = (int32_t)items.size();
         if (!items.empty()) {
-          HIPCHECK(h, hipMalloc((void**)&h->shell_items, items.size() * sizeof(int32_t)));
-          HIPCHECK(h, hipMemcpy(h->shell_items, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+          HIPCHECK(h, hipMalloc((void**)&list, items.size() * sizeof(int32_t)));
+          HIPCHECK(h, hipMemcpy(list, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
       }
-      a.item_list = h->shell_items;
-      a.nlist = h->shell_nitems;
+      a.item_list = list;
+      a.nlist = nlist;
     }
     int rc = h->use_mfma ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
                          : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);

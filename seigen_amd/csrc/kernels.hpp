@@ -33,7 +33,7 @@ struct StageArgs {
   int32_t nbox;
   int32_t boxes_o[6][3], boxes_n[6][3];
   int32_t spread;
-  const int32_t* item_list;  // spread = 1: the active items (cell group * ncls + class) of the shell, or null
+  const int32_t* item_list;  // a region of a split stage: its active items (cell group * ncls + class), else null
   int32_t nlist;
   int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
   int32_t grid_blocks;          // MFMA path: size of the persistent grid (a multiple of 8)

@@ -122,15 +122,15 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
   double* __restrict__ out = A.out;
 
   const long ngroups = md->ncube_pad >> 6;
-  const long nitems = ngroups * NCLS;
+  const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (api.cpp)
+  const long nitems = listed ? (long)A.nlist : ngroups * NCLS;
   // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2)
   const long nblk = gridDim.x, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
   const long blocks_here = (nblk - xcd + 7) / 8, ipx = (nitems + 7) / 8;
   const long lo = xcd * ipx, hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
 
   const long i0 = A.spread ? (long)blockIdx.x * 4 + wave : lo + slot * 4 + wave;
-  const bool listed = A.spread && A.item_list != nullptr;
-  const long i1 = listed ? (long)A.nlist : (A.spread ? nitems : hi);
+  const long i1 = A.spread ? nitems : hi;
   const long istep = A.spread ? (long)gridDim.x * 4 : blocks_here * 4;
   for (long it = i0; it < i1; it += istep) {
     const long item = listed ? (long)A.item_list[it] : it;

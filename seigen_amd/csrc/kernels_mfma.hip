@@ -249,12 +249,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   const double* __restrict__ aux = A.aux;
   double* __restrict__ out = A.out;
   const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range((A.spread && A.item_list) ? (long)A.nlist : ngroups * 6, wave, A.spread);
+  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
   STAMP_DECL;
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
-    const long item = (A.spread && A.item_list) ? (long)A.item_list[it] : it;
+    const long item = A.item_list ? (long)A.item_list[it] : it;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
@@ -560,12 +560,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   const double* __restrict__ aux = A.aux;
   double* __restrict__ out = A.out;
   const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range((A.spread && A.item_list) ? (long)A.nlist : ngroups * 6, wave, A.spread);
+  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
   STAMP_DECL;
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
-    const long item = (A.spread && A.item_list) ? (long)A.item_list[it] : it;
+    const long item = A.item_list ? (long)A.item_list[it] : it;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);

@@ -57,7 +57,55 @@ def run(mask, n=(64, 64, 64), degree=4, steps=10):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def breakdown(mask, n=(64, 64, 64), degree=4, steps=5):
+    """ms per step spent in the packs, the interior launches and the shell launches (events on the launch stream)."""
+    h = [1.0 / 64] * 3
+    blk = HipBlock(3, degree, n, h, [0.0] * 3, "left", mask)
+    blk.set_params(1.0, 0.5 / 64 / 8, 0.5, 0.25)
+    stream = torch.cuda.ExternalStream(blk.stream_ptr())
+    sides = [s for s in range(6) if mask >> s & 1]
+    bufs = {}
+    for kind, field in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S)):
+        for s in sides:
+            nb = blk.halo_bytes(field, s) // 8
+            bufs[(kind, s)] = (torch.zeros(nb, dtype=torch.float64, device="cuda"),
+                               torch.zeros(nb, dtype=torch.float64, device="cuda"))
+    for field in range(4):
+        kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+        for s in sides:
+            blk.halo_attach(field, s, bufs[(kind, s)][1].data_ptr())
+    tot = {"pack": 0.0, "interior": 0.0, "shell": 0.0}
+    for it in range(steps + 1):
+        marks = []
+        for stage in range(6):
+            field = STAGE_INPUT[stage]
+            kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(stream)
+            for s in sides:
+                blk.halo_pack(field, s, bufs[(kind, s)][0].data_ptr())
+            ev[1].record(stream)
+            blk.run_stage(stage, _lib.REGION_INTERIOR)
+            ev[2].record(stream)
+            blk.run_stage(stage, _lib.REGION_BOUNDARY)
+            ev[3].record(stream)
+            marks.append(ev)
+        blk.end_step()
+        blk.sync()
+        if it:
+            for ev in marks:
+                tot["pack"] += ev[0].elapsed_time(ev[1])
+                tot["interior"] += ev[1].elapsed_time(ev[2])
+                tot["shell"] += ev[2].elapsed_time(ev[3])
+    return {k: v / steps for k, v in tot.items()}
+
+
 if __name__ == "__main__":
+    if "--breakdown" in sys.argv:
+        for name, mask in (("z- and z+", 0b110000), ("y+, z-, z+", 0b111000)):
+            b = breakdown(mask)
+            print("%-28s packs %.3f  interior %.3f  shell %.3f ms/step" % (name, b["pack"], b["interior"], b["shell"]))
+        sys.exit(0)
     for name, mask in (("no neighbours (REGION_ALL)", 0), ("z- and z+", 0b110000), ("y+, z-, z+", 0b111000),
                        ("x+, y+, z+", 0b101010)):
         print("%-28s %.3f ms/step" % (name, run(mask)))
