@@ -66,6 +66,11 @@ struct sg_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int grid_blocks = 0;  // persistent grid of the MFMA stage kernels
+  // small blocks are launch-bound (config 1: six 5-us launches per step): sg_step replays captured
+  // hipGraphs of one and of eight steps there; any setter that changes kernel arguments bumps the epoch
+  bool graph_ok = false;
+  uint64_t epoch = 0, graph_epoch = ~0ull;
+  hipGraphExec_t graph1 = nullptr, graph8 = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
   bool timing = false;
@@ -111,6 +116,8 @@ void sg_destroy(sg_handle* h) {
   if (h->fragL) (void)hipFree(h->fragL);
   if (h->staging) (void)hipFree(h->staging);
   if (h->sym_flag) (void)hipFree(h->sym_flag);
+  if (h->graph1) (void)hipGraphExecDestroy(h->graph1);
+  if (h->graph8) (void)hipGraphExecDestroy(h->graph8);
   if (h->shell_items) (void)hipFree(h->shell_items);
   if (h->interior_items) (void)hipFree(h->interior_items);
   if (h->dbg) {
@@ -260,6 +267,11 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
   }
+  {
+    const char* ge = std::getenv("SEIGEN_HIP_GRAPH");  // 0/1 overrides (measurements)
+    const int64_t dofs = h->ncells * (int64_t)h->re.nd * (cfg->dim + cfg->dim * cfg->dim);
+    h->graph_ok = ge ? (std::strcmp(ge, "0") != 0) : (!h->use_mfma && dofs <= (int64_t)1 << 23);
+  }
   if (cfg->stream) {
     h->stream = (hipStream_t)cfg->stream;
   } else {
@@ -365,6 +377,7 @@ int sg_node_coords(const sg_handle* h, int degree, double* out, size_t nbytes) {
 }
 
 int sg_set_params(sg_handle* h, double density, double dt, const double* lambda, const double* mu, int per_cell) {
+  if (h) h->epoch += 1;
   if (!h || !lambda || !mu) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   h->rho = density;
@@ -389,6 +402,7 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
 
 // Leave symmetric-stress mode: make the (i > j) lines of both stress buffers valid again.
 static int leave_sym_mode(sg_handle* h) {
+  h->epoch += 1;
   if (!h->sym) return SG_OK;
   for (int f : {SG_FIELD_S, SG_FIELD_SH})
     if (launch_mirror(h->md, h->field[f], h->stream) != 0) return fail(h, SG_ERR_DEVICE, "mirror kernel launch failed");
@@ -483,6 +497,7 @@ int sg_get_field_range(sg_handle* h, int field, int64_t cell0, int64_t ncells, d
 }
 
 int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree) {
+  if (h) h->epoch += 1;
   if (!h) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -532,6 +547,7 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
 }
 
 int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values) {
+  if (h) h->epoch += 1;
   if (!h || nnz < 0) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -822,14 +838,57 @@ int sg_end_step(sg_handle* h) {
   return SG_OK;
 }
 
+// one LF4 step = six launches on the handle's stream (elastic.py:291-304)
+static int enqueue_step(sg_handle* h) {
+  for (int st = 0; st < 6; ++st) {
+    int rc = run_stage_impl(h, st, SG_REGION_ALL);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
+// capture `steps` steps into an executable graph; on any failure graphs are switched off for the handle
+static hipGraphExec_t capture_steps(sg_handle* h, int steps) {
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+  int rc = SG_OK;
+  for (int k = 0; k < steps && rc == SG_OK; ++k) rc = enqueue_step(h);
+  hipError_t e = hipStreamEndCapture(h->stream, &g);
+  if (rc == SG_OK && e == hipSuccess && g) {
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr;
+  }
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  return ge;
+}
+
 int sg_step(sg_handle* h, int64_t nsteps) {
   if (!h || nsteps < 0) return SG_ERR_ARG;
   if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
   for (int s = 0; s < 6; ++s)
     if (h->md.has_nbr[s]) return fail(h, SG_ERR_STATE, "sg_step on a block with neighbours: drive stages + halo from the host");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
+  int64_t k = 0;
+  // launch-bound blocks: replay captured graphs (no per-stage timing, no per-step source values)
+  const bool graphs = h->graph_ok && !h->timing && h->src_nnz == 0 && nsteps >= 2;
+  if (graphs && h->graph_epoch != h->epoch) {
+    if (h->graph1) (void)hipGraphExecDestroy(h->graph1);
+    if (h->graph8) (void)hipGraphExecDestroy(h->graph8);
+    h->graph1 = capture_steps(h, 1);
+    h->graph8 = h->graph1 ? capture_steps(h, 8) : nullptr;
+    h->graph_epoch = h->epoch;
+    if (!h->graph1 || !h->graph8) h->graph_ok = false;  // same kernels, launched one by one below
+  }
   HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
-  for (int64_t k = 0; k < nsteps; ++k) {
+  if (graphs && h->graph_ok) {
+    for (; k + 8 <= nsteps; k += 8) HIPCHECK(h, hipGraphLaunch(h->graph8, h->stream));
+    for (; k < nsteps; ++k) HIPCHECK(h, hipGraphLaunch(h->graph1, h->stream));
+    for (int st = 0; st < 6; ++st) h->counters.launches[st] += nsteps;
+    h->counters.steps += nsteps;
+    h->src_step += nsteps;
+  }
+  for (; k < nsteps; ++k) {
     for (int st = 0; st < 6; ++st) {
       if (h->timing) {
         int rc = sg_run_stage(h, st, SG_REGION_ALL);
