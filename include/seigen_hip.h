@@ -63,7 +63,11 @@ enum sg_stage {
 enum sg_region {
   SG_REGION_ALL = 0,
   SG_REGION_INTERIOR = 1, /* cubes whose stencil needs no remote trace */
-  SG_REGION_BOUNDARY = 2  /* the one-cube shell next to sides that have a neighbour block */
+  SG_REGION_BOUNDARY = 2, /* the one-cube shell next to sides that have a neighbour block */
+  /* the same stage cut differently, for the pipelined exchange (seigen_amd/parallel.py): */
+  SG_REGION_FIRST = 3,    /* the shell and the lower half of the interior: everything whose results
+                             the neighbours wait for, inside one large launch */
+  SG_REGION_SECOND = 4    /* the rest of the interior: runs while the traces of FIRST travel */
 };
 
 typedef struct sg_handle sg_handle;

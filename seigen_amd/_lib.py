@@ -12,7 +12,7 @@ LIB_ENV = "SEIGEN_HIP_LIB"
 SG_OK = 0
 FIELD_U, FIELD_UH, FIELD_S, FIELD_SH = 0, 1, 2, 3
 STAGE_UH1, STAGE_STEMP, STAGE_U1, STAGE_SH1, STAGE_UTEMP, STAGE_S1 = range(6)
-REGION_ALL, REGION_INTERIOR, REGION_BOUNDARY = 0, 1, 2
+REGION_ALL, REGION_INTERIOR, REGION_BOUNDARY, REGION_FIRST, REGION_SECOND = 0, 1, 2, 3, 4
 
 
 class SgConfig(C.Structure):

@@ -33,10 +33,9 @@ struct sg_handle {
   bool use_lane = false;
   bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
   int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
-  int32_t* shell_items = nullptr;  // active (cell group, class) items of the boundary shell (MFMA / lane paths)
-  int32_t shell_nitems = -1;       // -1: not built yet
-  int32_t* interior_items = nullptr;  // the same for the interior region of a block with halo neighbours
-  int32_t interior_nitems = -1;
+  // active (cell group, class) items of each region of a split stage (MFMA / lane paths), by sg_region
+  int32_t* region_items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t region_nitems[5] = {-1, -1, -1, -1, -1};  // -1: not built yet
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
@@ -56,6 +55,7 @@ struct sg_handle {
   double* sponge_B = nullptr;
   // source
   int64_t src_nnz = 0;
+  int64_t src_nfirst = 0;  // source nodes are stored with those in cells of SG_REGION_FIRST first
   int64_t* src_nodes = nullptr;
   double* src_values = nullptr;  // [nsteps][nnz][dim*dim]
   int64_t src_nsteps = 0;
@@ -65,7 +65,8 @@ struct sg_handle {
   // execution
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  int grid_blocks = 0;  // persistent grid of the MFMA stage kernels
+  int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
+  int grid_full = 0;    // ... and otherwise (every block slot of the device)
   // small blocks are launch-bound (config 1: six 5-us launches per step): sg_step replays captured
   // hipGraphs of one and of eight steps there; any setter that changes kernel arguments bumps the epoch
   bool graph_ok = false;
@@ -118,8 +119,8 @@ void sg_destroy(sg_handle* h) {
   if (h->sym_flag) (void)hipFree(h->sym_flag);
   if (h->graph1) (void)hipGraphExecDestroy(h->graph1);
   if (h->graph8) (void)hipGraphExecDestroy(h->graph8);
-  if (h->shell_items) (void)hipFree(h->shell_items);
-  if (h->interior_items) (void)hipFree(h->interior_items);
+  for (int r = 0; r < 5; ++r)
+    if (h->region_items[r]) (void)hipFree(h->region_items[r]);
   if (h->dbg) {
     unsigned long long v[32];
     if (hipMemcpy(v, h->dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
@@ -264,8 +265,10 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     hipDeviceProp_t prop;
     HIPCHECK(h, hipGetDeviceProperties(&prop, cfg->device));
     const int slots = 2 * prop.multiProcessorCount;
+    h->grid_full = slots / 8 * 8;
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
+    if (cfg->nbr_mask == 0) h->grid_full = h->grid_blocks;
   }
   {
     const char* ge = std::getenv("SEIGEN_HIP_GRAPH");  // 0/1 overrides (measurements)
@@ -546,6 +549,11 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   return SG_OK;
 }
 
+struct Box {
+  int o[3], n[3];
+};
+static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out);
+
 int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values) {
   if (h) h->epoch += 1;
   if (!h || nnz < 0) return SG_ERR_ARG;
@@ -581,28 +589,49 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   size_t vbytes = (size_t)nsteps * nnz * d * d * sizeof(double);
   HIPCHECK(h, hipMalloc((void**)&h->src_nodes, (size_t)nnz * sizeof(int64_t)));
   HIPCHECK(h, hipMalloc((void**)&h->src_values, vbytes));
-  // device offset of component 0 of each source node in the field layout (mesh_tables.hpp)
-  std::vector<int64_t> offs((size_t)nnz);
+  // Order the nodes so that those in cells of SG_REGION_FIRST come first: a split stage adds the
+  // source to each part right after the launch that wrote it (the traces of FIRST are packed
+  // before SECOND has run).  Then: device offset of component 0 of each node in the field layout.
+  std::vector<int64_t> order((size_t)nnz), offs((size_t)nnz);
   {
     const int64_t nd = h->re.nd, ncls = h->ncls, gw = h->md.gw, nc = (int64_t)d * d;
-    for (int64_t i = 0; i < nnz; ++i) {
-      int64_t e = nodes[i] / nd, b = nodes[i] % nd;
+    std::vector<Box> first;
+    region_boxes(h, SG_REGION_FIRST, first);
+    auto in_first = [&](int64_t node) {
+      const int64_t cube = node / nd / ncls;
+      const int64_t c[3] = {cube % h->cfg.n[0], (cube / h->cfg.n[0]) % h->cfg.n[1], cube / ((int64_t)h->cfg.n[0] * h->cfg.n[1])};
+      for (const Box& b : first) {
+        bool in = true;
+        for (int k = 0; k < 3; ++k) in = in && c[k] >= b.o[k] && c[k] < b.o[k] + b.n[k];
+        if (in) return true;
+      }
+      return false;
+    };
+    int64_t n1 = 0;
+    for (int64_t i = 0; i < nnz; ++i)
+      if (in_first(nodes[i])) order[(size_t)n1++] = i;
+    h->src_nfirst = n1;
+    for (int64_t i = 0; i < nnz; ++i)
+      if (!in_first(nodes[i])) order[(size_t)n1++] = i;
+    for (int64_t j = 0; j < nnz; ++j) {
+      const int64_t node = nodes[order[(size_t)j]];
+      int64_t e = node / nd, b = node % nd;
       int64_t cube = e / ncls, cls = e % ncls;
-      offs[(size_t)i] = ((((cube / gw) * ncls + cls) * nd + b) * nc) * gw + cube % gw;
+      offs[(size_t)j] = ((((cube / gw) * ncls + cls) * nd + b) * nc) * gw + cube % gw;
     }
   }
+  std::vector<double> vals((size_t)nsteps * nnz * d * d);
+  for (int64_t k = 0; k < nsteps; ++k)
+    for (int64_t j = 0; j < nnz; ++j)
+      std::memcpy(&vals[((size_t)k * nnz + j) * d * d], &values[((size_t)k * nnz + order[(size_t)j]) * d * d], sizeof(double) * d * d);
   HIPCHECK(h, hipMemcpy(h->src_nodes, offs.data(), (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
-  HIPCHECK(h, hipMemcpy(h->src_values, values, vbytes, hipMemcpyHostToDevice));
+  HIPCHECK(h, hipMemcpy(h->src_values, vals.data(), vbytes, hipMemcpyHostToDevice));
   h->src_nnz = nnz;
   h->src_nsteps = nsteps;
   return SG_OK;
 }
 
 // ---- stage launches --------------------------------------------------------------------
-
-struct Box {
-  int o[3], n[3];
-};
 
 static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
   out.clear();
@@ -623,6 +652,20 @@ static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) 
   if (region == SG_REGION_INTERIOR) {
     out.push_back(Box{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}});
     return;
+  }
+  // FIRST / SECOND: the interior cut in two along the slowest axis (whole runs of the layout)
+  const int ax = d - 1, mid = ilo[ax] + (ihi[ax] - ilo[ax]) / 2;
+  if (region == SG_REGION_SECOND) {
+    Box b{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}};
+    b.o[ax] = mid;
+    b.n[ax] = ihi[ax] - mid;
+    out.push_back(b);
+    return;
+  }
+  if (region == SG_REGION_FIRST) {
+    Box b{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}};
+    b.n[ax] = mid - ilo[ax];
+    out.push_back(b);
   }
   // boundary shell = all \ interior, as disjoint slabs: peel axis by axis
   int clo[3] = {lo[0], lo[1], lo[2]}, chi[3] = {hi[0], hi[1], hi[2]};
@@ -698,7 +741,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     }
     if (a.nbox == 0) return SG_OK;
     a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
-    a.grid_blocks = h->grid_blocks;
+    // only launches that run while an exchange is in flight leave block slots to RCCL
+    a.grid_blocks = (region == SG_REGION_INTERIOR || region == SG_REGION_SECOND) ? h->grid_blocks : h->grid_full;
     a.item_list = nullptr;
     a.nlist = 0;
     if (region != SG_REGION_ALL) {
@@ -707,8 +751,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       // (a shell is whole z-layers of groups, i.e. the first items of XCD 0 and the last of XCD 7:
       // skipping them inside an even split of all items would leave the launch as long as before);
       // the shell launch deals its few items round-robin over all waves.
-      int32_t*& list = a.spread ? h->shell_items : h->interior_items;
-      int32_t& nlist = a.spread ? h->shell_nitems : h->interior_nitems;
+      int32_t*& list = h->region_items[region];
+      int32_t& nlist = h->region_nitems[region];
       if (nlist < 0) {
         const int64_t gw = h->md.gw, ngroups = h->md.ncube_pad / gw;
         std::vector<char> hit((size_t)ngroups, 0);
@@ -751,11 +795,20 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   return SG_OK;
 }
 
-static int add_source(sg_handle* h, int field, double coef) {
-  if (h->src_nnz == 0 || h->src_step >= h->src_nsteps) return SG_OK;
+// the source lives on single nodes: added to each part of a split stage right after the launch
+// that wrote it (INTERIOR + BOUNDARY: all of it after the second launch)
+static int add_source(sg_handle* h, int field, double coef, int region = SG_REGION_ALL) {
+  if (h->src_nnz == 0 || h->src_step >= h->src_nsteps || region == SG_REGION_INTERIOR) return SG_OK;
   const int d = h->cfg.dim;
-  const double* vals = h->src_values + (size_t)h->src_step * h->src_nnz * d * d;
-  int rc = launch_source(h->field[field], d * d, h->md.gw, h->src_nnz, h->src_nodes, vals, coef, h->stream);
+  int64_t off = 0, cnt = h->src_nnz;
+  if (region == SG_REGION_FIRST) cnt = h->src_nfirst;
+  if (region == SG_REGION_SECOND) {
+    off = h->src_nfirst;
+    cnt = h->src_nnz - h->src_nfirst;
+  }
+  if (cnt == 0) return SG_OK;
+  const double* vals = h->src_values + ((size_t)h->src_step * h->src_nnz + off) * d * d;
+  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
   return SG_OK;
 }
@@ -763,27 +816,25 @@ static int add_source(sg_handle* h, int field, double coef) {
 static int run_stage_impl(sg_handle* h, int stage, int region) {
   const double dt = h->dt, c3 = dt * dt * dt / 24.0;
   int rc = SG_OK;
-  // the source lives on single nodes; apply it once per stage, with the region that owns everything
-  const bool src = (region == SG_REGION_ALL || region == SG_REGION_BOUNDARY);
   switch (stage) {
     case SG_STAGE_UH1:
       return run_op(h, 0, SG_FIELD_S, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
     case SG_STAGE_STEMP:
       rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
-      if (rc == SG_OK && src) rc = add_source(h, SG_FIELD_SH, 1.0);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
       return rc;
     case SG_STAGE_U1:
       // explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (elastic.py:341-345, :354-356)
       return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, h->rho, dt, c3, region);
     case SG_STAGE_SH1:
       rc = run_op(h, 1, SG_FIELD_U, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
-      if (rc == SG_OK && src) rc = add_source(h, SG_FIELD_SH, 1.0);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
       return rc;
     case SG_STAGE_UTEMP:
       return run_op(h, 0, SG_FIELD_SH, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
     case SG_STAGE_S1:
       rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, SG_FIELD_SH, 1, 1.0, dt, c3, region);
-      if (rc == SG_OK && src) rc = add_source(h, SG_FIELD_S, c3);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_S, c3, region);
       return rc;
   }
   return fail(h, SG_ERR_ARG, "unknown stage");
@@ -804,7 +855,7 @@ static int resolve_timing(sg_handle* h) {
 int sg_run_stage(sg_handle* h, int stage, int region) {
   if (!h) return SG_ERR_ARG;
   if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
-  if (region < 0 || region > 2) return fail(h, SG_ERR_ARG, "unknown region");
+  if (region < 0 || region > 4) return fail(h, SG_ERR_ARG, "unknown region");
   if (stage < 0 || stage > 5) return fail(h, SG_ERR_ARG, "unknown stage");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   size_t k = h->ev_stage.size();

@@ -4,10 +4,18 @@ Replaces the implicit PyOP2/MPI halo exchange that runs inside every
 ``assemble`` of the reference (``seigen/elastic.py:364``, ``:404-436``;
 ``ParLoopHaloEnd`` in ``tests/tiling/utils.py:144``).  DG couples cells only
 through facets (the ``dS`` terms, ``elastic.py:206``, ``:213-215``), so per
-stage each block sends the traces of the stage's INPUT field on its block
-sides to its face neighbours (`torch.distributed` point-to-point: RCCL over
-xGMI on GPUs, gloo in the CPU tests) and meanwhile computes the cells that
-need no remote data.
+stage each block sends the traces of a field on its block sides to its face
+neighbours (`torch.distributed` point-to-point: RCCL over xGMI on GPUs, gloo in
+the CPU tests) and meanwhile computes cells that nobody is waiting for.
+
+The exchange is pipelined across stages: the input of every stage is the output
+of the stage before it (STAGE_INPUT / STAGE_OUTPUT below), so a stage first
+runs SG_REGION_FIRST - the shell next to the neighbours together with half of
+the interior, one large launch -, sends the fresh traces of its OUTPUT, and
+runs the rest (SG_REGION_SECOND) while they travel; the next stage finds its
+halo in place.  (The plainer form - send the input's traces, run the interior,
+wait, run the shell - costs a separate small launch for the shell: 1.6 to 2.4
+items per wave on an MI355X, 7 % of the step.)
 """
 import os
 import sys
@@ -23,6 +31,16 @@ STAGE_INPUT = {
     _lib.STAGE_UTEMP: _lib.FIELD_SH,
     _lib.STAGE_S1: _lib.FIELD_UH,
 }
+# ... and its output, which is the input of the stage after it (cyclically over the step)
+STAGE_OUTPUT = {
+    _lib.STAGE_UH1: _lib.FIELD_UH,
+    _lib.STAGE_STEMP: _lib.FIELD_SH,
+    _lib.STAGE_U1: _lib.FIELD_U,
+    _lib.STAGE_SH1: _lib.FIELD_SH,
+    _lib.STAGE_UTEMP: _lib.FIELD_UH,
+    _lib.STAGE_S1: _lib.FIELD_S,
+}
+assert all(STAGE_OUTPUT[k] == STAGE_INPUT[(k + 1) % 6] for k in range(6))
 
 
 def _dist():
@@ -122,7 +140,23 @@ class HaloExchanger(object):
                     self.recv[(kind, s)].copy_(self.hrecv[(kind, s)], non_blocking=True)
 
     def step(self, nsteps=1):
-        """`nsteps` LF4 steps: per stage exchange || interior, then the boundary shell."""
+        """`nsteps` LF4 steps.  Per stage: FIRST (needs the halo of the stage's input, which the
+        stage before has sent) -> send the output's traces -> SECOND meanwhile -> receive.
+        The halo of the very first input is exchanged up front (the caller may have changed the
+        fields since the last call)."""
+        if int(nsteps) <= 0:
+            return
+        self.finish(self.start(STAGE_INPUT[0]))
+        for _ in range(int(nsteps)):
+            for stage in range(6):
+                self.block.run_stage(stage, _lib.REGION_FIRST)
+                reqs = self.start(STAGE_OUTPUT[stage])
+                self.block.run_stage(stage, _lib.REGION_SECOND)
+                self.finish(reqs)
+            self.block.end_step()
+
+    def step_unpipelined(self, nsteps=1):
+        """The plain schedule: per stage exchange the input's traces || interior, then the shell."""
         for _ in range(int(nsteps)):
             for stage in range(6):
                 reqs = self.start(STAGE_INPUT[stage])

@@ -121,7 +121,7 @@ class FakeBlock(object):
     def run_stage(self, stage, region):
         from seigen_amd.parallel import STAGE_INPUT
         self.stages.append((stage, region))
-        if region != self.lib.REGION_BOUNDARY:
+        if region not in (self.lib.REGION_BOUNDARY, self.lib.REGION_FIRST):   # the launches that read the halo
             return
         field = STAGE_INPUT[stage]
         for side in range(2 * self.dim):
@@ -167,11 +167,17 @@ def _worker(rank, world, port, dim, n, degree, grid):
         ex.step(2)
         nsides = len(ex.sides)
         assert nsides == sum(1 for s in range(2 * dim) if part.neighbour(s) is not None) and nsides > 0
-        # per step: 6 stages x (interior, boundary) + end
+        # per step: 6 stages x (first, second) + end; the halo is checked in every FIRST launch
         assert len(blk.stages) == 2 * 13
+        assert blk.stages[0] == (_lib.STAGE_UH1, _lib.REGION_FIRST)
+        assert blk.stages[1] == (_lib.STAGE_UH1, _lib.REGION_SECOND)
+        assert blk.checked > 0
+        # the plain schedule (interior, then the shell) drives the same block interface
+        checked, blk.stages = blk.checked, []
+        ex.step_unpipelined(1)
         assert blk.stages[0] == (_lib.STAGE_UH1, _lib.REGION_INTERIOR)
         assert blk.stages[1] == (_lib.STAGE_UH1, _lib.REGION_BOUNDARY)
-        assert blk.checked > 0
+        assert len(blk.stages) == 13 and blk.checked > checked
         # global DoF count through allreduce_sum (helpers.get_dofs)
         from seigen_amd.helpers import get_dofs
         S, U = get_dofs(mesh, degree)

@@ -127,28 +127,41 @@ class _LocalExchange(object):
             self.send.append(snd)
             self.recv.append(rcv)
 
-    def step(self, nsteps):
-        from seigen_amd.parallel import STAGE_INPUT
+    def _exchange(self, field):
         lib = self.lib
+        kind = "s" if field in (lib.FIELD_S, lib.FIELD_SH) else "u"
+        for r, (b, p) in enumerate(zip(self.blocks, self.parts)):
+            for s in range(2 * p.dim):
+                if p.neighbour(s) is not None:
+                    b.halo_pack(field, s, self.send[r][(kind, s)].data_ptr())
+        for b in self.blocks:
+            b.sync()
+        for r, p in enumerate(self.parts):
+            for s in range(2 * p.dim):
+                nb = p.neighbour(s)
+                if nb is not None:
+                    self.recv[r][(kind, s)].copy_(self.send[nb][(kind, s ^ 1)])
+        self.torch.cuda.synchronize()
+
+    def step(self, nsteps, pipelined=True):
+        from seigen_amd.parallel import STAGE_INPUT, STAGE_OUTPUT
+        lib = self.lib
+        if pipelined:
+            self._exchange(STAGE_INPUT[0])
         for _ in range(nsteps):
             for stage in range(6):
-                field = STAGE_INPUT[stage]
-                kind = "s" if field in (lib.FIELD_S, lib.FIELD_SH) else "u"
-                for r, (b, p) in enumerate(zip(self.blocks, self.parts)):
-                    for s in range(2 * p.dim):
-                        if p.neighbour(s) is not None:
-                            b.halo_pack(field, s, self.send[r][(kind, s)].data_ptr())
-                    b.run_stage(stage, lib.REGION_INTERIOR)
-                for b in self.blocks:
-                    b.sync()
-                for r, p in enumerate(self.parts):
-                    for s in range(2 * p.dim):
-                        nb = p.neighbour(s)
-                        if nb is not None:
-                            self.recv[r][(kind, s)].copy_(self.send[nb][(kind, s ^ 1)])
-                self.torch.cuda.synchronize()
-                for b in self.blocks:
-                    b.run_stage(stage, lib.REGION_BOUNDARY)
+                if pipelined:      # HaloExchanger.step: FIRST, traces of the output, SECOND
+                    for b in self.blocks:
+                        b.run_stage(stage, lib.REGION_FIRST)
+                    self._exchange(STAGE_OUTPUT[stage])
+                    for b in self.blocks:
+                        b.run_stage(stage, lib.REGION_SECOND)
+                else:              # HaloExchanger.step_unpipelined: traces of the input, interior, shell
+                    for b in self.blocks:
+                        b.run_stage(stage, lib.REGION_INTERIOR)
+                    self._exchange(STAGE_INPUT[stage])
+                    for b in self.blocks:
+                        b.run_stage(stage, lib.REGION_BOUNDARY)
                 for b in self.blocks:
                     b.sync()
             for b in self.blocks:
@@ -163,7 +176,8 @@ class _LocalExchange(object):
     (3, 4, (2, 4, 4), (1, 2, 2)),
     (3, 3, (4, 3, 2), (2, 1, 1)),
 ])
-def test_multiblock_equals_single_block(gpu, dim, degree, n, grid):
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -213,7 +227,7 @@ def test_multiblock_equals_single_block(gpu, dim, degree, n, grid):
         b.set_field(_lib.FIELD_S, s0[sel])
         blocks.append(b)
     ex = _LocalExchange(blocks, parts)
-    ex.step(3)
+    ex.step(3, pipelined)
     for b, p in zip(blocks, parts):
         sel = cells_of(p)
         assert np.array_equal(b.get_field(_lib.FIELD_U), uref[sel]), "velocity differs from the single-block run"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Cost of the multi-GPU launch structure on ONE device (no transport): a 64^3 P4 block that
-pretends to have neighbours on some sides runs every stage as pack + INTERIOR + BOUNDARY launches,
-compared with the single REGION_ALL launch.  Tells how much of the scaling loss is launch
+pretends to have neighbours on some sides runs every stage as FIRST + pack + SECOND launches (the
+pipelined exchange of seigen_amd/parallel.py; --unpipelined: pack + INTERIOR + BOUNDARY), compared
+with the single REGION_ALL launch.  Tells how much of the scaling loss is launch
 structure rather than RCCL."""
 import os
 import sys
@@ -14,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from seigen_amd import _lib  # noqa: E402
 from seigen_amd.backend import HipBlock  # noqa: E402
-from seigen_amd.parallel import STAGE_INPUT  # noqa: E402
+from seigen_amd.parallel import STAGE_INPUT, STAGE_OUTPUT  # noqa: E402
+
+PIPELINED = "--unpipelined" not in sys.argv
 
 
 def run(mask, n=(64, 64, 64), degree=4, steps=10):
@@ -38,6 +41,14 @@ def run(mask, n=(64, 64, 64), degree=4, steps=10):
         for stage in range(6):
             if not sides:
                 blk.run_stage(stage, _lib.REGION_ALL)
+                continue
+            if PIPELINED:      # HaloExchanger.step
+                field = STAGE_OUTPUT[stage]
+                kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+                blk.run_stage(stage, _lib.REGION_FIRST)
+                for s in sides:
+                    blk.halo_pack(field, s, bufs[(kind, s)][0].data_ptr())
+                blk.run_stage(stage, _lib.REGION_SECOND)
                 continue
             field = STAGE_INPUT[stage]
             kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
@@ -82,6 +93,18 @@ def breakdown(mask, n=(64, 64, 64), degree=4, steps=5):
             kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record(stream)
+            if PIPELINED:     # "interior" = FIRST, "shell" = SECOND in the printed line
+                fo = STAGE_OUTPUT[stage]
+                ko = "s" if fo in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
+                blk.run_stage(stage, _lib.REGION_FIRST)
+                ev[1].record(stream)
+                for s in sides:
+                    blk.halo_pack(fo, s, bufs[(ko, s)][0].data_ptr())
+                ev[2].record(stream)
+                blk.run_stage(stage, _lib.REGION_SECOND)
+                ev[3].record(stream)
+                marks.append([ev[1], ev[2], ev[0], ev[1], ev[2], ev[3]])
+                continue
             for s in sides:
                 blk.halo_pack(field, s, bufs[(kind, s)][0].data_ptr())
             ev[1].record(stream)
@@ -89,14 +112,14 @@ def breakdown(mask, n=(64, 64, 64), degree=4, steps=5):
             ev[2].record(stream)
             blk.run_stage(stage, _lib.REGION_BOUNDARY)
             ev[3].record(stream)
-            marks.append(ev)
+            marks.append([ev[0], ev[1], ev[1], ev[2], ev[2], ev[3]])
         blk.end_step()
         blk.sync()
         if it:
             for ev in marks:
                 tot["pack"] += ev[0].elapsed_time(ev[1])
-                tot["interior"] += ev[1].elapsed_time(ev[2])
-                tot["shell"] += ev[2].elapsed_time(ev[3])
+                tot["interior"] += ev[2].elapsed_time(ev[3])
+                tot["shell"] += ev[4].elapsed_time(ev[5])
     return {k: v / steps for k, v in tot.items()}
 
 
@@ -104,7 +127,8 @@ if __name__ == "__main__":
     if "--breakdown" in sys.argv:
         for name, mask in (("z- and z+", 0b110000), ("y+, z-, z+", 0b111000)):
             b = breakdown(mask)
-            print("%-28s packs %.3f  interior %.3f  shell %.3f ms/step" % (name, b["pack"], b["interior"], b["shell"]))
+            print("%-28s packs %.3f  %s %.3f  %s %.3f ms/step" % (name, b["pack"], "first" if PIPELINED else "interior",
+                                                                  b["interior"], "second" if PIPELINED else "shell", b["shell"]))
         sys.exit(0)
     for name, mask in (("no neighbours (REGION_ALL)", 0), ("z- and z+", 0b110000), ("y+, z-, z+", 0b111000),
                        ("x+, y+, z+", 0b101010)):
