@@ -210,13 +210,43 @@ __device__ __forceinline__ ItemRange item_range(long nitems, int wave, int sprea
   return r;
 }
 
+// Operator tiles and mesh tables into LDS, once per block.  All of a thread's loads are issued
+// before the first one is consumed (a plain copy loop compiles to load / wait / write per element:
+// 33 dependent L2 round trips, about 20 us of every launch).
+template <int N>
+__device__ __forceinline__ void copy_to_lds(double* dst, const double* __restrict__ src) {
+  constexpr int PER = (N + 255) / 256;
+  double v[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = threadIdx.x + j * 256;
+    v[j] = (i < N) ? src[i] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < N) dst[i] = v[j];
+  }
+}
+
 template <int NV, int NL>
 __device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* sMd, const StageArgs& A) {
-  for (int i = threadIdx.x; i < NV * 64; i += 256) sAV[i] = A.fragV[i];
-  for (int i = threadIdx.x; i < NL * 64; i += 256) sAL[i] = A.fragL[i];
   const int* src = reinterpret_cast<const int*>(A.md);
   int* dst = reinterpret_cast<int*>(sMd);
-  for (int i = threadIdx.x; i < (int)(sizeof(MeshDev) / sizeof(int)); i += 256) dst[i] = src[i];
+  constexpr int NI = (int)(sizeof(MeshDev) / sizeof(int)), PERI = (NI + 255) / 256;
+  int w[PERI];
+#pragma unroll
+  for (int j = 0; j < PERI; ++j) {
+    const int i = threadIdx.x + j * 256;
+    w[j] = (i < NI) ? src[i] : 0;
+  }
+  copy_to_lds<NV * 64>(sAV, A.fragV);
+  copy_to_lds<NL * 64>(sAL, A.fragL);
+#pragma unroll
+  for (int j = 0; j < PERI; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < NI) dst[i] = w[j];
+  }
   __syncthreads();
 }
 
