@@ -172,6 +172,8 @@ int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes);
 int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out);
 /* register the DEVICE buffer holding the neighbour block's packed traces of
  * `field` for `side`; read by the next stages that consume `field`. */
+/* the same for several sides in ONE launch: dev_out[side] = send buffer of that side or NULL, 6 entries */
+int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out);
 int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in);
 
 /* ---- instrumentation --------------------------------------------------------------- */

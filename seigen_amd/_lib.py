@@ -58,6 +58,7 @@ SYMBOLS = {
     "sg_apply_G": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "sg_halo_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "sg_halo_pack": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "sg_halo_pack_sides": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "sg_halo_attach": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sg_enable_timing": (C.c_int, [_P, C.c_int]),
     "sg_get_counters": (C.c_int, [_P, C.POINTER(SgCounters)]),

@@ -157,5 +157,10 @@ class HipBlock(object):
     def halo_pack(self, field, side, dev_ptr):
         check(self.lib.sg_halo_pack(self.h, field, side, C.c_void_p(dev_ptr)), self.h)
 
+    def halo_pack_sides(self, field, ptrs):
+        """ptrs: {side: device pointer}; every listed side in one launch."""
+        arr = (C.c_void_p * 6)(*[C.c_void_p(ptrs.get(s)) if ptrs.get(s) else None for s in range(6)])
+        check(self.lib.sg_halo_pack_sides(self.h, int(field), arr), self.h)
+
     def halo_attach(self, field, side, dev_ptr):
         check(self.lib.sg_halo_attach(self.h, field, side, C.c_void_p(dev_ptr)), self.h)

@@ -1005,7 +1005,27 @@ int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   const int d = h->cfg.dim;
   int comps = field_is_stress(field) ? d * d : d;
-  int rc = launch_pack(d, h->cfg.degree, h->md_dev, h->md, h->field[field], comps, side, (double*)dev_out,
+  double* out = (double*)dev_out;
+  int rc = launch_pack(h->md_dev, h->md, h->field[field], comps, 1, &side, &out,
+                       (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
+  if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
+  return SG_OK;
+}
+
+int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out) {
+  if (!h || !dev_out || field < 0 || field > 3) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  const int d = h->cfg.dim;
+  int comps = field_is_stress(field) ? d * d : d;
+  int sides[6], n = 0;
+  double* outs[6];
+  for (int s = 0; s < 2 * d; ++s)
+    if (dev_out[s]) {
+      sides[n] = s;
+      outs[n] = (double*)dev_out[s];
+      n += 1;
+    }
+  int rc = launch_pack(h->md_dev, h->md, h->field[field], comps, n, sides, outs,
                        (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
   return SG_OK;

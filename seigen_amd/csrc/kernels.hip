@@ -325,67 +325,83 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
 }
 
 // ---- halo pack ------------------------------------------------------------------------
-__global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, int side, long nslots, double* out,
-                            int sym) {
-  const int nd = md->nd, nf = md->nf, ncls = md->ncls, nfaces = md->nfaces, hpc = md->halo_per_cube;
+// one element (slot, facet node, component) of the packed traces of block side `side`
+__device__ __forceinline__ void pack_one(const MeshDev* md, const double* field, int ncomp, int side, long idx, double* out,
+                                         int sym) {
+  const int nd = md->nd, nf = md->nf, ncls = md->ncls, hpc = md->halo_per_cube;
   const int axis = side >> 1, hi = side & 1;
-  long total = nslots * nf * ncomp;
+  int cpt = (int)(idx % ncomp);
+  long t = idx / ncomp;
+  int b = (int)(t % nf);
+  long slot = t / nf;
+  int ord = (int)(slot % hpc);
+  long c2 = slot / hpc;
+  // boundary cube from its 2-D index
+  int c[3] = {0, 0, 0};
+  int n0 = md->n[0], n1 = md->n[1];
+  if (axis == 0) {
+    c[1] = (int)(c2 % n1);
+    c[2] = (int)(c2 / n1);
+  } else if (axis == 1) {
+    c[0] = (int)(c2 % n0);
+    c[2] = (int)(c2 / n0);
+  } else {
+    c[0] = (int)(c2 % n0);
+    c[1] = (int)(c2 / n0);
+  }
+  c[axis] = hi ? md->n[axis] - 1 : 0;
+  long cube = c[0] + (long)n0 * (c[1] + (long)n1 * c[2]);
+  // the (class, facet) with this ordinal on this side
+  const int cls = md->side_cls[side][ord], f = md->side_face[side][ord];
+  const int gw = md->gw;
+  int cs = cpt;
+  if (sym) {  // symmetric-mode stress field: the (i > j) lines are stale, read the mirror
+    const int d = md->dim, i = cpt / d, j = cpt % d;
+    if (i > j) cs = j * d + i;
+  }
+  long off = ((((cube / gw) * ncls + cls) * (long)nd + md->fnode[f][b]) * ncomp + cs) * gw + cube % gw;
+  out[idx] = field[off];
+}
+
+struct PackArgs {
+  int nside;
+  int side[6];
+  double* out[6];
+  long start[7];  // element ranges of the sides within the launch
+};
+
+// all sides of a block in one launch (one small launch per side costs more in gaps than in work)
+__global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, PackArgs P, int sym) {
+  const long total = P.start[P.nside];
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    int cpt = (int)(idx % ncomp);
-    long t = idx / ncomp;
-    int b = (int)(t % nf);
-    long slot = t / nf;
-    int ord = (int)(slot % hpc);
-    long c2 = slot / hpc;
-    // boundary cube from its 2-D index
-    int c[3] = {0, 0, 0};
-    int n0 = md->n[0], n1 = md->n[1];
-    if (axis == 0) {
-      c[1] = (int)(c2 % n1);
-      c[2] = (int)(c2 / n1);
-    } else if (axis == 1) {
-      c[0] = (int)(c2 % n0);
-      c[2] = (int)(c2 / n0);
-    } else {
-      c[0] = (int)(c2 % n0);
-      c[1] = (int)(c2 / n0);
-    }
-    c[axis] = hi ? md->n[axis] - 1 : 0;
-    long cube = c[0] + (long)n0 * (c[1] + (long)n1 * c[2]);
-    // the (class, facet) with this ordinal on this side
-    int cls = -1, f = -1;
-    for (int k = 0; k < ncls; ++k)
-      for (int ff = 0; ff < nfaces; ++ff)
-        if (md->nb_axis[k][ff] == axis && (md->nb_dir[k][ff] > 0) == (hi != 0) && md->face_ord[k][ff] == ord) {
-          cls = k;
-          f = ff;
-        }
-    const int gw = md->gw;
-    int cs = cpt;
-    if (sym) {  // symmetric-mode stress field: the (i > j) lines are stale, read the mirror
-      const int d = md->dim, i = cpt / d, j = cpt % d;
-      if (i > j) cs = j * d + i;
-    }
-    long off = ((((cube / gw) * ncls + cls) * (long)nd + md->fnode[f][b]) * ncomp + cs) * gw + cube % gw;
-    out[idx] = field[off];
+    int s = 0;
+    while (s + 1 < P.nside && idx >= P.start[s + 1]) ++s;
+    pack_one(md, field, ncomp, P.side[s], idx - P.start[s], P.out[s], sym);
   }
 }
 
-int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& mh, const double* field, int ncomp, int side,
-                double* out, int sym, void* stream) {
-  (void)dim;
-  (void)P;
-  int axis = side >> 1;
-  long n2 = 1;
-  for (int a = 0; a < 3; ++a)
-    if (a != axis) n2 *= mh.n[a];
-  long nslots = n2 * mh.halo_per_cube;
-  long total = nslots * mh.nf * ncomp;
+int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const double* field, int ncomp, int nside, const int* sides,
+                double* const* outs, int sym, void* stream) {
+  PackArgs P;
+  P.nside = 0;
+  P.start[0] = 0;
+  for (int i = 0; i < nside && P.nside < 6; ++i) {
+    const int axis = sides[i] >> 1;
+    long n2 = 1;
+    for (int a = 0; a < 3; ++a)
+      if (a != axis) n2 *= mh.n[a];
+    const long total = n2 * mh.halo_per_cube * mh.nf * ncomp;
+    if (total <= 0 || !outs[i]) continue;
+    P.side[P.nside] = sides[i];
+    P.out[P.nside] = outs[i];
+    P.start[P.nside + 1] = P.start[P.nside] + total;
+    P.nside += 1;
+  }
+  const long total = P.start[P.nside];
   if (total <= 0) return 0;
   long grid = (total + 255) / 256;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, field, ncomp, side,
-                     nslots, out, sym);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, field, ncomp, P, sym);
   return (int)hipGetLastError();
 }
 

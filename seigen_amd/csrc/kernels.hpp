@@ -60,10 +60,10 @@ int launch_layout(const MeshDev& md_host, int ncomp, int dir, double* field, dou
 // copy the upper triangle over the lower one in a whole stress field (leaving symmetric mode)
 int launch_mirror(const MeshDev& md_host, double* field, void* stream);
 
-// facet traces of a field on one block side -> packed device buffer
+// facet traces of a field on `nside` block sides -> one packed device buffer per side, one launch
 // (sym = 1: a stress field stored in symmetric mode; lower-triangle values come from their mirrors)
-int launch_pack(int dim, int P, const MeshDev* md_dev, const MeshDev& md_host, const double* field, int ncomp, int side,
-                double* out, int sym, void* stream);
+int launch_pack(const MeshDev* md_dev, const MeshDev& md_host, const double* field, int ncomp, int nside,
+                const int* sides, double* const* outs, int sym, void* stream);
 
 // field[off[k] + c*gw] += coef * values[k][c] at the sparse source nodes (off = device offset of comp 0)
 int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,

@@ -172,6 +172,10 @@ void build_mesh_tables(int dim, int P, int diagonal, const double h[3], const in
       if (!found) throw std::runtime_error("facet neighbour not found");
       if (md.nb_axis[c][f] >= 0) {
         int side = 2 * md.nb_axis[c][f] + (md.nb_dir[c][f] > 0 ? 1 : 0);
+        if (ord_count[side] < 2) {
+          md.side_cls[side][ord_count[side]] = (int8_t)c;
+          md.side_face[side][ord_count[side]] = (int8_t)f;
+        }
         md.face_ord[c][f] = ord_count[side]++;
       } else {
         md.face_ord[c][f] = -1;

@@ -37,6 +37,7 @@ struct MeshDev {
   int32_t nb_cls[MAX_CLS][MAX_FACES];   // neighbour's class
   int32_t nb_face[MAX_CLS][MAX_FACES];  // neighbour's local facet
   int32_t face_ord[MAX_CLS][MAX_FACES]; // ordinal of this facet among the cube's facets on that side
+  int8_t side_cls[6][2], side_face[6][2]; // inverse: the (class, facet) with ordinal o on cube side s
   uint8_t nb_node[MAX_CLS][MAX_FACES][MAX_NF + 1];  // neighbour ELEMENT node matching my facet node b
   uint8_t nb_fnode[MAX_CLS][MAX_FACES][MAX_NF + 1]; // same, as position in the neighbour's facet list
   uint8_t fnode[MAX_FACES][MAX_NF + 1];             // my element node of facet node b

@@ -104,9 +104,12 @@ class HaloExchanger(object):
     def start(self, field):
         """Pack the block-side traces of `field` and post the sends / receives."""
         kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
-        for s in self.sides:
-            self.block.halo_pack(field, s, self.send[(kind, s)].data_ptr())
-            self.bytes_sent += self.send[(kind, s)].numel() * 8
+        if hasattr(self.block, "halo_pack_sides"):      # all sides in one launch
+            self.block.halo_pack_sides(field, {s: self.send[(kind, s)].data_ptr() for s in self.sides})
+        else:
+            for s in self.sides:
+                self.block.halo_pack(field, s, self.send[(kind, s)].data_ptr())
+        self.bytes_sent += sum(self.send[(kind, s)].numel() * 8 for s in self.sides)
         if not self.sides:
             return (kind, [])
         wire_out, wire_in = (self.hsend, self.hrecv) if self.staged else (self.send, self.recv)

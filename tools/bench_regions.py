@@ -46,8 +46,7 @@ def run(mask, n=(64, 64, 64), degree=4, steps=10):
                 field = STAGE_OUTPUT[stage]
                 kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
                 blk.run_stage(stage, _lib.REGION_FIRST)
-                for s in sides:
-                    blk.halo_pack(field, s, bufs[(kind, s)][0].data_ptr())
+                blk.halo_pack_sides(field, {s: bufs[(kind, s)][0].data_ptr() for s in sides})
                 blk.run_stage(stage, _lib.REGION_SECOND)
                 continue
             field = STAGE_INPUT[stage]
@@ -98,8 +97,7 @@ def breakdown(mask, n=(64, 64, 64), degree=4, steps=5):
                 ko = "s" if fo in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
                 blk.run_stage(stage, _lib.REGION_FIRST)
                 ev[1].record(stream)
-                for s in sides:
-                    blk.halo_pack(fo, s, bufs[(ko, s)][0].data_ptr())
+                blk.halo_pack_sides(fo, {s: bufs[(ko, s)][0].data_ptr() for s in sides})
                 ev[2].record(stream)
                 blk.run_stage(stage, _lib.REGION_SECOND)
                 ev[3].record(stream)
