@@ -236,3 +236,39 @@ def test_every_kernel_family(gpu, monkeypatch, path, dim, degree, n, L, diagonal
     orc.step(2 * orc.dt)
     assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+
+
+def test_error_behaviour(gpu):
+    """Every entry point returns a negative code with a message instead of launching on bad input
+    (the reference raises Python exceptions: seigen/elastic.py:64, :234-242)."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    blk = HipBlock(3, 4, (4, 2, 2), (0.25, 0.5, 0.5), (0.0, 0.0, 0.0))
+    with pytest.raises(_lib.SeigenHipError, match="sg_set_params"):
+        blk.step(1)                                           # parameters not set
+    blk.set_params(1.0, 1e-3, 0.5, 0.25)
+    with pytest.raises(ValueError):
+        blk.set_field(_lib.FIELD_U, np.zeros((3, 35, 3)))     # wrong size, caught by the host layer
+    small = np.zeros((3, 35, 3))
+    assert blk.lib.sg_set_field(blk.h, _lib.FIELD_U, small.ctypes.data, small.nbytes) < 0    # and by the library
+    assert b"" != blk.lib.sg_last_error(blk.h)
+    assert blk.lib.sg_set_field_range(blk.h, _lib.FIELD_U, 90, 10, small.ctypes.data, small.nbytes) < 0   # past the end
+    with pytest.raises(_lib.SeigenHipError):
+        blk.run_stage(7)                                      # unknown stage
+    with pytest.raises(_lib.SeigenHipError):
+        blk.run_stage(0, 9)                                   # unknown region
+    with pytest.raises(_lib.SeigenHipError):
+        blk.apply_F(_lib.FIELD_U, _lib.FIELD_U, _lib.FIELD_UH)   # s_in must be a stress field
+    with pytest.raises(_lib.SeigenHipError):
+        blk.set_source([10 ** 9], np.zeros((1, 1, 3, 3)))     # node index out of range
+    blk.step(1)                                               # still usable afterwards
+    assert np.isfinite(blk.get_field(_lib.FIELD_U)).all()
+    # a block with halo neighbours refuses to run without attached halo buffers, and sg_step on it
+    nb = HipBlock(3, 4, (4, 2, 2), (0.25, 0.5, 0.5), (0.0, 0.0, 0.0), "left", 0b100000)
+    nb.set_params(1.0, 1e-3, 0.5, 0.25)
+    with pytest.raises(_lib.SeigenHipError, match="neighbours"):
+        nb.step(1)
+    with pytest.raises(_lib.SeigenHipError, match="halo"):
+        nb.run_stage(0, _lib.REGION_FIRST)
+    with pytest.raises(_lib.SeigenHipError):
+        HipBlock(3, 7, (2, 2, 2), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0))   # unsupported degree
