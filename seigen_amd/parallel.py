@@ -99,6 +99,10 @@ class HaloExchanger(object):
             kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
             for s in self.sides:
                 block.halo_attach(field, s, self.recv[(kind, s)].data_ptr())
+        if on_gpu:
+            # the zero fills above ran on torch's current stream, the block's kernels run on its own
+            # (non-blocking) stream: make sure no fill can land after the first pack
+            torch.cuda.synchronize(device)
         self.bytes_sent = 0
 
     def start(self, field):
