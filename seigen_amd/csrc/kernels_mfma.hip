@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       auto orow = [&](int m) { return (m == S4 - 1) ? ob_l : ob_q + (long)m * 4 * 9 * 16; };
       if constexpr (SYM || MODE == 0) {
         constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-        constexpr int PDE = 2;           // row-quads of old values in flight (MODE 1)
+#ifndef SG_PDE
+#define SG_PDE 4
+#endif
+        constexpr int PDE = SG_PDE;      // row-quads of old values in flight (MODE 1)
         double po[PDE][6], pa[PDE][6];
         auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
         auto fetch_old = [&](int m) {
@@ -773,37 +776,47 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345).
     //      All loads first (results built in place in the accumulators), all stores last: see G.
     if (MODE == 1) {
+      // every old value of the item is requested before the first one is used: one memory latency
+      // per item instead of one per row tile (the lifts' registers are free by now)
+      double po[MTF][4][3], pa[MTF][4][3], pos[NSM][3], pas[NSM][3];
 #pragma unroll
-      for (int t = 0; t < MTF; ++t) {
-        double po[4][3], pa[4][3];
+      for (int t = 0; t < MTF; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            po[reg][i] = LD_STREAM(&out[o + i * 16]);
-            pa[reg][i] = LD_STREAM(&aux[o + i * 16]);
+            po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
+            pa[t][reg][i] = LD_STREAM(&aux[o + i * 16]);
           }
         }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            double v = A.c_self * po[reg][i] + A.c_aux * pa[reg][i] + A.c_new * acc[i][t][reg];
-            asm volatile("" : "+v"(v));
-            acc[i][t][reg] = v;
-          }
-      }
 #pragma unroll
       for (int t = 0; t < NSM; ++t) {
         const int a = 16 * MTF + 4 * t + q;
         const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          accs[i][t] = A.c_self * LD_STREAM(&out[o + i * 16]) + A.c_aux * LD_STREAM(&aux[o + i * 16]) + A.c_new * accs[i][t];
-          asm volatile("" : "+v"(accs[i][t]));
+          pos[t][i] = LD_STREAM(&out[o + i * 16]);
+          pas[t][i] = LD_STREAM(&aux[o + i * 16]);
         }
       }
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            double v = A.c_self * po[t][reg][i] + A.c_aux * pa[t][reg][i] + A.c_new * acc[i][t][reg];
+            asm volatile("" : "+v"(v));
+            acc[i][t][reg] = v;
+          }
+#pragma unroll
+      for (int t = 0; t < NSM; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          accs[i][t] = A.c_self * pos[t][i] + A.c_aux * pas[t][i] + A.c_new * accs[i][t];
+          asm volatile("" : "+v"(accs[i][t]));
+        }
     }
     if (L.active) {
 #pragma unroll
