@@ -44,6 +44,7 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream);
 
 // MFMA path (3-D, degree >= 3; fields in the gw = 16 interleaved layout)
 bool mfma_supported(int dim, int P);
+int mfma_blocks_per_cu(int P);
 int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream);
 
 // lane-per-cell path (1-D / 2-D; fields in the gw = 64 interleaved layout; a.Dt = E[r][a][b],

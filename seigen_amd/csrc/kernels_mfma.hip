@@ -34,6 +34,7 @@ struct MG {
   static constexpr int MTF = ND / 16;                // full 16-row tiles over the nodes
   static constexpr int NSM = (ND % 16 + 3) / 4;      // 4-row tiles (4x4x4 MFMA) over the remaining rows
   static constexpr int MTT = MTF + NSM;
+  static constexpr int MTFA = MTF > 0 ? MTF : 1;     // array extent (degrees 1 and 2 have no full tile)
   static constexpr int S4 = (ND + 3) / 4;
   static constexpr int NFRAG_F = MTT * 3 * KS;
   static constexpr int NFRAG_G = 3 * MTT * KS;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         for (int i = 0; i < 3; ++i) bq[s][i] = brow(s % KS)[i * 16];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        d4 acc[MTF][3];
+        d4 acc[M::MTFA][3];
         double accs[NSM][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       for (int j = 0; j < 3; ++j) cnf[f][j] = md->cn[k][f][j];
 
     // rows 16t + 4reg + q in acc[i][t][reg] (large tiles), row 16*MTF + 4s + q in accs[i][s] (small)
-    d4 acc[3][MTF];
+    d4 acc[3][M::MTFA];
     double accs[3][NSM];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     if (MODE == 1) {
       // every old value of the item is requested before the first one is used: one memory latency
       // per item instead of one per row tile (the lifts' registers are free by now)
-      double po[MTF][4][3], pa[MTF][4][3], pos[NSM][3], pas[NSM][3];
+      double po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[NSM][3], pas[NSM][3];
 #pragma unroll
       for (int t = 0; t < MTF; ++t)
 #pragma unroll
@@ -866,11 +867,18 @@ static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
   return a.sym ? launch_ps<P, 1>(kind, a, s) : launch_ps<P, 0>(kind, a, s);
 }
 
-bool mfma_supported(int dim, int P) { return dim == 3 && (P == 3 || P == 4); }
+bool mfma_supported(int dim, int P) { return dim == 3 && P >= 1 && P <= 4; }
+
+// resident blocks per CU the persistent grid is sized for: registers and LDS allow exactly two at
+// degrees 3 and 4 (a third block at degree 3 measured slower); the low orders are memory-bound and
+// light (64 / 166 VGPRs, 12 / 28 KB of tiles) and want more waves in flight
+int mfma_blocks_per_cu(int P) { return P == 1 ? 4 : (P == 2 ? 3 : 2); }
 
 int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   switch (P) {
+    case 1: return launch_p<1>(kind, a, s);
+    case 2: return launch_p<2>(kind, a, s);
     case 3: return launch_p<3>(kind, a, s);
     case 4: return launch_p<4>(kind, a, s);
   }

@@ -29,8 +29,17 @@ def ms_per_step(path, dim, degree, n, steps=40):
 
 if __name__ == "__main__":
     cases = [(2, p, (m, m)) for p in (1, 2, 3, 4) for m in (128, 192, 256, 384, 512)]
-    cases += [(3, p, (m, m, m)) for p in (1, 2) for m in (16, 24, 32, 48)]
+    if "--3d" in sys.argv:
+        cases = []
+    cases += [(3, p, (m, m, m)) for p in (1, 2) for m in (4, 8, 16, 24, 32, 48)]
     for dim, p, n in cases:
         g, cells = ms_per_step("generic", dim, p, n)
         l, _ = ms_per_step("lane", dim, p, n)
-        print("dim %d P%d n=%-4d cells %8d: generic %.4f ms, lane %.4f ms  -> %s" % (dim, p, n[0], cells, g, l, "lane" if l < g else "generic"))
+        line = "dim %d P%d n=%-4d cells %8d: generic %.4f ms, lane %.4f ms" % (dim, p, n[0], cells, g, l)
+        best = "lane" if l < g else "generic"
+        if dim == 3:
+            m, _ = ms_per_step("mfma", dim, p, n)
+            line += ", mfma %.4f ms" % m
+            if m < min(g, l):
+                best = "mfma"
+        print(line + "  -> " + best)
