@@ -210,7 +210,7 @@ def main():
     ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
     nl = [c1["launches"][i] - c0["launches"][i] for i in range(6)]
     words = [d * d + d, d + d * d, d * d + 3 * d, d + d * d, d * d + d, 3 * d * d + d]   # per node per launch
-    mfma = os.environ.get("SEIGEN_HIP_PATH", "") not in ("generic", "lane") and (P >= 2 or blk.ncells >= 196608)
+    mfma = os.environ.get("SEIGEN_HIP_PATH", "") not in ("generic", "lane") and (P >= 2 or blk.ncells >= 65536)
     if mfma:
         sym = 0 if os.environ.get("SEIGEN_HIP_SYM", "") == "0" else 1     # symmetric-stress mode (default)
         names = (("sg::mfma_stage_F<%d, 0, %d>" % (P, sym), (0, 4)), ("sg::mfma_stage_F<%d, 1, %d>" % (P, sym), (2,)),

@@ -181,12 +181,12 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   const bool force_generic = path_env && std::strcmp(path_env, "generic") == 0;
   // 3-D: the MFMA kernels at every degree (degrees 1 and 2 use 4x4x4 tiles only); measured with
   // tools/path_sweep.py they beat the lane and generic kernels everywhere except degree 1 on blocks
-  // under 196608 cells (SEIGEN_HIP_PATH=mfma forces them)
+  // under 65536 cells (SEIGEN_HIP_PATH=mfma forces them)
   const bool force_mfma = path_env && std::strcmp(path_env, "mfma") == 0;
   const int64_t ncells_all = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2] * h->ncls;
   h->use_mfma = mfma_supported(cfg->dim, cfg->degree) && !force_generic &&
                 !(path_env && std::strcmp(path_env, "lane") == 0) &&
-                (cfg->degree >= 2 || ncells_all >= 196608 || force_mfma);
+                (cfg->degree >= 2 || ncells_all >= 65536 || force_mfma);
   // lane-per-cell kernels need enough 64-cell groups to fill the chip; below that the
   // thread-per-node generic kernel has more parallelism (SEIGEN_HIP_PATH=lane forces them)
   const bool force_lane = path_env && std::strcmp(path_env, "lane") == 0;
