@@ -112,6 +112,11 @@ __device__ __forceinline__ void load_tensor(const double* p, int stride, double 
 }
 __device__ __forceinline__ constexpr bool upper(int ij) { return (ij / 3) <= (ij % 3); }
 
+// wave-uniform test on the bits (scalar compare and branch; there is no scalar f64 compare)
+__device__ __forceinline__ bool uniform_nonzero(double c) {
+  return (__builtin_bit_cast(unsigned long long, c) << 1) != 0ull;
+}
+
 struct LaneGeo {
   long c;      // linear cube index of this lane's cell
   int cc[3];   // cube coordinates
@@ -379,30 +384,39 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
             }
           }
         }
-        auto fold = [&](int m, double v0, double v1, double v2) {
-          const double v[3] = {v0, v1, v2};
+        // W_ik += Jm[r][k] (D_r u_i).  On the Kuhn classes J^-1 has five non-zeros out of nine: the
+        // zero columns are skipped with a scalar branch (the class is uniform over the wave)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
+        for (int kk = 0; kk < 3; ++kk) {
+          const double c = Jm[r][kk];
+          if (uniform_nonzero(c)) {
 #pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-              const double wv = Jm[r][kk] * v[i];
-              if (i == kk)
-                Sd[i][m] += wv;
-              else
-                So[i + kk - 1][m] += wv;
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+              for (int t = 0; t < MTF; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                  if (i == kk)
+                    Sd[i][4 * t + reg] += c * acc[t][i][reg];
+                  else
+                    So[i + kk - 1][4 * t + reg] += c * acc[t][i][reg];
+                }
+#pragma unroll
+              for (int t = 0; t < NSM; ++t) {
+                if (i == kk)
+                  Sd[i][4 * MTF + t] += c * accs[t][i];
+                else
+                  So[i + kk - 1][4 * MTF + t] += c * accs[t][i];
+              }
             }
           }
-          // pin the fold here: LLVM otherwise sinks these FMA chains down to the epilogue
-          // (their only use), which keeps every accumulator tile live and spills
+        }
+        // pin the folds here: LLVM otherwise sinks these FMA chains down to the epilogue (their
+        // only use), which keeps every accumulator tile live and spills
+#pragma unroll
+        for (int m = 0; m < S4; ++m)
 #pragma unroll
           for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
-        };
-#pragma unroll
-        for (int t = 0; t < MTF; ++t)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) fold(4 * t + reg, acc[t][0][reg], acc[t][1][reg], acc[t][2][reg]);
-#pragma unroll
-        for (int t = 0; t < NSM; ++t) fold(4 * MTF + t, accs[t][0], accs[t][1], accs[t][2]);
       }
     }
 
@@ -425,21 +439,30 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         for (int t = 0; t < MTT; ++t) {
           // next facet's traces: asked for a whole facet ahead
           if (t == 0 && f + 1 < 4) request(f + 1, nx[(f + 1) & 1]);
-          auto fold = [&](int m, double v0, double v1, double v2) {
-            const double v[3] = {v0, v1, v2};
+          // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
+          auto fold = [&](int m0, int nm, const double (&v)[3][4]) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int kk = 0; kk < 3; ++kk) {
+              const double c = cnf[f][kk];
+              if (uniform_nonzero(c)) {
 #pragma unroll
-              for (int kk = 0; kk < 3; ++kk) {
-                const double wv = cnf[f][kk] * v[i];
-                if (i == kk)
-                  Sd[i][m] += wv;
-                else
-                  So[i + kk - 1][m] += wv;
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    if (j < nm) {
+                      if (i == kk)
+                        Sd[i][m0 + j] += c * v[i][j];
+                      else
+                        So[i + kk - 1][m0 + j] += c * v[i][j];
+                    }
               }
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+            for (int j = 0; j < 4; ++j)
+              if (j < nm) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m0 + j]), "+v"(So[i][m0 + j]));
+              }
           };
           if (t < MTF) {
             d4 tmp[3];
@@ -451,8 +474,14 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
               for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
             }
+            {
+              double v[3][4];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) fold(4 * t + reg, tmp[0][reg], tmp[1][reg], tmp[2][reg]);
+              for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) v[i][reg] = tmp[i][reg];
+              fold(4 * t, 4, v);
+            }
           } else {
             double tmp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -461,7 +490,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
               for (int i = 0; i < 3; ++i) tmp[i] = MFMA4(a, flf[ks][i], tmp[i]);
             }
-            fold(4 * MTF + (t - MTF), tmp[0], tmp[1], tmp[2]);
+            {
+              const double v[3][4] = {{tmp[0], 0, 0, 0}, {tmp[1], 0, 0, 0}, {tmp[2], 0, 0, 0}};
+              fold(4 * MTF + (t - MTF), 1, v);
+            }
           }
         }
       }
