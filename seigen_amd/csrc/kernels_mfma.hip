@@ -128,11 +128,14 @@ __device__ __forceinline__ LaneGeo lane_geo(const MeshDev& md, const StageArgs& 
   LaneGeo L;
   L.c = g * 16 + w;
   L.valid = L.c < md.ncube;
-  long cl = L.valid ? L.c : 0;
-  L.cc[0] = (int)(cl % md.n[0]);
-  long t = cl / md.n[0];
-  L.cc[1] = (int)(t % md.n[1]);
-  L.cc[2] = (int)(t / md.n[1]);
+  // 32-bit arithmetic: a block has far fewer than 2^31 cubes (288 GB hold about 2^24 of them at
+  // degree 1), and the 64-bit divisions this replaces are some hundred instructions each
+  const unsigned cl = L.valid ? (unsigned)L.c : 0u;
+  const unsigned n0 = (unsigned)md.n[0], n1 = (unsigned)md.n[1];
+  const unsigned t = cl / n0, z = t / n1;
+  L.cc[0] = (int)(cl - t * n0);
+  L.cc[1] = (int)(t - z * n1);
+  L.cc[2] = (int)z;
   bool in = false;
   for (int bx = 0; bx < A.nbox; ++bx) {
     bool ib = true;
