@@ -261,6 +261,12 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
       const long sbase = ((g * NCLS + k) * (long)ND) * DIM * DIM * 64 + lane;
       double po[DIM * DIM], pa[DIM * DIM];   // in-place combine operands, one node ahead
+      // Fused stage: loads and stores share one counter and complete out of order with each
+      // other, so a wait for a load with stores in flight waits for every store's acknowledgement
+      // (kernels_mfma.hip).  Where the cell's results fit in registers they are all kept until the
+      // last old value has been read, and stored together at the end.
+      constexpr bool DEFER = (MODE == 1) && (ND * DIM * DIM <= 24);
+      double res[DEFER ? ND : 1][DIM * DIM];
       if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < DIM * DIM; ++c)
@@ -330,11 +336,21 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
               pa[c] = aux[sbase + ((a + 1) * DIM * DIM + c) * 64];
             }
         }
-        if (L.active) {
+        if (DEFER) {
+#pragma unroll
+          for (int c = 0; c < DIM * DIM; ++c) res[DEFER ? a : 0][c] = v[c];
+        } else if (L.active) {
 #pragma unroll
           for (int c = 0; c < DIM * DIM; ++c)
             if (!SYM || (c / DIM) <= (c % DIM)) out[sbase + (a * DIM * DIM + c) * 64] = v[c];
         }
+      }
+      if (DEFER && L.active) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+          for (int c = 0; c < DIM * DIM; ++c)
+            if (!SYM || (c / DIM) <= (c % DIM)) out[sbase + (a * DIM * DIM + c) * 64] = res[DEFER ? a : 0][c];
       }
     }
   }
