@@ -116,35 +116,58 @@ class HaloExchanger(object):
         self.bytes_sent += sum(self.send[(kind, s)].numel() * 8 for s in self.sides)
         if not self.sides:
             return (kind, [])
-        wire_out, wire_in = (self.hsend, self.hrecv) if self.staged else (self.send, self.recv)
         if self.staged:
-            with self.torch.cuda.stream(self.stream):
+            # host-staged: queue the copies out and mark their end; the host waits for that mark and
+            # posts the transfers only in finish(), after the caller has queued the next launch
+            ev = None
+            if self.stream is not None:
+                with self.torch.cuda.stream(self.stream):
+                    for s in self.sides:
+                        self.hsend[(kind, s)].copy_(self.send[(kind, s)], non_blocking=True)
+                    ev = self.torch.cuda.Event()
+                    ev.record(self.stream)
+            else:
                 for s in self.sides:
-                    self.hsend[(kind, s)].copy_(self.send[(kind, s)], non_blocking=True)
-            (self.stream.synchronize if self.stream is not None else self.torch.cuda.synchronize)()
+                    self.hsend[(kind, s)].copy_(self.send[(kind, s)])
+                self.torch.cuda.synchronize()
+            return (kind, ev)
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):   # RCCL orders itself against the CURRENT stream
+                return (kind, self.dist.batch_isend_irecv(self._ops(kind, self.send, self.recv)))
+        return (kind, self.dist.batch_isend_irecv(self._ops(kind, self.send, self.recv)))
+
+    def _ops(self, kind, wire_out, wire_in):
         ops = []
         for s in self.sides:
             peer = self.part.neighbour(s)
             ops.append(self.dist.P2POp(self.dist.isend, wire_out[(kind, s)], peer, self.group))
             ops.append(self.dist.P2POp(self.dist.irecv, wire_in[(kind, s)], peer, self.group))
-        if self.stream is not None and not self.staged:
-            with self.torch.cuda.stream(self.stream):   # RCCL orders itself against the CURRENT stream
-                return (kind, self.dist.batch_isend_irecv(ops))
-        return (kind, self.dist.batch_isend_irecv(ops))
+        return ops
 
     def finish(self, pending):
         kind, reqs = pending
-        if self.stream is not None and not self.staged:
+        if not self.sides:
+            return
+        if self.staged:
+            if reqs is not None:
+                reqs.synchronize()          # the copies out are done (later launches keep running)
+            for r in self.dist.batch_isend_irecv(self._ops(kind, self.hsend, self.hrecv)):
+                r.wait()
+            if self.stream is not None:
+                with self.torch.cuda.stream(self.stream):
+                    for s in self.sides:
+                        self.recv[(kind, s)].copy_(self.hrecv[(kind, s)], non_blocking=True)
+            else:
+                for s in self.sides:
+                    self.recv[(kind, s)].copy_(self.hrecv[(kind, s)])
+            return
+        if self.stream is not None:
             with self.torch.cuda.stream(self.stream):
                 for r in reqs:
                     r.wait()
             return
         for r in reqs:
             r.wait()
-        if self.staged:
-            with self.torch.cuda.stream(self.stream):
-                for s in self.sides:
-                    self.recv[(kind, s)].copy_(self.hrecv[(kind, s)], non_blocking=True)
 
     def step(self, nsteps=1):
         """`nsteps` LF4 steps.  Per stage: FIRST (needs the halo of the stage's input, which the
