@@ -52,6 +52,13 @@ struct MG {
 #define LD_STREAM(p) (*(p))
 #define ST_STREAM(p, v) (*(p) = (v))
 #endif
+// A wave raises its issue priority for its MFMA phases (volume, lifts) and drops it for the epilogue,
+// so that the other wave of the SIMD cannot hold up matrix instructions with its loads and stores
+// (+1 % on the step).
+#ifndef SG_PRIO_HI
+#define SG_PRIO_HI 3
+#endif
+#define SG_PRIO(p) do { if (SG_PRIO_HI) __builtin_amdgcn_s_setprio(p); } while (0)
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 // 4 rows x 16 cells (four 4x4 blocks), same B register as MFMA64; lane l of the result holds
 // row (l >> 4) of cell (l & 15).  About 1/6 of the issue time of MFMA64 (mfma_tables.hpp).
@@ -342,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         for (int i = 0; i < 3; ++i) dst[ks][i] = R.p[(nn * 3 + i) * R.cstride];
       }
     };
+    SG_PRIO(SG_PRIO_HI);
     STAMP(st1);
     // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead.
     //      One pass over the k-steps per reference direction r with all row tiles of D_r live:
@@ -502,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       }
     }
 
+    SG_PRIO(0);
     STAMP(st3);
     // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
     //      vmcnt counts loads and stores together and the two kinds complete out of order with
@@ -669,6 +678,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       for (int t = 0; t < NSM; ++t) accs[i][t] = 0.0;
     }
 
+    SG_PRIO(SG_PRIO_HI);
     STAMP(st1);
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
     {
@@ -765,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       }
     }
 
+    SG_PRIO(0);
     STAMP(st3);
     // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
     // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
