@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
 #ifndef SG_PF
-#define SG_PF 3
+#define SG_PF 4
 #endif
   constexpr int PF = SG_PF;  // B-operand prefetch distance, in k-steps
   __shared__ double sAV[M::NFRAG_G * 64];
