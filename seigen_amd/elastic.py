@@ -116,8 +116,12 @@ class ElasticLF4(object):
 
         if self.output:
             with timed_region('i/o'):
-                self.u_stream = "velocity"
-                self.s_stream = "stress"
+                # File("velocity.pvd") / File("stress.pvd") of the reference (elastic.py:117-124);
+                # SEIGEN_OUTPUT=npy writes raw arrays instead
+                from .vtu import VtuStream
+                rank, nranks = world()
+                self.u_stream = VtuStream("velocity", rank, nranks)
+                self.s_stream = VtuStream("stress", rank, nranks)
 
     # ---- device block ---------------------------------------------------------------------
     def _create_block(self):
@@ -170,15 +174,22 @@ class ElasticLF4(object):
     form_s1 = property(lambda self: ("sh2+s1", _lib.STAGE_S1))
 
     def write(self, u=None, s=None):
-        r"""Write the velocity and/or stress fields (``.npy`` snapshots instead of the
-        reference's VTK streams, ``seigen/elastic.py:221-232``)."""
+        r"""Write the velocity and/or stress fields (``seigen/elastic.py:221-232``): numbered
+        ``.vtu`` files with point data named like the function (``VelocityNew``, ``StressNew``) and
+        a ``.pvd`` index, as the reference's VTK streams; raw ``.npy`` with ``SEIGEN_OUTPUT=npy``."""
         if self.output:
             with timed_region('i/o'):
-                rank = world()[0]
+                if os.environ.get("SEIGEN_OUTPUT", "vtu") == "npy":
+                    rank = world()[0]
+                    if u:
+                        np.save("velocity_%d_r%d.npy" % (self._step_index, rank), u.dat.data)
+                    if s:
+                        np.save("stress_%d_r%d.npy" % (self._step_index, rank), s.dat.data)
+                    return
                 if u:
-                    np.save("%s_%d_r%d.npy" % (self.u_stream, self._step_index, rank), u.dat.data)
+                    self.u_stream.write(u, self._step_index * (self.dt or 0.0))
                 if s:
-                    np.save("%s_%d_r%d.npy" % (self.s_stream, self._step_index, rank), s.dat.data)
+                    self.s_stream.write(s, self._step_index * (self.dt or 0.0))
 
     def create_solver(self, form, result=None):
         """Solver context of one stage = its fused-launch id (``elastic.py:354-356``)."""

@@ -2,6 +2,7 @@
 sponge + source (explosive source set-up), eigenmode (BASELINE config 1), per-cell
 material, multi-block halo exchange on one device."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -329,3 +330,25 @@ def test_3d_source_and_sponge(gpu, degree, n):
     plain.set_field(_lib.FIELD_S, 0.5 * (s0 + np.swapaxes(s0, -1, -2)))
     plain.step(nsteps)
     assert rel_err(plain.get_field(_lib.FIELD_U), orc.u1) > 1e-6
+
+
+def test_output_streams(gpu, tmp_path, monkeypatch):
+    """output=True (the reference's default, seigen/elastic.py:28): velocity_<k>.vtu / stress_<k>.vtu
+    after the initial state and after every step, with point data VelocityNew / StressNew that a
+    probe like tests/explosive_source/uy.py:36-43 reads."""
+    from seigen_amd import ElasticLF4, UnitSquareMesh, Function, Expression
+    from seigen_amd.vtu import read_vtu, vertex_nodes
+    monkeypatch.chdir(tmp_path)
+    el = ElasticLF4.create(UnitSquareMesh(4, 4), "DG", 2, dimension=2, solver="explicit", output=True)
+    el.density, el.dt, el.mu, el.l = 1.0, 0.01, 0.25, 0.5
+    el.u0.assign(Function(el.U).interpolate(Expression(("sin(3*x[0])", "cos(2*x[1])"))))
+    el.s0.assign(Function(el.S).interpolate(Expression((("x[0]", "0.0"), ("0.0", "x[1]")))))
+    u1, s1 = el.run(0.03)                      # 3 steps
+    files = sorted(f for f in os.listdir(".") if f.startswith("velocity_"))
+    assert files == ["velocity_%d.vtu" % k for k in range(4)]          # initial state + 3 steps
+    assert os.path.exists("velocity.pvd") and os.path.exists("stress.pvd")
+    pts, data = read_vtu("velocity_3.vtu")
+    vn = vertex_nodes(2, 2)
+    np.testing.assert_allclose(data["VelocityNew"][:, :2], u1.dat.data_cells[:, vn].reshape(-1, 2), rtol=0, atol=1e-15)
+    _, sd = read_vtu("stress_3.vtu")
+    np.testing.assert_allclose(sd["StressNew"].reshape(-1, 3, 3)[:, :2, :2], s1.dat.data_cells[:, vn].reshape(-1, 2, 2), atol=1e-15)

@@ -285,3 +285,42 @@ def test_marmousi_lookup():
     assert lam.shape == (383 * 121 * 2,)
     np.testing.assert_allclose(lam + 2 * mu, vp ** 2, rtol=1e-14)
     np.testing.assert_allclose(mu, vp ** 2 / 3.0, rtol=1e-14)
+
+
+def test_vtu_stream_round_trip(tmp_path):
+    """Output path (seigen/elastic.py:117-124, :221-232): numbered .vtu files + .pvd index, every cell
+    with its own vertices, point data named like the function - written and parsed back."""
+    from seigen_amd import UnitSquareMesh, UnitCubeMesh
+    from seigen_amd.functionspace import VectorFunctionSpace, TensorFunctionSpace, Function
+    from seigen_amd.vtu import VtuStream, read_vtu, vertex_nodes
+    for mesh, dim, degree in ((UnitSquareMesh(3, 2), 2, 3), (UnitCubeMesh(2, 1, 2), 3, 2)):
+        U = VectorFunctionSpace(mesh, "DG", degree)
+        u = Function(U, name="VelocityNew")
+        X = U.node_coords()
+        vals = np.stack([X[..., 0] + 2 * X[..., 1], X[..., 0] * X[..., 1]] + ([X[..., 2] ** 2] if dim == 3 else []), axis=-1)
+        u.dat.data = vals.reshape(-1, dim)
+        st = VtuStream("velocity", directory=str(tmp_path))
+        f0 = st.write(u, 0.0)
+        f1 = st.write(u, 0.5)
+        assert (f0, f1) == ("velocity_0.vtu", "velocity_1.vtu")
+        pvd = (tmp_path / "velocity.pvd").read_text()
+        assert 'file="velocity_0.vtu"' in pvd and 'timestep="0.5" file="velocity_1.vtu"' in pvd
+        pts, data = read_vtu(str(tmp_path / f1))
+        vn = vertex_nodes(dim, degree)
+        ncells = X.shape[0]
+        assert pts.shape == (ncells * (dim + 1), 3)
+        np.testing.assert_allclose(pts[:, :dim], X[:, vn, :].reshape(-1, dim), atol=1e-15)
+        got = data["VelocityNew"]
+        assert got.shape == (ncells * (dim + 1), 3)
+        np.testing.assert_allclose(got[:, :dim], vals[:, vn, :].reshape(-1, dim), atol=1e-14)
+        # the listed nodes really are the cell's vertices: corners of the node cloud of every cell
+        for c in range(0, ncells, 3):
+            hull = X[c][vn]
+            lam = np.linalg.lstsq(np.vstack([hull.T, np.ones(dim + 1)]), np.vstack([X[c].T, np.ones(X.shape[1])]), rcond=None)[0]
+            assert lam.min() > -1e-12                        # every node is a convex combination of them
+        S = TensorFunctionSpace(mesh, "DG", degree)
+        s = Function(S, name="StressNew")
+        s.dat.data = np.einsum("ni,nj->nij", vals.reshape(-1, dim), vals.reshape(-1, dim))
+        ss = VtuStream("stress", directory=str(tmp_path))
+        _, sd = read_vtu(str(tmp_path / ss.write(s)))
+        assert sd["StressNew"].shape == (ncells * (dim + 1), 9)
