@@ -107,3 +107,30 @@ class VtuStream(object):
                     f.write('<DataSet timestep="%s" file="%s"/>\n' % (t, fn))
                 f.write('</Collection>\n</VTKFile>\n')
         return fname
+
+
+def probe(path, name, xs):
+    """Values of point data `name` at the points `xs` [n, dim] of a file written by write_vtu: the
+    containing cell is searched among all cells, the value interpolated linearly between its vertices
+    (what ``vtktools.ProbeData`` does in ``tests/explosive_source/uy.py:36-43``).  On a grid line
+    the lowest-numbered containing cell answers."""
+    pts, data = read_vtu(path)
+    xs = np.atleast_2d(np.asarray(xs, dtype=np.float64))
+    dim = xs.shape[1]
+    nv = dim + 1
+    P = pts[:, :dim].reshape(-1, nv, dim)
+    V = data[name].reshape(P.shape[0], nv, -1)
+    # barycentric coordinates of every query point in every cell
+    T = np.transpose(P[:, 1:, :] - P[:, :1, :], (0, 2, 1))          # [cells, dim, dim]
+    Tinv = np.linalg.inv(T)
+    out = np.empty((xs.shape[0], V.shape[2]))
+    for k, x in enumerate(xs):
+        lam = np.einsum("cij,cj->ci", Tinv, x[None, :] - P[:, 0, :])
+        lam0 = 1.0 - lam.sum(axis=1)
+        inside = (lam.min(axis=1) >= -1e-12) & (lam0 >= -1e-12)
+        if not inside.any():
+            raise ValueError("point %r is outside the mesh" % (tuple(x),))
+        c = int(np.nonzero(inside)[0][0])
+        w = np.concatenate([[lam0[c]], lam[c]])
+        out[k] = w @ V[c]
+    return out

@@ -318,6 +318,11 @@ def test_vtu_stream_round_trip(tmp_path):
             hull = X[c][vn]
             lam = np.linalg.lstsq(np.vstack([hull.T, np.ones(dim + 1)]), np.vstack([X[c].T, np.ones(X.shape[1])]), rcond=None)[0]
             assert lam.min() > -1e-12                        # every node is a convex combination of them
+        # probing (uy.py:36-43): a field that is linear in x is reproduced exactly anywhere
+        from seigen_amd.vtu import probe
+        xq = np.array([[0.31, 0.47, 0.12][:dim], [0.5, 0.5, 0.5][:dim], [1.0, 1.0, 1.0][:dim]])
+        got = probe(str(tmp_path / f1), "VelocityNew", xq)
+        np.testing.assert_allclose(got[:, 0], xq[:, 0] + 2 * xq[:, 1], atol=1e-13)
         S = TensorFunctionSpace(mesh, "DG", degree)
         s = Function(S, name="StressNew")
         s.dat.data = np.einsum("ni,nj->nij", vals.reshape(-1, dim), vals.reshape(-1, dim))
