@@ -352,3 +352,20 @@ def test_output_streams(gpu, tmp_path, monkeypatch):
     np.testing.assert_allclose(data["VelocityNew"][:, :2], u1.dat.data_cells[:, vn].reshape(-1, 2), rtol=0, atol=1e-15)
     _, sd = read_vtu("stress_3.vtu")
     np.testing.assert_allclose(sd["StressNew"].reshape(-1, 3, 3)[:, :2, :2], s1.dat.data_cells[:, vn].reshape(-1, 2, 2), atol=1e-15)
+
+
+def test_eigenmode_bench_record(gpu, tmp_path):
+    """The pybench-style record of tests/eigenmode/eigenmode_bench.py:19-57: series, timers, metadata."""
+    import json
+    from seigen_amd.harness.eigenmode_bench import eigenmode_record
+    path = tmp_path / "EigenmodeLF4.json"
+    # T = 5: the error functional of the reference compares with the analytic fields at t = 5
+    # (eigenmode_2d.py:49-63), whatever T the run had
+    rec = eigenmode_record(dim=2, N=8, degree=2, dt=-1.0, T=5.0, path=str(path))
+    assert rec["series"] == {"np": 1, "dim": 2, "size": 8, "T": 5.0, "solver": "explicit", "opt": 2, "degree": 2,
+                             "dt": 0.5 / 8 / 2}
+    assert rec["meta"]["dofs"] == 8 * 8 * 2 * 6 * 4                      # S dofs as elastic.py:85-86
+    assert 0 < rec["meta"]["u_error"] < 1e-2 and 0 < rec["meta"]["s_error"] < 1e-2
+    for task in ("timestepping", "solver setup", "compute_error"):
+        assert rec["timings"][task] > 0
+    assert json.loads(path.read_text())["meta"]["dofs"] == rec["meta"]["dofs"]
