@@ -2,6 +2,8 @@
 seeded inputs.  FP64 everywhere; tolerance = 1e-11 relative to the largest
 entry of the expected field per operator application (different summation
 order only), looser bounds stated where many steps accumulate."""
+import os
+
 import numpy as np
 import pytest
 
@@ -272,3 +274,46 @@ def test_error_behaviour(gpu):
         nb.run_stage(0, _lib.REGION_FIRST)
     with pytest.raises(_lib.SeigenHipError):
         HipBlock(3, 7, (2, 2, 2), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0))   # unsupported degree
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEIGEN_TEST_RANDOM_CASES", "10"))))
+def test_kernel_families_agree_on_random_blocks(gpu, monkeypatch, seed):
+    """Differential test: random dimension, degree, (ragged) block size, cell size, diagonal, sponge
+    and per-cell material; the kernel families that support the case must agree after two steps."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.integers(2, 4))
+    degree = int(rng.integers(1, 5))
+    n = tuple(int(x) for x in (rng.integers(1, 20, size=dim) if dim == 3 else rng.integers(1, 40, size=dim)))
+    h = tuple(float(x) for x in rng.uniform(0.2, 1.5, size=dim))
+    diagonal = "right" if (dim == 2 and rng.integers(0, 2)) else "left"
+    dt = 0.05 * min(h) / degree ** 2
+    results = {}
+    for path in ("generic", "lane", "mfma"):
+        if path == "mfma" and dim != 3:
+            continue
+        if path == "lane" and dim == 3 and degree > 2:
+            continue
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        blk = HipBlock(dim, degree, n, h, (0.0,) * dim, diagonal)
+        r2 = np.random.default_rng(2000 + seed)
+        lam = r2.uniform(0.4, 0.9, blk.ncells) if seed % 2 else 0.5
+        mu = r2.uniform(0.2, 0.5, blk.ncells) if seed % 2 else 0.25
+        blk.set_params(1.0, dt, lam, mu)
+        if seed % 3 == 0:
+            nq = {2: 15, 3: 35}[dim]
+            blk.set_absorption(np.where(r2.uniform(size=(blk.ncells, nq)) > 0.7, 5.0, 0.0), 4)
+        u0 = r2.uniform(-1, 1, blk.field_shape(_lib.FIELD_U))
+        s0 = r2.uniform(-1, 1, blk.field_shape(_lib.FIELD_S))
+        if seed % 4:                       # mostly symmetric stress (symmetric mode), sometimes not
+            s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        blk.set_field(_lib.FIELD_U, u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.step(2)
+        results[path] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    ref_u, ref_s = results["generic"]
+    assert np.isfinite(ref_u).all() and np.isfinite(ref_s).all()
+    for path, (u, s) in results.items():
+        assert rel_err(u, ref_u) < 1e-11 and rel_err(s, ref_s) < 1e-11, (path, dim, degree, n)
