@@ -169,16 +169,7 @@ class _LocalExchange(object):
                 b.end_step()
 
 
-@pytest.mark.parametrize("dim,degree,n,grid", [
-    (2, 2, (6, 4), (2, 2)),
-    (2, 3, (5, 4), (1, 2)),
-    (3, 2, (4, 4, 2), (2, 2, 1)),
-    (3, 4, (4, 2, 4), (2, 1, 2)),
-    (3, 4, (2, 4, 4), (1, 2, 2)),
-    (3, 3, (4, 3, 2), (2, 1, 1)),
-])
-@pytest.mark.parametrize("pipelined", [True, False])
-def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
+def _multiblock_case(dim, degree, n, grid, pipelined):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -205,7 +196,9 @@ def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
         """global cell indices of a block, in the block's own cell order"""
         idx = []
         rng = [range(p.start[a], p.start[a] + p.n[a]) for a in range(dim)]
-        if dim == 2:
+        if dim == 1:
+            idx.extend(rng[0])
+        elif dim == 2:
             for j in rng[1]:
                 for i in rng[0]:
                     cube = i + n[0] * j
@@ -233,6 +226,33 @@ def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
         sel = cells_of(p)
         assert np.array_equal(b.get_field(_lib.FIELD_U), uref[sel]), "velocity differs from the single-block run"
         assert np.array_equal(b.get_field(_lib.FIELD_S), sref[sel]), "stress differs from the single-block run"
+
+
+@pytest.mark.parametrize("dim,degree,n,grid", [
+    (2, 2, (6, 4), (2, 2)),
+    (2, 3, (5, 4), (1, 2)),
+    (3, 2, (4, 4, 2), (2, 2, 1)),
+    (3, 4, (4, 2, 4), (2, 1, 2)),
+    (3, 4, (2, 4, 4), (1, 2, 2)),
+    (3, 3, (4, 3, 2), (2, 1, 1)),
+])
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
+    _multiblock_case(dim, degree, n, grid, pipelined)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEIGEN_TEST_RANDOM_CASES", "8"))))
+def test_multiblock_random_grids(gpu, seed):
+    """Random block grids, x splits and one-cube-thin blocks included (the shell then covers the whole
+    block and the halves of the pipelined schedule are empty): bitwise equal to the single block."""
+    rng = np.random.default_rng(500 + seed)
+    dim = int(rng.integers(1, 4))
+    degree = int(rng.integers(1, 5))
+    grid = tuple(int(g) for g in rng.integers(1, 4, size=dim))
+    if int(np.prod(grid)) == 1:
+        grid = grid[:-1] + (2,)
+    n = tuple(int(g * rng.integers(1, 4) + rng.integers(0, 2)) for g in grid)
+    _multiblock_case(dim, degree, n, grid, bool(seed % 2 == 0))
 
 
 def test_receiver_traces_full_run_vs_oracle_and_ref_c(gpu):
