@@ -169,7 +169,7 @@ class _LocalExchange(object):
                 b.end_step()
 
 
-def _multiblock_case(dim, degree, n, grid, pipelined):
+def _multiblock_case(dim, degree, n, grid, pipelined, extras=False):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -185,6 +185,16 @@ def _multiblock_case(dim, degree, n, grid, pipelined):
     single.set_params(1.0, dt, 0.5, 0.25)
     single.set_field(_lib.FIELD_U, u0)
     single.set_field(_lib.FIELD_S, s0)
+    nd = single.nd
+    if extras:      # a sponge and a time-dependent source scattered over the mesh (shell cells included)
+        r3 = np.random.default_rng(77)
+        nq = {1: 5, 2: 15, 3: 35}[dim]
+        sigma = np.where(r3.uniform(size=(single.ncells, nq)) > 0.6, 3.0, 0.0)
+        src_nodes = np.unique(r3.integers(0, single.ncells * nd, size=min(40, single.ncells * nd)))
+        sv = r3.uniform(-1, 1, size=(3, len(src_nodes), dim, dim))
+        src_vals = 0.5 * (sv + np.swapaxes(sv, -1, -2))
+        single.set_absorption(sigma, 4)
+        single.set_source(src_nodes, src_vals)
     single.step(3)
     uref, sref = single.get_field(_lib.FIELD_U), single.get_field(_lib.FIELD_S)
 
@@ -219,6 +229,12 @@ def _multiblock_case(dim, degree, n, grid, pipelined):
         b.set_params(1.0, dt, 0.5, 0.25)
         b.set_field(_lib.FIELD_U, u0[sel])
         b.set_field(_lib.FIELD_S, s0[sel])
+        if extras:
+            b.set_absorption(sigma[sel], 4)
+            local = {int(c): i for i, c in enumerate(sel)}        # global cell -> cell of this block
+            mine = [j for j, g in enumerate(src_nodes) if int(g) // nd in local]
+            b.set_source(np.array([local[int(src_nodes[j]) // nd] * nd + int(src_nodes[j]) % nd for j in mine], dtype=np.int64),
+                         src_vals[:, mine] if mine else None)
         blocks.append(b)
     ex = _LocalExchange(blocks, parts)
     ex.step(3, pipelined)
@@ -252,7 +268,7 @@ def test_multiblock_random_grids(gpu, seed):
     if int(np.prod(grid)) == 1:
         grid = grid[:-1] + (2,)
     n = tuple(int(g * rng.integers(1, 4) + rng.integers(0, 2)) for g in grid)
-    _multiblock_case(dim, degree, n, grid, bool(seed % 2 == 0))
+    _multiblock_case(dim, degree, n, grid, bool(seed % 2 == 0), extras=(seed % 3 != 1))
 
 
 def test_receiver_traces_full_run_vs_oracle_and_ref_c(gpu):
