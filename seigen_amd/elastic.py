@@ -281,7 +281,10 @@ class ElasticLF4(object):
 
     def _advance(self, nsteps):
         if self._exchanger is not None:
-            self._exchanger.step(nsteps)
+            if os.environ.get("SEIGEN_HALO_SCHEDULE", "pipelined") == "plain":
+                self._exchanger.step_unpipelined(nsteps)      # input traces || interior, then the shell
+            else:
+                self._exchanger.step(nsteps)
         else:
             self._block.step(nsteps)
         self._step_index += nsteps
