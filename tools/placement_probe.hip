@@ -41,6 +41,13 @@ static void run(hipStream_t s, int nblk, const char* name) {
     }
     int mx = 0;
     for (auto& kv : cus) mx = kv.second > mx ? kv.second : mx;
+    int labels[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nblk; ++b)
+      if ((((unsigned)h[2 * b + 1] >> 16) & 15) == (unsigned)x) labels[b % 8] += 1;
+    printf("  XCD %d holds blockIdx %% 8 =", x);
+    for (int l = 0; l < 8; ++l)
+      if (labels[l]) printf(" %d (x%d)", l, labels[l]);
+    printf("\n");
     printf("  XCD %d: %3d blocks on %2zu CUs (max %d per CU), %d started late, %d with blockIdx %% 8 != XCD\n", x, nb,
            cus.size(), mx, late, lab_mismatch);
   }
