@@ -6,6 +6,11 @@ config 3: 64^3 cubes x 6 tets, P4, FP64), one mesh block per GPU.
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Started WITHOUT torchrun and with --gpus N > 1, this process starts the N ranks itself (a child
+`python -m torch.distributed.run ...`, before anything here touches a GPU), relays rank 0's JSON
+line and exits non-zero if any rank failed - the reference's protocol is
+`mpiexec -n NP python eigenmode_bench.py ...` (tests/eigenmode/README.md:7-13).
+
 One "step" = one full LF4 timestep (six fused HIP launches = the reference's
 eight solves + two assigns, seigen/elastic.py:291-304) over the whole mesh.
 DoF-updates = (U dofs + S dofs) * steps  (SURVEY.md 8d).  Weak scaling: every
@@ -70,6 +75,34 @@ def fill_initial_condition(elastic, dt):
         blk.set_field_range(_lib.FIELD_S, k * cells_per_layer, T)
 
 
+def self_launch(ngpus):
+    """--gpus N > 1 without a torchrun environment: start the ranks as a child process group and
+    relay what they print.  Nothing in this parent has initialised HIP (no exec of a GPU process)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        print(ln)
+    sys.stdout.flush()
+    if proc.returncode != 0:
+        print("bench.py: a rank failed (torch.distributed.run exit code %d)" % proc.returncode, file=sys.stderr)
+        sys.exit(proc.returncode)
+    if len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
 def cpu_baseline(degree, budget_s=15.0):
     """The oracle's plain-C/OpenMP restatement of the reference path (oracle/c/seigen_oracle.c,
     kind "port") timed on this host's cores: 3-D eigenmode, N=16 (24 576 tets), same P, FP64.
@@ -96,12 +129,21 @@ def cpu_baseline(degree, budget_s=15.0):
         ncpu = os.cpu_count() or 1
     best = (float("inf"), 1)
     tcount = 1
+    one_core = None
     while tcount <= ncpu:
         cp.set_threads(tcount)
         cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)
         t0 = time.perf_counter()
         cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)
         el = time.perf_counter() - t0
+        if tcount == 1:
+            # the 1-core figure of SURVEY 8d: a few more steps on one thread (about 3 s)
+            t0 = time.perf_counter()
+            k1 = 0
+            while time.perf_counter() - t0 < 3.0 and k1 < 50:
+                cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)
+                k1 += 1
+            one_core = dofs * k1 / (time.perf_counter() - t0) / 1e6
         if el < best[0]:
             best = (el, tcount)
         if el > 4.0 * best[0]:
@@ -116,7 +158,8 @@ def cpu_baseline(degree, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s or n >= 2000:
             break
     el = time.perf_counter() - t0
-    return {"value": dofs * n / el / 1e6, "unit": "M DoF-updates/s", "cores": cp.threads(), "kind": "port",
+    return {"value": dofs * n / el / 1e6, "unit": "M DoF-updates/s", "cores": cp.threads(), "value_1core": one_core,
+            "kind": "port",
             "sample": "oracle/c/seigen_oracle.c (plain C + OpenMP) 3D eigenmode N=%d P=%d, %d tets, %d steps in %.1f s, "
                       "%d threads" % (N, degree, m.ncells, n, el, cp.threads())}
 
@@ -124,12 +167,16 @@ def cpu_baseline(degree, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: as many as make the timed region at least 2 s, e.g. 250 at config 3)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--cubes", type=int, default=64, help="cubes per axis per GPU (64 = BASELINE config 3)")
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)      # never returns
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,8 +194,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import seigen_amd
     from seigen_amd import ElasticLF4, BoxMesh
@@ -178,22 +227,50 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    def reduce_max(x):
+        if world == 1:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def gather(x):
+        """one float per rank -> list over ranks (on every rank)"""
+        if world == 1:
+            return [float(x)]
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [o.item() for o in outs]
+
+    sync()
+    t0 = time.perf_counter()
     elastic._advance(args.warmup)
     sync()
+    warm_s = reduce_max(time.perf_counter() - t0)
+    if args.steps is None:
+        # long enough for clocks and power to settle (the package reaches its power cap within about
+        # a second): at least 2 s of timed stepping, from the warm-up's own rate
+        per_step = warm_s / max(args.warmup, 1)
+        args.steps = int(min(max(math.ceil(2.2 / max(per_step, 1e-6)), 20), 20000))
+        if n == 64 and P == 4 and world == 1:
+            args.steps = max(args.steps, 250)
+    ex = elastic._exchanger
+    if ex is not None:
+        ex.reset_stats(timing=True)
     blk.enable_timing(True)
     c0 = blk.counters()
+    sync()
     t0 = time.perf_counter()
     elastic._advance(args.steps)
     sync()
     t1 = time.perf_counter()
     c1 = blk.counters()
     blk.enable_timing(False)
-    elapsed = t1 - t0
-    if world > 1:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = reduce_max(t1 - t0)
+    ranks_reporting = int(round(sum(gather(1.0))))
 
     # sanity: the field must still be finite
     probe = blk.get_field_range(seigen_amd._lib.FIELD_U, 0, 6)
@@ -202,59 +279,95 @@ def main():
     d = 3
     nodes = blk.ncells * blk.nd
     dofs_per_gpu = blk.u_dofs + blk.s_dofs
-    total_dofs = dofs_per_gpu * world
+    total_dofs = int(round(sum(gather(dofs_per_gpu))))
     value = total_dofs * args.steps / elapsed / 1e6
 
     # kernels as rocprofv3 names them: <P, 0> plain store (stages uh1/utemp, stemp/sh1),
     # <P, 1> fused LF4 combine (stage u1, stage s1)
     ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
     nl = [c1["launches"][i] - c0["launches"][i] for i in range(6)]
-    words = [d * d + d, d + d * d, d * d + 3 * d, d + d * d, d * d + d, 3 * d * d + d]   # per node per launch
+    nst = c1["steps"] - c0["steps"]
+    assert nst == args.steps, (nst, args.steps)
+    # algorithmic words per node and STAGE (every input read once, every output written
+    # once, 9-component stress = the metric's 64 B per DoF-update) ...
+    sw = d * d
+    words = [sw + d, d + sw, sw + 3 * d, d + sw, sw + d, 3 * sw + d]
+    # ... and what the kernels physically move in symmetric-stress mode (6 of the 9 lines)
+    sw6 = d * (d + 1) // 2
+    words_phys = [sw6 + d, d + sw6, sw6 + 3 * d, d + sw6, sw6 + d, 3 * sw6 + d]
     mfma = os.environ.get("SEIGEN_HIP_PATH", "") not in ("generic", "lane") and (P >= 2 or blk.ncells >= 65536)
+    sym = 1 if blk.is_sym() else 0      # symmetric-stress storage (default; SEIGEN_HIP_SYM=0 switches it off)
     if mfma:
-        sym = 0 if os.environ.get("SEIGEN_HIP_SYM", "") == "0" else 1     # symmetric-stress mode (default)
         names = (("sg::mfma_stage_F<%d, 0, %d>" % (P, sym), (0, 4)), ("sg::mfma_stage_F<%d, 1, %d>" % (P, sym), (2,)),
                  ("sg::mfma_stage_G<%d, 0, %d>" % (P, sym), (1, 3)), ("sg::mfma_stage_G<%d, 1, %d>" % (P, sym), (5,)))
     else:
         names = (("sg::stage_kernel<3, %d, 0>" % P, (0, 2, 4)), ("sg::stage_kernel<3, %d, 1>" % P, (1, 3, 5)))
+    if not sym:
+        words_phys = words
     kern = {}
     for name, stages in names:
         tot_ms = sum(ms[i] for i in stages)
         launches = sum(nl[i] for i in stages)
-        byts = sum(words[i] * nl[i] for i in stages) * nodes * 8.0
+        # bytes per STEP, not per launch: a split stage (multi-GPU: FIRST + SECOND) covers the block once
+        byts = sum(words[i] for i in stages) * nst * nodes * 8.0
+        byts_phys = sum(words_phys[i] for i in stages) * nst * nodes * 8.0
         kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(launches, 1),
-                          gbs=byts / max(tot_ms, 1e-12) / 1e6)
+                          gbs=byts / max(tot_ms, 1e-12) / 1e6, gbs_phys=byts_phys / max(tot_ms, 1e-12) / 1e6,
+                          bytes_per_launch=byts / max(launches, 1), bytes_phys_per_launch=byts_phys / max(launches, 1))
     dom = max(kern, key=lambda k: kern[k]["ms"])
     # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE,
     # calibrated with tools/calib_fetch.hip) - measured separately, see profiles/<round>/*_traffic.json
     traffic = None
+    traffic_src = None
     if world == 1 and n == 64 and P == 4:
         for tj in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "config3_traffic.json"))):
             try:
-                traffic = json.load(open(tj))["kernels"].get(dom, {}).get("bytes", traffic)
+                t = json.load(open(tj))["kernels"].get(dom, {}).get("bytes")
+                if t:
+                    traffic, traffic_src = t, os.path.relpath(tj, ROOT)
             except (OSError, ValueError, KeyError):
                 pass
-    roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": kern[dom]["gbs"] * 1e6 * kern[dom]["avg_ms"],
-            "avg_launch_ms": kern[dom]["avg_ms"],
-            "kernels": {k: {"avg_ms": v["avg_ms"], "algorithmic_GBps": v["gbs"]} for k, v in kern.items()},
+    k = kern[dom]
+    roof = {"bound": "hbm", "kernel": dom,
+            # 9-component accounting = the metric's 64 B per DoF-update
+            "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
+            # what the kernel moves at best in symmetric-stress mode (6-component stress)
+            "achieved_physical": k["gbs_phys"], "frac_physical": k["gbs_phys"] / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_ratio": (traffic / k["bytes_phys_per_launch"]) if traffic else None,
+            "algorithmic_bytes_per_launch": k["bytes_per_launch"],
+            "physical_bytes_per_launch": k["bytes_phys_per_launch"],
+            "avg_launch_ms": k["avg_ms"],
+            "kernels": {kk: {"avg_ms": v["avg_ms"], "launches": v["launches"], "algorithmic_GBps": v["gbs"],
+                             "physical_GBps": v["gbs_phys"]} for kk, v in kern.items()},
             "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9),
-            "stage_avg_ms": [ms[i] / max(nl[i], 1) for i in range(6)]}
+            "stage_avg_ms": [ms[i] / max(nst, 1) for i in range(6)]}
     if mfma:
         # second view of the same kernel: the dense element-local products on the FP64 matrix pipe.
         # Algorithmic flop per cell and launch: 2 * (9 nd^2 + 12 nd nf), F and G alike.
         nf = (P + 1) * (P + 2) // 2
-        flop = 2.0 * (9 * blk.nd ** 2 + 12 * blk.nd * nf) * blk.ncells
-        tf = flop / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+        stages_dom = dict(names)[dom]
+        flop = 2.0 * (9 * blk.nd ** 2 + 12 * blk.nd * nf) * blk.ncells * len(stages_dom) * nst / max(k["launches"], 1)
+        tf = flop / (k["avg_ms"] * 1e-3) / 1e12
         roof["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                         "sustained_measured": FP64_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": tf / FP64_MFMA_SUSTAINED_TFLOPS,
                         "algorithmic_flop_per_launch": flop}
 
+    # halo layer, per rank (lists over ranks): device time of the trace packs, bytes handed to the
+    # transport, and the time the launch stream (RCCL) or the host (host-staged) waited for traces
+    halo = None
+    if world > 1:
+        st = ex.stats()
+        halo = {"transport": "host-staged/%s" % backend if ex.staged else backend,
+                "pack_ms_per_step": gather((c1["halo_pack_ms"] - c0["halo_pack_ms"]) / nst),
+                "bytes_sent_per_step": gather((c1["halo_bytes_packed"] - c0["halo_bytes_packed"]) / nst),
+                "exposed_wait_ms_per_step": gather(st["exposed_wait_ms"] / nst),
+                "exchanges_per_step": st["exchanges"] / nst,
+                "kernel_ms_per_step": gather(sum(ms) / nst)}
     if rank == 0:
         out = {
             "metric": "M DoF-updates/sec, 3D elastic P=%d" % P, "value": value, "unit": "M DoF-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ranks_reporting, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3D eigenmode, %dx%dx%d cubes x 6 tets (%d^3 per GPU), DG P%d, FP64, LF4"
@@ -262,7 +375,10 @@ def main():
                        "cells": int(blk.ncells * world), "dofs": int(total_dofs),
                        "block_grid": list(grid), "dt": elastic.dt},
             "roofline": roof,
+            "timed_region_s": elapsed,
         }
+        if halo is not None:
+            out["halo"] = halo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out))

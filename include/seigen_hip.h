@@ -100,6 +100,10 @@ typedef struct sg_counters {
   double kernel_ms[6];   /* accumulated device time per stage (hipEvent), only when timing is enabled */
   int64_t launches[6];
   int64_t steps;
+  /* halo layer (the role of ParLoopHaloEnd, tests/tiling/utils.py:144) */
+  double halo_pack_ms;       /* device time of the trace-pack launches, only when timing is enabled */
+  int64_t halo_pack_launches;
+  int64_t halo_bytes_packed; /* bytes written to send buffers = bytes this block hands to the transport */
 } sg_counters_t;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -127,6 +131,14 @@ int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t n
 /* per_cell = 0: lambda/mu point to one value each; 1: one value per cell
  * (build-defined heterogeneous extension). */
 int sg_set_params(sg_handle* h, double density, double dt, const double* lambda, const double* mu, int per_cell);
+/* Density beyond the scalar of sg_set_params (which it overrides until the next sg_set_params):
+ *   per_cell = 0: rho[0];  1: one value per cell (SURVEY 8 f2 "(and rho)", build-defined like per-cell
+ *   lambda/mu: each cell's velocity update uses its own density).
+ *   physical = 0: the explicit reference's update u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 - explicit
+ *   mode keeps only rhs(form_u1) and applies the unweighted mass inverse (elastic.py:341-345,
+ *   :354-356, :376), which is the physical update only for rho = 1;
+ *   physical = 1: u1 = u0 + (dt*uh1 + dt^3/24*uh2)/rho, what the implicit form solves (elastic.py:175-178). */
+int sg_set_density(sg_handle* h, const double* rho, int per_cell, int physical);
 
 /* ---- field transfer (u0.assign(...), s0.assign(...): eigenmode_2d.py:32,36) -------- */
 int sg_set_field(sg_handle* h, int field, const double* host, size_t nbytes);
@@ -145,7 +157,8 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
  * source; values[k][i][dim*dim] is the nodal S_ij of entry i during step k
  * (k = 0 .. nsteps-1 counted from this call; no source afterwards).  This is the
  * re-interpolated `source_function` of elastic.py:285-288 restricted to its
- * support.  nnz = 0 disables. */
+ * support.  nsteps = -1: a time-independent source, values[0][i][dim*dim] holds at
+ * every step.  nnz = 0 disables. */
 int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values);
 
 /* ---- the hot path ---------------------------------------------------------------- */
@@ -175,6 +188,11 @@ int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out);
 /* the same for several sides in ONE launch: dev_out[side] = send buffer of that side or NULL, 6 entries */
 int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out);
 int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in);
+/* Symmetric-stress storage is left automatically when THIS block is handed a
+ * non-symmetric stress or source; blocks of one mesh must agree, so the host layer reads the
+ * state of every block (sg_get_sym) and makes all of them leave together (sg_leave_sym). */
+int sg_get_sym(const sg_handle* h, int* sym);
+int sg_leave_sym(sg_handle* h);
 
 /* ---- instrumentation --------------------------------------------------------------- */
 int sg_enable_timing(sg_handle* h, int on);
@@ -194,6 +212,11 @@ int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out
 /* phi[p][a]: Lagrange basis of P_degree (degree <= 8) at reference points xi[p][dim] - the
  * tabulation behind Function evaluation / the error functional of eigenmode_2d.py:49-63. */
 int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi);
+/* The disjoint boxes of cubes {origin[3], extent[3]} a region of a split stage covers in the block
+ * `cfg` describes (n, dim, nbr_mask); returns their number (at most SG_MAX_REGION_BOXES; a stage
+ * launch carries that many), writes the first `max_boxes` of them to boxes[][6]. */
+#define SG_MAX_REGION_BOXES 7
+int sg_region_boxes(const sg_config* cfg, int region, int32_t* boxes, int max_boxes);
 /* Translation-invariant neighbour tables of the structured simplicial mesh:
  * nb [cls][face][5] = {axis crossed (-1: same cube), direction, neighbour class,
  * neighbour facet, ordinal on the cube side}; nb_node [cls][face][nf] neighbour

@@ -42,7 +42,8 @@ class OracleLF4(object):
         self.s0 = np.zeros((nc, nd, d, d))
         self.u1 = np.zeros((nc, nd, d))
         self.s1 = np.zeros((nc, nd, d, d))
-        self.density = 1.0
+        self.density = 1.0           # float or one value per cell
+        self.density_physical = False  # False: rho*u0 + ... (explicit reference, :341-345); True: u0 + (...)/rho (:175-178)
         self.dt = None
         self.mu = None
         self.l = None
@@ -58,7 +59,12 @@ class OracleLF4(object):
         uh1 = E.apply_F(self.s0, self.u0)
         stemp = E.apply_G(uh1, self.l, self.mu, S)
         uh2 = E.apply_F(stemp, self.u0)
-        self.u1 = rho * self.u0 + dt * uh1 + (dt ** 3 / 24.0) * uh2
+        if np.ndim(rho):
+            rho = np.asarray(rho, dtype=np.float64).reshape(-1, 1, 1)
+        if self.density_physical:
+            self.u1 = self.u0 + (dt * uh1 + (dt ** 3 / 24.0) * uh2) / rho
+        else:
+            self.u1 = rho * self.u0 + dt * uh1 + (dt ** 3 / 24.0) * uh2
         self.u0 = self.u1
         sh1 = E.apply_G(self.u1, self.l, self.mu, S)
         utemp = E.apply_F(sh1, self.u1)

@@ -29,7 +29,8 @@ class SgInfo(C.Structure):
 
 
 class SgCounters(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("steps", C.c_int64)]
+    _fields_ = [("kernel_ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("steps", C.c_int64),
+                ("halo_pack_ms", C.c_double), ("halo_pack_launches", C.c_int64), ("halo_bytes_packed", C.c_int64)]
 
 
 # every symbol include/seigen_hip.h declares: name -> (restype, argtypes)
@@ -45,6 +46,7 @@ SYMBOLS = {
     "sg_node_coords": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "sg_block_node_coords": (C.c_int, [C.POINTER(SgConfig), C.c_int, _P, C.c_size_t]),
     "sg_set_params": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, C.c_int]),
+    "sg_set_density": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "sg_set_field": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "sg_get_field": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "sg_set_field_range": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_size_t]),
@@ -60,10 +62,13 @@ SYMBOLS = {
     "sg_halo_pack": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sg_halo_pack_sides": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "sg_halo_attach": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "sg_get_sym": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "sg_leave_sym": (C.c_int, [_P]),
     "sg_enable_timing": (C.c_int, [_P, C.c_int]),
     "sg_get_counters": (C.c_int, [_P, C.POINTER(SgCounters)]),
     "sg_last_step_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "sg_reference_operator": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
+    "sg_region_boxes": (C.c_int, [C.POINTER(SgConfig), C.c_int, _P, C.c_int]),
     "sg_tabulate": (C.c_int, [C.c_int, C.c_int, C.c_int64, _P, _P]),
     "sg_mesh_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
 }

@@ -99,6 +99,23 @@ class HipBlock(object):
         check(self.lib.sg_set_params(self.h, float(density), float(dt), lam_a.ctypes.data, mu_a.ctypes.data,
                                      per_cell), self.h)
 
+    def set_density(self, rho, physical=False):
+        """Scalar or per-cell density; physical=False: the explicit reference's u1 = rho*u0 + ...,
+        True: u1 = u0 + (...)/rho (include/seigen_hip.h, sg_set_density)."""
+        rho_a = _f64(np.atleast_1d(rho)).ravel()
+        per_cell = int(rho_a.size > 1)
+        if per_cell and rho_a.size != self.ncells:
+            raise ValueError("per-cell density needs one value per cell of the block (%d), got %d" % (self.ncells, rho_a.size))
+        check(self.lib.sg_set_density(self.h, rho_a.ctypes.data, per_cell, int(bool(physical))), self.h)
+
+    def is_sym(self):
+        v = C.c_int()
+        check(self.lib.sg_get_sym(self.h, C.byref(v)), self.h)
+        return bool(v.value)
+
+    def leave_sym(self):
+        check(self.lib.sg_leave_sym(self.h), self.h)
+
     def set_absorption(self, sigma_nodes, sigma_degree):
         if sigma_nodes is None:
             check(self.lib.sg_set_absorption(self.h, None, 0), self.h)
@@ -106,14 +123,17 @@ class HipBlock(object):
         s = _f64(sigma_nodes).reshape(self.ncells, -1)
         check(self.lib.sg_set_absorption(self.h, s.ctypes.data, int(sigma_degree)), self.h)
 
-    def set_source(self, nodes, values):
-        """nodes: flat scalar node indices [nnz]; values [nsteps, nnz, d, d]."""
+    def set_source(self, nodes, values, static=False):
+        """nodes: flat scalar node indices [nnz]; values [nsteps, nnz, d, d] for the next nsteps steps,
+        or (static=True) [1, nnz, d, d] holding at every step."""
         nodes = np.ascontiguousarray(nodes, dtype=np.int64).ravel()
         if nodes.size == 0 or values is None or len(values) == 0:
             check(self.lib.sg_set_source(self.h, 0, None, 0, None), self.h)
             return
         values = _f64(values).reshape(-1, nodes.size, self.dim, self.dim)
-        check(self.lib.sg_set_source(self.h, nodes.size, nodes.ctypes.data, values.shape[0],
+        if static and values.shape[0] != 1:
+            raise ValueError("a static source is one time slice")
+        check(self.lib.sg_set_source(self.h, nodes.size, nodes.ctypes.data, -1 if static else values.shape[0],
                                      values.ctypes.data), self.h)
 
     # ---- hot path ---------------------------------------------------------------------
@@ -146,7 +166,9 @@ class HipBlock(object):
     def counters(self):
         c = SgCounters()
         check(self.lib.sg_get_counters(self.h, C.byref(c)), self.h)
-        return dict(kernel_ms=list(c.kernel_ms), launches=list(c.launches), steps=int(c.steps))
+        return dict(kernel_ms=list(c.kernel_ms), launches=list(c.launches), steps=int(c.steps),
+                    halo_pack_ms=float(c.halo_pack_ms), halo_pack_launches=int(c.halo_pack_launches),
+                    halo_bytes_packed=int(c.halo_bytes_packed))
 
     # ---- halo ---------------------------------------------------------------------------
     def halo_bytes(self, field, side):

@@ -50,6 +50,8 @@ struct sg_handle {
   int per_cell = 0;
   double* lam_d = nullptr;
   double* mu_d = nullptr;
+  double* rho2_d = nullptr;  // per-cell density factors [cell][2] (kernels.hpp), or null
+  int rho_physical = 0;      // scalar density: 0 = rho*u0 + ..., 1 = u0 + (...)/rho
   // sponge
   int32_t* sponge_slot = nullptr;
   double* sponge_B = nullptr;
@@ -60,6 +62,7 @@ struct sg_handle {
   double* src_values = nullptr;  // [nsteps][nnz][dim*dim]
   int64_t src_nsteps = 0;
   int64_t src_step = 0;
+  bool src_static = false;  // one time slice that holds at every step
   // halo
   const double* ghost[4][6];
   // execution
@@ -82,6 +85,7 @@ struct sg_handle {
 };
 
 static std::string g_create_err;
+static_assert(SG_MAX_BOXES == SG_MAX_REGION_BOXES, "kernels.hpp and seigen_hip.h disagree on the box limit");
 
 #define HIPCHECK(h, expr)                                                                        \
   do {                                                                                           \
@@ -133,6 +137,7 @@ void sg_destroy(sg_handle* h) {
   }
   if (h->lam_d) (void)hipFree(h->lam_d);
   if (h->mu_d) (void)hipFree(h->mu_d);
+  if (h->rho2_d) (void)hipFree(h->rho2_d);
   if (h->sponge_slot) (void)hipFree(h->sponge_slot);
   if (h->sponge_B) (void)hipFree(h->sponge_B);
   if (h->src_nodes) (void)hipFree(h->src_nodes);
@@ -391,6 +396,12 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
   if (!h || !lambda || !mu) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   h->rho = density;
+  h->rho_physical = 0;
+  if (h->rho2_d) {
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->rho2_d);
+    h->rho2_d = nullptr;
+  }
   h->dt = dt;
   h->per_cell = per_cell ? 1 : 0;
   if (per_cell) {
@@ -407,6 +418,33 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
     h->mu0 = mu[0];
   }
   h->params_set = true;
+  return SG_OK;
+}
+
+int sg_set_density(sg_handle* h, const double* rho, int per_cell, int physical) {
+  if (h) h->epoch += 1;
+  if (!h || !rho) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (h->rho2_d) {
+    (void)hipFree(h->rho2_d);
+    h->rho2_d = nullptr;
+  }
+  h->rho_physical = physical ? 1 : 0;
+  if (!per_cell) {
+    if (physical && rho[0] == 0.0) return fail(h, SG_ERR_ARG, "sg_set_density: zero density");
+    h->rho = rho[0];
+    return SG_OK;
+  }
+  std::vector<double> r2((size_t)h->ncells * 2);
+  for (int64_t e = 0; e < h->ncells; ++e) {
+    if (physical && rho[e] == 0.0) return fail(h, SG_ERR_ARG, "sg_set_density: zero density");
+    r2[2 * (size_t)e] = physical ? 1.0 : rho[e];
+    r2[2 * (size_t)e + 1] = physical ? 1.0 / rho[e] : 1.0;
+  }
+  h->rho = rho[0];
+  HIPCHECK(h, hipMalloc((void**)&h->rho2_d, r2.size() * sizeof(double)));
+  HIPCHECK(h, hipMemcpy(h->rho2_d, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
   return SG_OK;
 }
 
@@ -559,7 +597,10 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
 struct Box {
   int o[3], n[3];
 };
-static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out);
+static void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out);
+static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
+  region_boxes(h->cfg.dim, h->cfg.n, h->md.has_nbr, region, out);
+}
 
 int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values) {
   if (h) h->epoch += 1;
@@ -577,8 +618,11 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   h->src_nnz = 0;
   h->src_nsteps = 0;
   h->src_step = 0;
+  h->src_static = false;
   if (nnz == 0 || nsteps == 0) return SG_OK;
-  if (!nodes || !values || nsteps < 0) return SG_ERR_ARG;
+  if (!nodes || !values || nsteps < -1) return SG_ERR_ARG;
+  const bool is_static = nsteps == -1;
+  if (is_static) nsteps = 1;
   const int d = h->cfg.dim;
   int64_t nscalar = h->ncells * h->re.nd;
   for (int64_t k = 0; k < nnz; ++k)
@@ -635,16 +679,16 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   HIPCHECK(h, hipMemcpy(h->src_values, vals.data(), vbytes, hipMemcpyHostToDevice));
   h->src_nnz = nnz;
   h->src_nsteps = nsteps;
+  h->src_static = is_static;
   return SG_OK;
 }
 
 // ---- stage launches --------------------------------------------------------------------
 
-static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
+static void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out) {
   out.clear();
-  const int d = h->cfg.dim;
   int lo[3] = {0, 0, 0}, hi[3];
-  for (int a = 0; a < 3; ++a) hi[a] = h->cfg.n[a];
+  for (int a = 0; a < 3; ++a) hi[a] = n[a];
   if (region == SG_REGION_ALL) {
     out.push_back(Box{{0, 0, 0}, {hi[0], hi[1], hi[2]}});
     return;
@@ -652,8 +696,8 @@ static void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) 
   // interior: peel one cube off every side that has a neighbour block
   int ilo[3] = {0, 0, 0}, ihi[3] = {hi[0], hi[1], hi[2]};
   for (int a = 0; a < d; ++a) {
-    if (h->md.has_nbr[2 * a]) ilo[a] = 1;
-    if (h->md.has_nbr[2 * a + 1]) ihi[a] = hi[a] - 1;
+    if (has_nbr[2 * a]) ilo[a] = 1;
+    if (has_nbr[2 * a + 1]) ihi[a] = hi[a] - 1;
     if (ihi[a] < ilo[a]) ihi[a] = ilo[a];
   }
   if (region == SG_REGION_INTERIOR) {
@@ -729,6 +773,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.lam0 = h->lam0;
   a.mu0 = h->mu0;
   a.per_cell = h->per_cell;
+  a.rho2 = (kind == 0 && mode == 1) ? h->rho2_d : nullptr;
   a.mode = mode;
   a.c_self = c_self;
   a.c_aux = c_aux;
@@ -740,6 +785,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     a.nbox = 0;
     for (const Box& b : boxes) {
       if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;
+      if (a.nbox >= SG_MAX_BOXES) return fail(h, SG_ERR_STATE, "region has more boxes than a launch can carry");
       for (int k = 0; k < 3; ++k) {
         a.boxes_o[a.nbox][k] = b.o[k];
         a.boxes_n[a.nbox][k] = b.n[k];
@@ -805,7 +851,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
 // the source lives on single nodes: added to each part of a split stage right after the launch
 // that wrote it (INTERIOR + BOUNDARY: all of it after the second launch)
 static int add_source(sg_handle* h, int field, double coef, int region = SG_REGION_ALL) {
-  if (h->src_nnz == 0 || h->src_step >= h->src_nsteps || region == SG_REGION_INTERIOR) return SG_OK;
+  if (h->src_nnz == 0 || (!h->src_static && h->src_step >= h->src_nsteps) || region == SG_REGION_INTERIOR) return SG_OK;
   const int d = h->cfg.dim;
   int64_t off = 0, cnt = h->src_nnz;
   if (region == SG_REGION_FIRST) cnt = h->src_nfirst;
@@ -814,7 +860,7 @@ static int add_source(sg_handle* h, int field, double coef, int region = SG_REGI
     cnt = h->src_nnz - h->src_nfirst;
   }
   if (cnt == 0) return SG_OK;
-  const double* vals = h->src_values + ((size_t)h->src_step * h->src_nnz + off) * d * d;
+  const double* vals = h->src_values + ((size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz + off) * d * d;
   int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
   return SG_OK;
@@ -831,7 +877,10 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
       if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
       return rc;
     case SG_STAGE_U1:
-      // explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (elastic.py:341-345, :354-356)
+      // explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (elastic.py:341-345, :354-356);
+      // sg_set_density(physical = 1): u1 = u0 + (dt*uh1 + dt^3/24*uh2)/rho; per-cell density: factors in rho2
+      if (h->rho2_d) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt, c3, region);
+      if (h->rho_physical) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt / h->rho, c3 / h->rho, region);
       return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, h->rho, dt, c3, region);
     case SG_STAGE_SH1:
       rc = run_op(h, 1, SG_FIELD_U, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
@@ -853,7 +902,10 @@ static int resolve_timing(sg_handle* h) {
   for (size_t k = 0; k < h->ev_stage.size(); ++k) {
     float ms = 0;
     HIPCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]));
-    h->counters.kernel_ms[h->ev_stage[k]] += ms;
+    if (h->ev_stage[k] == 6)
+      h->counters.halo_pack_ms += ms;
+    else
+      h->counters.kernel_ms[h->ev_stage[k]] += ms;
   }
   h->ev_stage.clear();
   return SG_OK;
@@ -1007,16 +1059,48 @@ int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes) {
   return SG_OK;
 }
 
+// pack launches are timed like stage launches (event pairs resolved lazily; stage id 6 = halo pack)
+static int pack_begin(sg_handle* h, size_t& k) {
+  k = h->ev_stage.size();
+  if (!h->timing) return SG_OK;
+  if (k >= 8192) {
+    int rc = resolve_timing(h);
+    if (rc != SG_OK) return rc;
+    k = 0;
+  }
+  while (h->ev_pool.size() < 2 * k + 2) {
+    hipEvent_t e;
+    HIPCHECK(h, hipEventCreate(&e));
+    h->ev_pool.push_back(e);
+  }
+  HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k], h->stream));
+  return SG_OK;
+}
+
+static int pack_end(sg_handle* h, size_t k, size_t nbytes) {
+  if (h->timing) {
+    HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k + 1], h->stream));
+    h->ev_stage.push_back(6);
+  }
+  h->counters.halo_pack_launches += 1;
+  h->counters.halo_bytes_packed += (int64_t)nbytes;
+  return SG_OK;
+}
+
 int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out) {
   if (!h || !dev_out || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   const int d = h->cfg.dim;
   int comps = field_is_stress(field) ? d * d : d;
   double* out = (double*)dev_out;
-  int rc = launch_pack(h->md_dev, h->md, h->field[field], comps, 1, &side, &out,
-                       (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
+  size_t k = 0, nb = 0;
+  int rc = pack_begin(h, k);
+  if (rc != SG_OK) return rc;
+  rc = launch_pack(h->md_dev, h->md, h->field[field], comps, 1, &side, &out,
+                   (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
-  return SG_OK;
+  (void)sg_halo_bytes(h, field, side, &nb);
+  return pack_end(h, k, nb);
 }
 
 int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out) {
@@ -1032,10 +1116,30 @@ int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out) {
       outs[n] = (double*)dev_out[s];
       n += 1;
     }
-  int rc = launch_pack(h->md_dev, h->md, h->field[field], comps, n, sides, outs,
-                       (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
+  size_t k = 0, total = 0;
+  int rc = pack_begin(h, k);
+  if (rc != SG_OK) return rc;
+  rc = launch_pack(h->md_dev, h->md, h->field[field], comps, n, sides, outs,
+                   (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
+  for (int i = 0; i < n; ++i) {
+    size_t nb = 0;
+    (void)sg_halo_bytes(h, field, sides[i], &nb);
+    total += nb;
+  }
+  return pack_end(h, k, total);
+}
+
+int sg_get_sym(const sg_handle* h, int* sym) {
+  if (!h || !sym) return SG_ERR_ARG;
+  *sym = h->sym ? 1 : 0;
   return SG_OK;
+}
+
+int sg_leave_sym(sg_handle* h) {
+  if (!h) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return leave_sym_mode(h);
 }
 
 int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in) {
@@ -1088,6 +1192,26 @@ int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out
     std::memcpy(out, v.data(), nbytes);
   }
   return (int64_t)v.size();
+}
+
+int sg_region_boxes(const sg_config* cfg, int region, int32_t* boxes, int max_boxes) {
+  if (!cfg || !boxes || cfg->dim < 1 || cfg->dim > 3 || region < 0 || region > 4 || max_boxes < 0) return SG_ERR_ARG;
+  int32_t n[3] = {1, 1, 1}, has_nbr[6] = {0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < cfg->dim; ++a) n[a] = cfg->n[a];
+  for (int s2 = 0; s2 < 2 * cfg->dim; ++s2) has_nbr[s2] = (cfg->nbr_mask >> s2) & 1;
+  std::vector<Box> out;
+  region_boxes(cfg->dim, n, has_nbr, region, out);
+  int cnt = 0;
+  for (const Box& b : out) {
+    if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;
+    if (cnt < max_boxes)
+      for (int k = 0; k < 3; ++k) {
+        boxes[6 * cnt + k] = b.o[k];
+        boxes[6 * cnt + 3 + k] = b.n[k];
+      }
+    cnt += 1;
+  }
+  return cnt;
 }
 
 int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi) {

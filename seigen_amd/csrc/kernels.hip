@@ -221,8 +221,14 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
 #pragma unroll
           for (int i = 0; i < DIM; ++i) A.out[o + i] = acc[i];
         } else {
+          double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+          if (A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
+            cs = A.rho2[2 * g];
+            ca *= A.rho2[2 * g + 1];
+            cn *= A.rho2[2 * g + 1];
+          }
 #pragma unroll
-          for (int i = 0; i < DIM; ++i) A.out[o + i] = A.c_self * A.out[o + i] + A.c_aux * A.aux[o + i] + A.c_new * acc[i];
+          for (int i = 0; i < DIM; ++i) A.out[o + i] = cs * A.out[o + i] + ca * A.aux[o + i] + cn * acc[i];
         }
       }
     } else {

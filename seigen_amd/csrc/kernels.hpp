@@ -6,6 +6,9 @@
 
 namespace sg {
 
+// SG_REGION_FIRST of a 3-D block with neighbours on all six sides = half of the interior + six shell slabs
+constexpr int SG_MAX_BOXES = 7;
+
 struct StageArgs {
   const double* in;    // stress for F, velocity for G           [cell][node][comp]
   double* out;         // result, or in-place target of a fused combine
@@ -24,14 +27,17 @@ struct StageArgs {
   const double* mu;
   double lam0, mu0;
   double c_self, c_aux, c_new;  // mode 1: out = c_self*out + c_aux*aux + c_new*rhs
+  // F, mode 1, per-cell density: rho2[cell][2] = {factor replacing c_self, factor multiplying c_aux and c_new}
+  // (reference update: {rho, 1}; physical update: {1, 1/rho}); null: the scalars above
+  const double* rho2;
   int32_t mode;                 // 0: out = rhs
   int32_t per_cell;
   int32_t box_o[3], box_n[3];   // region of cubes covered by this launch (generic kernel: one box per launch)
-  // MFMA / lane kernels: one launch covers up to 6 disjoint boxes (a boundary shell); `spread` deals
+  // MFMA / lane kernels: one launch covers up to SG_MAX_BOXES disjoint boxes (a boundary shell + half an interior); `spread` deals
   // the items round-robin over all waves instead of one contiguous range per XCD, because a shell's
   // active items are a few contiguous runs that would otherwise land on one XCD
   int32_t nbox;
-  int32_t boxes_o[6][3], boxes_n[6][3];
+  int32_t boxes_o[SG_MAX_BOXES][3], boxes_n[SG_MAX_BOXES][3];
   int32_t spread;
   const int32_t* item_list;  // a region of a split stage: its active items (cell group * ncls + class), else null
   int32_t nlist;

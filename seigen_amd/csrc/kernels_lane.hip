@@ -178,6 +178,12 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       if (A.sponge_slot != nullptr && L.active) sslot = A.sponge_slot[e];
       const bool any_sponge = __any(sslot >= 0);
       const long ubase = ((g * NCLS + k) * (long)ND) * DIM * 64 + lane;
+      double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
+        cs = A.rho2[2 * e];
+        ca *= A.rho2[2 * e + 1];
+        cn *= A.rho2[2 * e + 1];
+      }
 #pragma unroll
       for (int i = 0; i < DIM; ++i) {
         double q[ND][DIM];  // T_ij (j = 0..DIM-1) at every node, all requested at once
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
 #pragma unroll
             for (int b = 0; b < ND; ++b) acc -= B[b] * ua[b];
           }
-          if (MODE == 1) acc = A.c_self * po[a] + A.c_aux * pa[a] + A.c_new * acc;
+          if (MODE == 1) acc = cs * po[a] + ca * pa[a] + cn * acc;
           if (L.active) out[ubase + (a * DIM + i) * 64] = acc;
         }
       }

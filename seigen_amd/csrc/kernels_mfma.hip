@@ -823,6 +823,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345).
     //      All loads first (results built in place in the accumulators), all stores last: see G.
     if (MODE == 1) {
+      double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      if (A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
+        cs = A.rho2[2 * e];
+        ca *= A.rho2[2 * e + 1];
+        cn *= A.rho2[2 * e + 1];
+      }
       // every old value of the item is requested before the first one is used: one memory latency
       // per item instead of one per row tile (the lifts' registers are free by now)
       double po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[NSM][3], pas[NSM][3];
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            double v = A.c_self * po[t][reg][i] + A.c_aux * pa[t][reg][i] + A.c_new * acc[i][t][reg];
+            double v = cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg];
             asm volatile("" : "+v"(v));
             acc[i][t][reg] = v;
           }
@@ -861,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       for (int t = 0; t < NSM; ++t)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          accs[i][t] = A.c_self * pos[t][i] + A.c_aux * pas[t][i] + A.c_new * accs[i][t];
+          accs[i][t] = cs * pos[t][i] + ca * pas[t][i] + cn * accs[i][t];
           asm volatile("" : "+v"(accs[i][t]));
         }
     }

@@ -105,6 +105,10 @@ class ElasticLF4(object):
             self.source_function = None
             self.source_expression = None
             self.density = None
+            # False: the explicit reference's update u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (only rhs(form_u1)
+            # is kept, elastic.py:341-345, :354-356); True: u1 = u0 + (...)/rho, what the implicit form
+            # solves (elastic.py:175-178).  Identical for rho = 1, which every reference test uses.
+            self.density_physical = False
             self.dt = None
             self.mu = None
             self.l = None
@@ -208,7 +212,12 @@ class ElasticLF4(object):
             for name in ("density", "dt", "mu", "l"):
                 if getattr(self, name) is None:
                     raise ValueError("ElasticLF4.%s must be set before run()" % name)
-            self._block.set_params(self.density, self.dt, self.l, self.mu)
+            # density, l, mu: floats as in the reference's tests, or one value per cell of this
+            # rank's block (build-defined heterogeneous extension)
+            rho = np.atleast_1d(np.asarray(self.density, dtype=np.float64)).ravel()
+            self._block.set_params(float(rho[0]), self.dt, self.l, self.mu)
+            if rho.size > 1 or self.density_physical:
+                self._block.set_density(rho if rho.size > 1 else float(rho[0]), self.density_physical)
             if self.absorption_function is not None:
                 self._block.set_absorption(self.absorption_function.dat.data_cells,
                                            self.absorption_function.function_space().degree)
@@ -235,39 +244,44 @@ class ElasticLF4(object):
         return empty_loop_context
 
     # ---- source handling -----------------------------------------------------------------------
+    # a support this large means the source is not the localised kind the sparse table is meant for
+    SOURCE_TABLE_MAX_BYTES = 2 << 30
+
     def _source_table(self, times):
-        """Sparse per-step source values (nodes, values[nsteps, nnz, d, d]).
+        """Sparse source values: (nodes, values[nsteps or 1, nnz, d, d], static).
 
         The reference re-interpolates ``source_expression`` into ``source_function``
         at every step (``elastic.py:285-288``).  The same nodal values are computed
-        here for all steps up front, but only on the support of the source (found
-        by sampling the expression over the run), and uploaded once."""
+        here for all steps up front, but only on the support of the source, and uploaded
+        once.  The support is found with ``t`` treated as unknown
+        (``Expression.support_mask``): every node where the expression can be non-zero at
+        ANY time - a time-windowed source is not missed, a source whose position depends on
+        ``t`` gets the whole region it can reach.  A source without ``t`` is one time slice."""
         expr = self.source_expression
-        X = self.S.node_coords()
         nsteps = len(times)
+        d = self.dimension
         if expr is None or not hasattr(expr, "_params") or "t" not in expr._params:
             vals = self.source_function.dat.data_cells
             nz = np.nonzero(np.abs(vals).reshape(vals.shape[0] * vals.shape[1], -1).max(axis=1) > 0)[0]
-            v = vals.reshape(-1, self.dimension, self.dimension)[nz]
-            return nz, np.broadcast_to(v, (nsteps,) + v.shape)
+            v = vals.reshape(-1, d, d)[nz]
+            return nz, v[None], True
         t_keep = expr.t
-        sample = sorted(set(range(0, nsteps, max(1, nsteps // 5))) | {0, nsteps - 1})
         nz, Xs = [], []
         for cell0, X in self.S.node_coords_chunks():      # slab by slab: bounded host memory
-            support = np.zeros(X.shape[0] * X.shape[1], dtype=bool)
-            for k in sample:
-                expr.t = times[k]
-                support |= expr.nonzero_mask(X).reshape(-1)
-            idx = np.nonzero(support)[0]
+            idx = np.nonzero(expr.support_mask(X).reshape(-1))[0]
             nz.append(idx + cell0 * X.shape[1])
             Xs.append(X.reshape(-1, X.shape[-1])[idx])
         nz, Xs = np.concatenate(nz), np.concatenate(Xs)
-        values = np.zeros((nsteps, len(nz), self.dimension, self.dimension))
+        if nsteps * len(nz) * d * d * 8 > self.SOURCE_TABLE_MAX_BYTES:
+            raise MemoryError("the source can be non-zero at %d nodes over %d steps: its table would take %.1f GB; "
+                              "the sparse per-step source of libseigen_hip is meant for localised sources"
+                              % (len(nz), nsteps, nsteps * len(nz) * d * d * 8 / 1e9))
+        values = np.zeros((nsteps, len(nz), d, d))
         for k in range(nsteps):
             expr.t = times[k]
             values[k] = expr.evaluate(Xs)
         expr.t = t_keep
-        return nz, values
+        return nz, values, False
 
     # ---- time loop (elastic.py:267-315) ----------------------------------------------------------
     def step_times(self, T):
@@ -289,6 +303,14 @@ class ElasticLF4(object):
             self._block.step(nsteps)
         self._step_index += nsteps
 
+    def _agree_on_stress_storage(self):
+        """A block leaves symmetric-stress storage when IT is handed a non-symmetric stress or
+        source; its neighbours read its traces, so all blocks of the mesh must store alike."""
+        if self.mesh.partition.world > 1:
+            mine = 0 if self._block.is_sym() else 1
+            if allreduce_sum(mine) > 0 and not mine:
+                self._block.leave_sym()
+
     def run(self, T):
         """Run the elastic wave simulation until t = T; returns (u1, s1)."""
         # Write out the initial condition.
@@ -301,10 +323,11 @@ class ElasticLF4(object):
             times = self.step_times(T)
             if self.source:
                 with timed_region('source term update'):
-                    nodes, values = self._source_table(times)
-                    self._block.set_source(nodes, values)
+                    nodes, values, static = self._source_table(times)
+                    self._block.set_source(nodes, values, static=static)
             else:
                 self._block.set_source([], None)
+            self._agree_on_stress_storage()
             with self.loop_context():
                 if self.output:
                     for t in times:

@@ -223,6 +223,51 @@ def _eval(node, env):
     return np.where(ops[k](a, b), 1.0, 0.0)
 
 
+def _depends(node, names):
+    """Does the expression tree mention one of `names`?"""
+    k = node[0]
+    if k == "num":
+        return False
+    if k == "id":
+        return node[1] in names
+    if k == "index":
+        return node[1] in names or _depends(node[2], names)
+    if k == "call":
+        return any(_depends(a, names) for a in node[2])
+    return any(_depends(c, names) for c in node[1:] if isinstance(c, tuple))
+
+
+def _may_be_nonzero(node, env, unknown, shape):
+    """Conservative support of an expression whose parameters `unknown` may take any value:
+    bool array of `shape`, True wherever the value can be non-zero for some value of them.
+    Sub-expressions that do not mention an unknown are evaluated exactly; a ternary whose
+    condition is known selects per point; products intersect, sums unite."""
+    if not _depends(node, unknown):
+        v = np.asarray(_eval(node, env))
+        return np.broadcast_to(v != 0, shape)
+    k = node[0]
+    if k == "?:":
+        a = _may_be_nonzero(node[2], env, unknown, shape)
+        b = _may_be_nonzero(node[3], env, unknown, shape)
+        if _depends(node[1], unknown):
+            # the condition can hold only where it "may be non-zero"; that it may fail is assumed everywhere
+            return (_may_be_nonzero(node[1], env, unknown, shape) & a) | b
+        c = np.broadcast_to(_truth(_eval(node[1], env)), shape)
+        return np.where(c, a, b)
+    if k == "neg":
+        return _may_be_nonzero(node[1], env, unknown, shape)
+    if k == "*":
+        return _may_be_nonzero(node[1], env, unknown, shape) & _may_be_nonzero(node[2], env, unknown, shape)
+    if k == "/":
+        return _may_be_nonzero(node[1], env, unknown, shape)
+    if k in ("+", "-"):
+        return _may_be_nonzero(node[1], env, unknown, shape) | _may_be_nonzero(node[2], env, unknown, shape)
+    if k == "&&":
+        return _may_be_nonzero(node[1], env, unknown, shape) & _may_be_nonzero(node[2], env, unknown, shape)
+    # identifiers, calls, comparisons, ||, ! of something unknown: anything is possible
+    return np.ones(shape, dtype=bool)
+
+
 def _shape_of(code):
     if isinstance(code, str):
         return ()
@@ -290,4 +335,16 @@ class Expression(object):
                     mask[...] = True
             else:
                 mask |= np.broadcast_to(v, mask.shape) != 0
+        return mask
+
+    def support_mask(self, X, unknown=("t",)):
+        """X: [..., dim] -> bool [...]: True wherever some component can be non-zero for SOME value of
+        the parameters `unknown` (a superset of the support at every instant; exact for the usual
+        `spatial condition ? f(t) : 0` sources, explosive_source_lf4.py:36-40)."""
+        X = np.asarray(X, dtype=np.float64)
+        env = {k: v for k, v in self._params.items() if k not in unknown}
+        env["x"] = [np.ascontiguousarray(X[..., i]) for i in range(X.shape[-1])]
+        mask = np.zeros(X.shape[:-1], dtype=bool)
+        for key in set(self._keys):
+            mask |= _may_be_nonzero(self._asts[self._keys.index(key)], env, set(unknown), mask.shape)
         return mask

@@ -72,8 +72,8 @@ class ExplosiveSourceLF4():
         el.setup()
         times = el.step_times(T)
         if el.source:
-            nodes, values = el._source_table(times)
-            el.block.set_source(nodes, values)
+            nodes, values, static = el._source_table(times)
+            el.block.set_source(nodes, values, static=static)
         locs = [locate(el.U, r) for r in receivers]
         out_t, out_v = [], []
         done = 0

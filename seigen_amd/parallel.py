@@ -104,6 +104,28 @@ class HaloExchanger(object):
             # (non-blocking) stream: make sure no fill can land after the first pack
             torch.cuda.synchronize(device)
         self.bytes_sent = 0
+        self.reset_stats(False)
+
+    # ---- instrumentation: what PyOP2's ParLoopHaloEnd timer measures in the reference (tests/tiling/utils.py:144)
+    def reset_stats(self, timing=False):
+        """timing=True: measure how long the consumer waits for each exchange - on the launch stream
+        (event pair around the wait) with a device-aware transport, on the host otherwise."""
+        self.timing = bool(timing)
+        self.exchanges = 0
+        self._wait_host_s = 0.0
+        self._wait_events = []
+        self._wait_dev_ms = 0.0
+
+    def _resolve_wait_events(self):
+        for a, b in self._wait_events:
+            b.synchronize()
+            self._wait_dev_ms += a.elapsed_time(b)
+        self._wait_events = []
+
+    def stats(self):
+        self._resolve_wait_events()
+        return {"exposed_wait_ms": self._wait_dev_ms + 1e3 * self._wait_host_s, "exchanges": self.exchanges,
+                "bytes_sent": self.bytes_sent}
 
     def start(self, field):
         """Pack the block-side traces of `field` and post the sends / receives."""
@@ -148,6 +170,26 @@ class HaloExchanger(object):
         kind, reqs = pending
         if not self.sides:
             return
+        self.exchanges += 1
+        if self.timing and (self.staged or self.stream is None):
+            import time
+            t0 = time.perf_counter()
+            try:
+                return self._finish(kind, reqs)
+            finally:
+                self._wait_host_s += time.perf_counter() - t0
+        if self.timing:
+            a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+            self._finish(kind, reqs)
+            b.record(self.stream)
+            self._wait_events.append((a, b))
+            if len(self._wait_events) >= 4096:
+                self._resolve_wait_events()
+            return
+        return self._finish(kind, reqs)
+
+    def _finish(self, kind, reqs):
         if self.staged:
             if reqs is not None:
                 reqs.synchronize()          # the copies out are done (later launches keep running)

@@ -74,3 +74,38 @@ def test_bench_two_ranks_one_gpu(gpu):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["cells"] == 2 * 16 ** 3 * 6
     assert "cpu_baseline" not in out
+    _check_halo_block(out, 2)
+
+
+def _check_halo_block(out, world):
+    h = out["halo"]
+    assert h["transport"] == "host-staged/gloo" and h["exchanges_per_step"] == 6
+    for key in ("pack_ms_per_step", "bytes_sent_per_step", "exposed_wait_ms_per_step", "kernel_ms_per_step"):
+        assert len(h[key]) == world and all(v >= 0 for v in h[key]), (key, h[key])
+    # 1x1x2 grid of 16^3 blocks, P4: one side of 16*16*2 facets * 15 nodes; 3 stress (9 comps) + 3 velocity (3 comps) exchanges
+    assert all(v == 16 * 16 * 2 * 15 * (3 * 9 + 3 * 3) * 8 for v in h["bytes_sent_per_step"]), h["bytes_sent_per_step"]
+    assert all(v > 0 for v in h["pack_ms_per_step"])
+    # per-kernel accounting counts every stage once per step although a split stage is two launches
+    r = out["roofline"]
+    assert all(v["launches"] % out["steps"] == 0 for v in r["kernels"].values())
+    assert 0 < r["frac_physical"] < r["frac"] < 1
+
+
+def test_bench_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no torchrun environment (how the driver starts N = 1) must start
+    the two ranks itself and relay rank 0's line; a failing rank must fail the command."""
+    env = dict(os.environ, SEIGEN_DIST_BACKEND="gloo", SEIGEN_HIP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cubes", "16"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["block_grid"] == [1, 1, 2]
+    _check_halo_block(out, 2)
+    # a rank that cannot run (degree 9 does not exist) makes the whole command fail
+    r = subprocess.run(cmd + ["--degree", "9"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -72,6 +72,45 @@ def test_explosive_source_sponge_and_source(gpu):
     assert np.abs(u1.dat.data_cells - ou).max() / max(np.abs(ou).max(), 1e-300) < 1e-9
 
 
+def test_time_windowed_and_static_sources(gpu):
+    """Sources the reference would simply re-interpolate every step (elastic.py:285-288): one that is
+    non-zero during four steps only - zero at t = 0, at the last step and at any coarse sampling of the
+    run - and one without time dependence (uploaded as a single slice, sg_set_source nsteps = -1)."""
+    from seigen_amd import ElasticLF4, Expression, Function, RectangleMesh
+    nx, ny, P, dt, nsteps = 12, 8, 2, 1e-3, 40
+    box = "x[0] >= 2.5 && x[0] <= 6.0 && x[1] >= 3.0 && x[1] <= 5.5"
+    for kind in ("window", "static"):
+        mesh = RectangleMesh(nx, ny, 12.0, 8.0)
+        el = ElasticLF4.create(mesh, "DG", P, dimension=2, solver="explicit", output=False)
+        el.density, el.mu, el.l, el.dt = 1.0, 3.0, 2.0, dt
+        if kind == "window":
+            code = "%s && t >= 0.0165 && t <= 0.0205 ? 50.0*x[0] : 0.0" % box       # steps 17..20
+            el.source_expression = Expression(((code, "0.0"), ("0.0", code)), t=0)
+        else:
+            code = "%s ? 2.0 + x[1] : 0.0" % box
+            el.source_expression = Expression(((code, "0.0"), ("0.0", code)))
+        el.source_function = Function(el.S)
+        el.source = el.source_expression
+        u1, s1 = el.run(nsteps * dt * (1 + 1e-9))
+
+        m = omesh.RectangleMesh(nx, ny, 12.0, 8.0)
+        orc = OracleLF4(m, P)
+        orc.density, orc.mu, orc.l, orc.dt = 1.0, 3.0, 2.0, dt
+        X = m.node_coords(P)
+        inbox = (X[..., 0] >= 2.5) & (X[..., 0] <= 6.0) & (X[..., 1] >= 3.0) & (X[..., 1] <= 5.5)
+        pat = np.zeros(X.shape[:-1] + (2, 2))
+        if kind == "window":
+            pat[inbox, 0, 0] = pat[inbox, 1, 1] = 50.0 * X[inbox][:, 0]
+            orc.source = lambda t: pat if 0.0165 <= t <= 0.0205 else None
+        else:
+            pat[inbox, 0, 0] = pat[inbox, 1, 1] = 2.0 + X[inbox][:, 1]
+            orc.source = lambda t: pat
+        orc.run(nsteps * dt * (1 + 1e-9))
+        assert orc.nsteps == nsteps and np.abs(orc.s1).max() > 1e-3
+        assert rel_err(u1.dat.data_cells, orc.u1) < 1e-10, kind
+        assert rel_err(s1.dat.data_cells, orc.s1) < 1e-10, kind
+
+
 def test_per_cell_material(gpu):
     """Build-defined heterogeneous extension: each cell scales its own g by its own (lambda, mu)."""
     from seigen_amd import _lib
@@ -251,6 +290,10 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False):
     (3, 4, (4, 2, 4), (2, 1, 2)),
     (3, 4, (2, 4, 4), (1, 2, 2)),
     (3, 3, (4, 3, 2), (2, 1, 1)),
+    # 27 blocks: the centre block has neighbours on all six sides, so its FIRST region is seven
+    # boxes (half an interior + six slabs): MFMA kernels (P3) and generic kernels (P1)
+    (3, 3, (9, 9, 9), (3, 3, 3)),
+    (3, 1, (7, 8, 9), (3, 3, 3)),
 ])
 @pytest.mark.parametrize("pipelined", [True, False])
 def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):

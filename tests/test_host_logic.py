@@ -210,6 +210,38 @@ def test_expression_parser():
         Expression("foo*x[0]").evaluate(X)
 
 
+def test_source_support_with_time_unknown():
+    """The per-step source table (seigen_amd/elastic.py _source_table; the reference re-interpolates
+    at every step, elastic.py:285-288) is built on Expression.support_mask: where the source CAN be
+    non-zero at some time.  A source that is zero at every sampled instant must not be lost."""
+    rng = np.random.default_rng(1)
+    X = rng.uniform(0, 10, (50, 6, 2))
+    box = "x[0] >= 2 && x[0] <= 5 && x[1] >= 1 && x[1] <= 4"
+    inbox = (X[..., 0] >= 2) & (X[..., 0] <= 5) & (X[..., 1] >= 1) & (X[..., 1] <= 4)
+    ricker = "(-1.0 + 2*a*pow(t - 0.3, 2))*exp(-a*pow(t - 0.3, 2))"
+    # the reference's shape: spatial condition ? f(t) : 0  -> exactly the box
+    e = Expression((("%s ? %s : 0.0" % (box, ricker), "0.0"), ("0.0", "%s ? %s : 0.0" % (box, ricker))), a=159.42, t=0)
+    np.testing.assert_array_equal(e.support_mask(X), inbox)
+    # time window inside the condition: zero at t = 0 (and at any handful of samples), support still the box
+    e = Expression("%s && t >= 0.30 && t <= 0.31 ? 1.0 : 0.0" % box, t=0)
+    assert not e.nonzero_mask(X).any()
+    np.testing.assert_array_equal(e.support_mask(X), inbox)
+    # window as a factor
+    e = Expression("(%s ? 2.0 : 0.0) * (t >= 0.30 && t <= 0.31 ? sin(t) : 0.0)" % box, t=0)
+    np.testing.assert_array_equal(e.support_mask(X), inbox)
+    # a source whose position depends on t can reach every node of the strip it moves in
+    e = Expression("x[0] >= 10*t && x[0] <= 10*t + 1 && x[1] <= 4 ? 1.0 : 0.0", t=0)
+    np.testing.assert_array_equal(e.support_mask(X), X[..., 1] <= 4)
+    # no t at all: support = where it is non-zero
+    e = Expression("%s ? 3.0 : 0.0" % box)
+    np.testing.assert_array_equal(e.support_mask(X), inbox)
+    # support is a superset of the instantaneous non-zero set at any time
+    e = Expression("%s ? cos(7*t)*x[0] : 0.0" % box, t=0)
+    for t in (0.0, 0.1, 0.2243, 1.7):
+        e.t = t
+        assert not (e.nonzero_mask(X) & ~e.support_mask(X)).any()
+
+
 def test_function_interpolate_and_assign():
     mesh = UnitSquareMesh(2, 2)
     U = VectorFunctionSpace(mesh, "DG", 2)
@@ -249,6 +281,66 @@ def test_partition_covers_mesh():
         assert (seen == 1).all()
 
 
+def _region_boxes(dim, n, mask, region):
+    cfg = _lib.SgConfig()
+    cfg.dim, cfg.degree = dim, 1
+    for a in range(3):
+        cfg.n[a] = n[a] if a < dim else 1
+        cfg.h[a] = 1.0
+    cfg.nbr_mask = mask
+    buf = (C.c_int32 * (6 * 16))()
+    cnt = lib().sg_region_boxes(C.byref(cfg), region, buf, 16)
+    assert 0 <= cnt <= 16
+    return [tuple(buf[6 * i + k] for k in range(6)) for i in range(cnt)]
+
+
+@pytest.mark.parametrize("dim,n", [(3, (6, 5, 7)), (3, (2, 2, 2)), (3, (16, 3, 1)), (2, (9, 4)), (1, (5,))])
+def test_region_boxes_partition_the_block_for_every_neighbour_mask(dim, n):
+    """The regions of a split stage (include/seigen_hip.h, enum sg_region) for EVERY combination of
+    block sides with a neighbour, all six included (a 3x3x3 process grid's centre block): the boxes
+    of a region are disjoint, INTERIOR + BOUNDARY = FIRST + SECOND = ALL, the shell is exactly the
+    cubes with a neighbour across one of their faces, and no region needs more boxes than a stage
+    launch can carry (SG_MAX_REGION_BOXES; api.cpp refuses beyond that)."""
+    hdr = open(os.path.join(ROOT, "include", "seigen_hip.h")).read()
+    max_boxes = int(re.search(r"#define SG_MAX_REGION_BOXES (\d+)", hdr).group(1))
+    full = tuple(n) + (1,) * (3 - dim)
+    for mask in range(1 << (2 * dim)):
+        cover = {}
+        for region in range(5):
+            boxes = _region_boxes(dim, n, mask, region)
+            assert len(boxes) <= max_boxes, (mask, region, boxes)
+            seen = np.zeros(full, dtype=int)
+            for (o0, o1, o2, n0, n1, n2) in boxes:
+                assert n0 > 0 and n1 > 0 and n2 > 0
+                seen[o0:o0 + n0, o1:o1 + n1, o2:o2 + n2] += 1
+            assert seen.max() <= 1, "boxes of a region overlap"
+            cover[region] = seen
+        assert (cover[0] == 1).all()
+        np.testing.assert_array_equal(cover[1] + cover[2], cover[0])
+        np.testing.assert_array_equal(cover[3] + cover[4], cover[0])
+        shell = np.zeros(full, dtype=int)
+        for a in range(dim):
+            idx = [slice(None)] * 3
+            if mask >> (2 * a) & 1:
+                idx[a] = 0
+                shell[tuple(idx)] = 1
+            if mask >> (2 * a + 1) & 1:
+                idx[a] = full[a] - 1
+                shell[tuple(idx)] = 1
+        if all(full[a] >= 2 for a in range(dim)):
+            np.testing.assert_array_equal(cover[2], shell)
+        assert (cover[3] >= cover[2]).all(), "FIRST contains the shell"
+    if dim == 3 and min(n) >= 3:
+        assert len(_region_boxes(dim, n, 0x3f, 3)) == 7      # half the interior + six slabs
+
+
+def test_unknown_solver_string_raises_value_error():
+    """seigen/elastic.py:64"""
+    from seigen_amd import ElasticLF4
+    with pytest.raises(ValueError, match="Unknown solver mode"):
+        ElasticLF4.create(UnitSquareMesh(2, 2), "DG", 1, dimension=2, solver="bogus", output=False)
+
+
 def test_step_count_follows_reference_loop():
     """t = dt; while t <= T + 1e-12: ...; t += dt   (seigen/elastic.py:279-313)"""
     from oracle.lf4 import count_steps
@@ -270,21 +362,33 @@ def test_helpers():
 
 
 def test_marmousi_lookup():
-    """seigen/marmousi.py:4-14: 384 x 122 nearest-cell lookup in marmhard.dat (depth counted from the
-    surface, with the reference's j = 0 slip fixed), and the derived per-cell Lame parameters."""
+    """seigen/marmousi.py:4-14: 384 x 122 nearest-cell lookup in marmhard.dat.  rule="reference" is
+    the reference's `data[i][-j]` evaluated literally (incl. its j = 0 slip to the surface row);
+    the default differs from it only at j = 0."""
     from seigen_amd import marmousi
     data = marmousi.load_model()
     assert data.shape == (384, 122) and data.min() == 1500.0 and data.max() == 5500.0
     H = marmousi.H
-    # a point in cell (i, j) from the bottom maps to data[i][121 - j]
-    assert marmousi.vp_at(data, 3.5 * H, 0.5 * H) == data[3, 121]
-    assert marmousi.vp_at(data, 100.2 * H, 121.9 * H) == data[100, 0]
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 383 * H, 400)
+    y = np.concatenate([rng.uniform(0, 121 * H, 380), rng.uniform(0, H, 20)])
+    want = np.array([data[int(np.floor(xx / 24.0))][-int(np.floor(yy / 24.0))] for xx, yy in zip(x, y)])
+    np.testing.assert_array_equal(marmousi.vp_at(data, x, y, rule="reference"), want)
+    fixed = marmousi.vp_at(data, x, y)
+    up = y >= H
+    np.testing.assert_array_equal(fixed[up], want[up])
+    np.testing.assert_array_equal(fixed[~up], data[np.floor(x[~up] / H).astype(int), 121])
+    assert marmousi.vp_at(data, 3.5 * H, 1.5 * H) == data[3, 121]
+    assert marmousi.vp_at(data, 100.2 * H, 120.9 * H) == data[100, 2]
     mesh = RectangleMesh(383, 121, 383 * H, 121 * H)
     V = VectorFunctionSpace(mesh, "DG", 1)
     lam, mu, vp = marmousi.cell_material(V, data)
     assert lam.shape == (383 * 121 * 2,)
     np.testing.assert_allclose(lam + 2 * mu, vp ** 2, rtol=1e-14)
     np.testing.assert_allclose(mu, vp ** 2 / 3.0, rtol=1e-14)
+    rho = marmousi.gardner_density(vp)
+    lam2, mu2, _ = marmousi.cell_material(V, data, density=marmousi.gardner_density)
+    np.testing.assert_allclose(lam2 + 2 * mu2, rho * vp ** 2, rtol=1e-14)
 
 
 def test_vtu_stream_round_trip(tmp_path):

@@ -34,8 +34,8 @@ def timed(elastic, steps, warmup):
     blk = elastic.block
     if elastic.source:
         times = [elastic.dt * (k + 1) for k in range(steps + warmup)]
-        nodes, values = elastic._source_table(times)
-        blk.set_source(nodes, values)
+        nodes, values, static = elastic._source_table(times)
+        blk.set_source(nodes, values, static=static)
     else:
         blk.set_source([], None)
     blk.step(warmup)
