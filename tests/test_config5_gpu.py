@@ -141,7 +141,7 @@ def test_config5_full_size_time_reversal_heterogeneous(gpu):
     mesh = RectangleMesh(NX - 1, NY - 1, (NX - 1) * H, (NY - 1) * H)           # seigen/marmousi.py:16-21
     el = ElasticLF4.create(mesh, "DG", 3, dimension=2, solver="explicit", output=False)
     lam, mu, vp = cell_material(el.U, density=gardner_density)
-    assert vp.min() == 1500.0 and vp.max() == 5500.0 and len(np.unique(vp)) > 100
+    assert 1500.0 <= vp.min() < 1600.0 and vp.max() == 5500.0 and len(np.unique(vp)) > 100
     el.density, el.density_physical, el.l, el.mu = gardner_density(vp), True, lam, mu
     el.dt = dt = cfl_dt(H, float(vp.max()), 0.05)
     el.setup()
