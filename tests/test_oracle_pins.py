@@ -196,16 +196,26 @@ def _load_traces():
     return d["times"], d["traces"], refs
 
 
+def _lsq_ratio(ours, ref, w):
+    return float(np.dot(ours[w], ref[w]) / np.dot(ref[w], ref[w]))
+
+
 def test_ref_c_traces():
     """tests/explosive_source/REF-C1..3 (external code, compared by eye in uy.py:45-80) against
     the oracle's run of explosive_source_lf4.py with dt = 0.001 (uy.py:25).
-      C1 (45, 149), 0.25 m from the source node: the direct pulse matches to a few per cent in
-         amplitude and 5 ms in time;
-      C2 (90, 149), C3 (140, 149): arrival times and wave forms match (correlation), amplitudes
-         are 1.4-2.3x the reference's: the far field scales with the moment of a nodal point
-         source, which depends on the mesh (structured here; the reference data come from
-         another code and mesh).  Late-time differences at C2 are reflections off the abrupt
-         sponge of explosive_source_lf4.py:45."""
+      C1 (45, 149), inside the source cell: the direct pulse matches to a few per cent in
+         amplitude and 5 ms in time.
+      C2 (90, 149), C3 (140, 149): arrival times and wave forms match (correlation >= 0.97); the
+         least-squares amplitude ratio to the reference is the SAME at both (2.24 and 2.18) - so it
+         is no propagation effect (a 2-D/3-D spreading mismatch would grow like sqrt(r): 1.45x
+         from C2 to C3) - and equals, to 4-7 %, the integral of the nodally interpolated source:
+         the indicator of the 1 m x 1 m box of explosive_source_lf4.py:36-38 hits two DG2 nodes of
+         the 2.5 m mesh, whose basis functions integrate to 2 |K| / 3 = 2.083 m^2, not 1 m^2.
+         [upstream] the reference's own run interpolates the same way on the same mesh.
+         tools/refc_moment.py (profiles/r02/refc_moment.txt) repeats the run on the HIP path at
+         h = 2.5 and h = 1.25, where the integral drops to 0.52 m^2 and the far field to 0.78 of
+         REF-C: it follows the discretised source, not the mesh resolution.
+      Late-time differences at C2 are reflections off the abrupt sponge of explosive_source_lf4.py:45."""
     times, tr, refs = _load_traces()
     for r in refs:
         np.testing.assert_allclose(r[:, 0], times, atol=1e-9)
@@ -220,15 +230,20 @@ def test_ref_c_traces():
     assert np.linalg.norm(uy[0][w] - ry[0][w]) / np.linalg.norm(ry[0][w]) < 0.15
     # C1 records no x-motion in the reference (source x-position); ours is small
     assert np.abs(tr[w, 0, 0]).max() < 0.02 * np.abs(uy[0]).max()
-    # C2: P + Rayleigh arrival window
-    w = (times > 0.5) & (times < 1.45)
-    assert np.corrcoef(uy[1][w], ry[1][w])[0, 1] > 0.9
-    assert 1.2 < np.abs(uy[1][w]).max() / np.abs(ry[1][w]).max() < 2.4
-    # C3
-    w = (times > 1.0) & (times < 2.45)
-    assert np.corrcoef(uy[2][w], ry[2][w])[0, 1] > 0.9
-    assert 1.2 < np.abs(uy[2][w]).max() / np.abs(ry[2][w]).max() < 2.4
-    assert abs(times[w][np.abs(uy[2][w]).argmax()] - times[w][np.abs(ry[2][w]).argmax()]) < 0.05
+    # integral of the interpolated source per unit amplitude, from the oracle's own mass matrix
+    ex = harness.ExplosiveSource()
+    ops = ex.elastic.E.ops
+    area = float((ops.M @ ex.pattern[..., 0, 0].reshape(-1)).sum())
+    assert abs(area - 2.0 * 2.5 ** 2 / 2.0 / 3.0) < 1e-12 and int(ex.src_mask.sum()) == 2
+    # C2 / C3: P + Rayleigh arrival windows (the plot ranges of uy.py:65,78)
+    w2 = (times > 0.5) & (times < 1.45)
+    w3 = (times > 1.0) & (times < 2.45)
+    assert np.corrcoef(uy[1][w2], ry[1][w2])[0, 1] > 0.97
+    assert np.corrcoef(uy[2][w3], ry[2][w3])[0, 1] > 0.97
+    a2, a3 = _lsq_ratio(uy[1], ry[1], w2), _lsq_ratio(uy[2], ry[2], w3)
+    assert abs(a3 / a2 - 1.0) < 0.05, "the amplitude ratio must not depend on the distance"
+    assert abs(a2 / area - 1.0) < 0.12 and abs(a3 / area - 1.0) < 0.12, (a2, a3, area)
+    assert abs(times[w3][np.abs(uy[2][w3]).argmax()] - times[w3][np.abs(ry[2][w3]).argmax()]) < 0.05
     # quiet before the first arrival, as in the reference
     assert np.abs(uy[2][times < 0.9]).max() < 1e-3 * np.abs(uy[2]).max()
 
