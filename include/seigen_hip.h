@@ -179,8 +179,10 @@ int sg_apply_G(sg_handle* h, int u_in, int s_out, int use_source);
 
 /* ---- halo layer (replaces PyOP2's implicit halo exchange, elastic.py:404-436) ------- */
 /* Facet traces of `field` on block side `side` (2*axis + hi), packed as
- * [facet][facet-node][comp] with comp = dim (velocity) or dim*dim (stress),
- * written to the DEVICE buffer `dev_out` (caller-allocated, e.g. a torch tensor). */
+ * [facet][facet-node][dim]: the velocity components, or for a stress field the column
+ * T_i,axis (i < dim) - on an axis-aligned block side the only part of the neighbour's tensor that
+ * enters `avg(s0)*n` (elastic.py:206; SURVEY 8e "send T.n").  Written to the DEVICE buffer
+ * `dev_out` (caller-allocated, e.g. a torch tensor). */
 int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes);
 int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out);
 /* register the DEVICE buffer holding the neighbour block's packed traces of

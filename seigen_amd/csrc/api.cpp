@@ -1054,8 +1054,9 @@ int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes) {
   size_t n2 = 1;
   for (int a = 0; a < 3; ++a)
     if (a != axis) n2 *= (size_t)h->cfg.n[a];
-  size_t comps = field_is_stress(field) ? (size_t)d * d : (size_t)d;
-  *nbytes = n2 * h->md.halo_per_cube * h->re.nf * comps * sizeof(double);
+  // dim components per facet node for every field: a stress trace travels as T_i,axis (kernels.hip pack_one)
+  *nbytes = n2 * h->md.halo_per_cube * h->re.nf * (size_t)d * sizeof(double);
+  (void)field;
   return SG_OK;
 }
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
       const double* own = &sQ[(el * ND + sMd.fnode[f][b]) * NC];
       const double* nbr = nullptr;
       int axis = sMd.nb_axis[cls][f];
-      bool physical = false;
+      bool physical = false, ghost = false;
       if (axis < 0) {
         long ng = cube * NCLS + sMd.nb_cls[cls][f];
         nbr = A.in + (ng * ND + sMd.nb_node[cls][f][b]) * NC;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
           int side = 2 * axis + (dir > 0 ? 1 : 0);
           if (sMd.has_nbr[side]) {
             long slot = cube2d(axis, c, sMd.n) * sMd.halo_per_cube + sMd.face_ord[sMd.nb_cls[cls][f]][sMd.nb_face[cls][f]];
-            nbr = A.ghost[side] + (slot * NF + sMd.nb_fnode[cls][f][b]) * NC;
+            nbr = A.ghost[side] + (slot * NF + sMd.nb_fnode[cls][f][b]) * DIM;  // packed trace: DIM comps
+            ghost = true;
           } else {
             physical = true;
           }
@@ -140,8 +141,10 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
         for (int i = 0; i < DIM; ++i) {
           double s = 0.0;
           if (!physical) {
+            // a packed remote trace holds g_i = T_i,axis only; the columns j != axis meet cn_j = 0 on a
+            // block side, so any finite value (here g_i again) gives the same flux bit for bit
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) s += 0.5 * (own[i * DIM + j] + nbr[i * DIM + j]) * sMd.cn[cls][f][j];
+            for (int j = 0; j < DIM; ++j) s += 0.5 * (own[i * DIM + j] + nbr[ghost ? i : i * DIM + j]) * sMd.cn[cls][f][j];
           }
           fl[i] = s;
         }
@@ -331,13 +334,16 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
 }
 
 // ---- halo pack ------------------------------------------------------------------------
-// one element (slot, facet node, component) of the packed traces of block side `side`
+// one element (slot, facet node, component) of the packed traces of block side `side`.
+// A packed trace has dim components per facet node: the velocity, or - for a stress field - the
+// column T_i,axis of the side's axis: the only part of the neighbour's tensor that f's interior-facet
+// term `avg(s)*n` (elastic.py:206) uses on an axis-aligned block side, where n = +-e_axis.
 __device__ __forceinline__ void pack_one(const MeshDev* md, const double* field, int ncomp, int side, long idx, double* out,
                                          int sym) {
-  const int nd = md->nd, nf = md->nf, ncls = md->ncls, hpc = md->halo_per_cube;
+  const int nd = md->nd, nf = md->nf, ncls = md->ncls, hpc = md->halo_per_cube, d = md->dim;
   const int axis = side >> 1, hi = side & 1;
-  int cpt = (int)(idx % ncomp);
-  long t = idx / ncomp;
+  int cpt = (int)(idx % d);
+  long t = idx / d;
   int b = (int)(t % nf);
   long slot = t / nf;
   int ord = (int)(slot % hpc);
@@ -361,9 +367,9 @@ __device__ __forceinline__ void pack_one(const MeshDev* md, const double* field,
   const int cls = md->side_cls[side][ord], f = md->side_face[side][ord];
   const int gw = md->gw;
   int cs = cpt;
-  if (sym) {  // symmetric-mode stress field: the (i > j) lines are stale, read the mirror
-    const int d = md->dim, i = cpt / d, j = cpt % d;
-    if (i > j) cs = j * d + i;
+  if (ncomp != d) {  // stress: component (i, axis); symmetric-mode storage keeps only the i <= j lines valid
+    const int i = cpt, j = axis;
+    cs = (sym && i > j) ? j * d + i : i * d + j;
   }
   long off = ((((cube / gw) * ncls + cls) * (long)nd + md->fnode[f][b]) * ncomp + cs) * gw + cube % gw;
   out[idx] = field[off];
@@ -396,7 +402,7 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const double* field, i
     long n2 = 1;
     for (int a = 0; a < 3; ++a)
       if (a != axis) n2 *= mh.n[a];
-    const long total = n2 * mh.halo_per_cube * mh.nf * ncomp;
+    const long total = n2 * mh.halo_per_cube * mh.nf * mh.dim;
     if (total <= 0 || !outs[i]) continue;
     P.side[P.nside] = sides[i];
     P.out[P.nside] = outs[i];

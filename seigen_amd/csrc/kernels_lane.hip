@@ -86,7 +86,7 @@ __device__ __forceinline__ LaneNbr lane_nbr(const MeshDev* md, const StageArgs& 
     long c2 = (axis == 0) ? (L.cc[1] + (long)md->n[1] * L.cc[2])
                           : (axis == 1) ? (L.cc[0] + (long)md->n[0] * L.cc[2]) : (L.cc[0] + (long)md->n[0] * L.cc[1]);
     long slot = c2 * md->halo_per_cube + md->face_ord[kn][md->nb_face[k][f]];
-    R.p = A.ghost[side] + slot * NF * NC;
+    R.p = A.ghost[side] + slot * NF * DIM;  // packed trace: DIM comps per facet node (velocity, or T_i,axis)
     R.cstride = 1;
     R.ghost = true;
     return R;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
     int nst[NFACES];
     double wf[NFACES];
     int nnode[NFACES][NF];
+    bool gh[NFACES];   // F: this lane reads the facet from a packed remote trace (T_i,axis only)
 #pragma unroll
     for (int f = 0; f < NFACES; ++f) {
       const LaneNbr R = lane_nbr<DIM, ND, NF, NC, NCLS>(md, A, L, g, k, f, lane, own);
@@ -163,10 +164,11 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       // F: +1/2 neighbour flux inside, -1/2 own flux on the boundary (cancels the folded half: T.n = 0);
       // G: 1/2 of the neighbour, or the missing 1/2 of the own trace on the boundary
       wf[f] = (KIND == 0 && R.physical) ? -0.5 : 0.5;
+      gh[f] = R.ghost;
 #pragma unroll
       for (int bp = 0; bp < NF; ++bp) {
         const int on = md->fnode[f][bp];
-        nnode[f][bp] = (R.ghost ? md->nb_fnode[k][f][bp] : (R.physical ? on : md->nb_node[k][f][bp])) * NC * R.cstride;
+        nnode[f][bp] = R.ghost ? md->nb_fnode[k][f][bp] * DIM : (R.physical ? on : md->nb_node[k][f][bp]) * NC * R.cstride;
       }
     }
     const long e = (L.valid ? L.c : 0) * NCLS + k;
@@ -198,7 +200,11 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
           for (int bp = 0; bp < NF; ++bp) {
             double sacc = 0.0;
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) sacc += cnv[f][j] * np[f][nnode[f][bp] + cidx<DIM, SYM>(i, j) * nst[f]];
+            for (int j = 0; j < DIM; ++j) {
+              // a packed remote trace holds g_i = T_i,axis only: such a lane reads g_i for every j (one
+              // unconditional load, selected offset); the columns j != axis meet cn_j = 0 there
+              sacc += cnv[f][j] * np[f][nnode[f][bp] + (gh[f] ? i : cidx<DIM, SYM>(i, j) * 64)];
+            }
             fl[f][bp] = wf[f] * sacc;
           }
         // sponge operand and in-place combine operands, read before this cell's u_i is written

@@ -119,6 +119,46 @@ __device__ __forceinline__ void load_tensor(const double* p, int stride, double 
 }
 __device__ __forceinline__ constexpr bool upper(int ij) { return (ij / 3) <= (ij % 3); }
 
+// Neighbour tensor at one facet node.  GHOST = 0 (a block without neighbour blocks): out of the
+// field, exactly load_tensor.  GHOST = 1: a lane whose neighbour lives in another block reads the
+// packed remote trace instead, which holds only the column g_i = T_i,axis of the block side's axis
+// (kernels.hip pack_one).  The other columns meet (c n)_j = 0 on such a facet, so ANY finite value
+// in their place gives the same flux bit for bit: the loads stay unconditional and only their
+// offsets differ per lane - c * 16 into a field, or into the 3-word record such that every needed
+// (i, axis) entry (or, in symmetric mode, the pair that stands for it) finds g_i:
+//   full tensor: (i, j) -> i;   pairs i <= j: axis 0 -> j, axis 1 -> i + j - 1 (clamped), axis 2 -> i.
+// `axis` is uniform over the wave (a property of class and facet).  No branch: a divergent branch
+// around the loads costs the F stages a factor two (the hand-pipelined load/MFMA interleaving is lost).
+template <int SYM, int GHOST>
+__device__ __forceinline__ void load_trace(const double* p, bool ghost, int axis, double (&T)[9]) {
+  if (!GHOST) {
+    load_tensor<SYM>(p, 16, T);
+    return;
+  }
+  auto at = [&](int i, int j) {
+    int og = i;
+    if (SYM) {
+      const int mid = (i + j - 1 < 0) ? 0 : (i + j - 1 > 2 ? 2 : i + j - 1);
+      og = (axis == 0) ? j : (axis == 1 ? mid : i);
+    }
+    return p[ghost ? og : (i * 3 + j) * 16];
+  };
+  if (SYM) {
+    T[0] = at(0, 0);
+    T[1] = at(0, 1);
+    T[2] = at(0, 2);
+    T[4] = at(1, 1);
+    T[5] = at(1, 2);
+    T[8] = at(2, 2);
+    T[3] = T[1];
+    T[6] = T[2];
+    T[7] = T[5];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) T[c] = at(c / 3, c % 3);
+  }
+}
+
 // wave-uniform test on the bits (scalar compare and branch; there is no scalar f64 compare)
 __device__ __forceinline__ bool uniform_nonzero(double c) {
   return (__builtin_bit_cast(unsigned long long, c) << 1) != 0ull;
@@ -191,7 +231,7 @@ __device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A,
     long c2 = (axis == 0) ? (L.cc[1] + (long)md.n[1] * L.cc[2])
                           : (axis == 1) ? (L.cc[0] + (long)md.n[0] * L.cc[2]) : (L.cc[0] + (long)md.n[0] * L.cc[1]);
     long slot = c2 * md.halo_per_cube + md.face_ord[kn][md.nb_face[k][f]];
-    R.p = A.ghost[side] + slot * NF * NC;
+    R.p = A.ghost[side] + slot * NF * 3;  // packed trace: 3 comps per facet node (velocity, or T_i,axis)
     R.cstride = 1;
     R.ghost = true;
     return R;
@@ -620,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 // --------------------------------------------------------------------------------------------
 //  F: uh_i = -sum_r D_r (Jinv_rj T_ij) + sum_f L_f [ (c n)_j {T_ij} ] - sponge
 // --------------------------------------------------------------------------------------------
-template <int P, int MODE, int SYM>
+template <int P, int MODE, int SYM, int GHOST>
 __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   using M = MG<P>;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
@@ -723,21 +763,23 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #endif
     constexpr int PFL = SG_PFLF;  // facet k-steps of neighbour traces in flight
     const double* np[4];
-    int nst[4];
     double wf[4];
     int noff[4][KSF];
+    bool gh[4];
+    int fax[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
       np[f] = R.p;
-      nst[f] = R.cstride;
+      gh[f] = GHOST && R.ghost;
+      fax[f] = GHOST ? __builtin_amdgcn_readfirstlane(sMd.nb_axis[k][f]) : 0;
       wf[f] = R.physical ? -1.0 : 1.0;
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
         const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
         const int on = sMd.fnode[f][bb];
         const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-        noff[f][ks] = nn * 9 * R.cstride;
+        noff[f][ks] = R.ghost ? nn * 3 : nn * 9 * R.cstride;
       }
     }
     double nq[PFL][9];
@@ -745,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       constexpr int NS = 4 * KSF;
 #pragma unroll
       for (int s = 0; s < PFL; ++s)
-        load_tensor<SYM>(np[s / KSF] + noff[s / KSF][s % KSF], nst[s / KSF], nq[s]);
+        load_trace<SYM, GHOST>(np[s / KSF] + noff[s / KSF][s % KSF], gh[s / KSF], fax[s / KSF], nq[s]);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -758,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
                              cnf[f][2] * nq[s % PFL][i * 3 + 2]);
           if (s + PFL < NS) {
             const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
-            load_tensor<SYM>(np[f1] + noff[f1][k1], nst[f1], nq[s % PFL]);
+            load_trace<SYM, GHOST>(np[f1] + noff[f1][k1], gh[f1], fax[f1], nq[s % PFL]);
           }
 #pragma unroll
           for (int t = 0; t < MTT; ++t) {
@@ -901,10 +943,20 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
   // persistent grid, at most 2 blocks per CU; a multiple of 8 (one item range per XCD label)
   const dim3 grid((unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512)), block(256);
   if (kind == 0) {
-    if (a.mode == 0)
-      hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((mfma_stage_F<P, 1, SYM>), grid, block, 0, s, a);
+    // blocks without neighbour blocks never meet a packed remote trace: GHOST = 0 instantiation
+    bool ghosts = false;
+    for (int sd = 0; sd < 6; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
+    if (a.mode == 0) {
+      if (ghosts)
+        hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM, 1>), grid, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM, 0>), grid, block, 0, s, a);
+    } else {
+      if (ghosts)
+        hipLaunchKernelGGL((mfma_stage_F<P, 1, SYM, 1>), grid, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((mfma_stage_F<P, 1, SYM, 0>), grid, block, 0, s, a);
+    }
   } else {
     if (a.mode == 0)
       hipLaunchKernelGGL((mfma_stage_G<P, 0, SYM>), grid, block, 0, s, a);

@@ -88,8 +88,7 @@ class FakeBlock(object):
         return x @ w
 
     def ncomp(self, field):
-        d = self.dim
-        return d * d if field in (self.lib.FIELD_S, self.lib.FIELD_SH) else d
+        return self.dim          # packed traces carry dim components: velocity, or T_i,axis of a stress
 
     # -- interface used by HaloExchanger
     def halo_bytes(self, field, side):
