@@ -197,7 +197,8 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   const bool force_lane = path_env && std::strcmp(path_env, "lane") == 0;
   const int64_t ncube_all = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->use_lane = !h->use_mfma && lane_supported(cfg->dim, cfg->degree) && !force_generic &&
-                (force_lane || ncube_all * h->ncls >= 196608);  // crossover measured with tools/path_sweep.py
+                (force_lane || ncube_all * h->ncls >= (cfg->degree == 1 ? 196608 : 120000));  // crossovers measured
+                                                                     // (tools/path_sweep.py, profiles/r02/lane_split_sweep_negative.txt)
   h->md.gw = h->use_mfma ? 16 : (h->use_lane ? 64 : 1);
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
