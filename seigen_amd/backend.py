@@ -85,8 +85,13 @@ class HipBlock(object):
         ncells = arr.shape[0]
         check(self.lib.sg_set_field_range(self.h, field, int(cell0), int(ncells), arr.ctypes.data, arr.nbytes), self.h)
 
-    def get_field_range(self, field, cell0, ncells):
-        out = np.empty((int(ncells),) + self.field_shape(field)[1:])
+    def get_field_range(self, field, cell0, ncells, out=None):
+        """`out`: a C-contiguous float64 array to fill (re-used buffers skip the page faults of a fresh one)"""
+        shape = (int(ncells),) + self.field_shape(field)[1:]
+        if out is None:
+            out = np.empty(shape)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape %r" % (shape,))
         check(self.lib.sg_get_field_range(self.h, field, int(cell0), int(ncells), out.ctypes.data, out.nbytes), self.h)
         return out
 

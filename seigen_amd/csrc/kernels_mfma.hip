@@ -722,15 +722,20 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     STAMP(st1);
     // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
     {
-      double Tq[9];
-      load_tensor<SYM>(brow(0), 16, Tq);
+#ifndef SG_PFV
+#define SG_PFV 1
+#endif
+      constexpr int PFV = SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
+      double Tq[PFV][9];
+#pragma unroll
+      for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         double T[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) T[c] = Tq[c];
-        if (ks + 1 < KS) {
-          load_tensor<SYM>(brow(ks + 1), 16, Tq);
+        for (int c = 0; c < 9; ++c) T[c] = Tq[ks % PFV][c];
+        if (ks + PFV < KS) {
+          load_tensor<SYM>(brow(ks + PFV), 16, Tq[ks % PFV]);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {

@@ -76,14 +76,19 @@ class FunctionSpace(object):
         """nodes * value size on this rank (seigen/elastic.py:85)."""
         return self.node_count * self.value_size
 
+    # spaces above this many nodes do not keep their coordinates (config 3: 55 M nodes = 1.3 GB per space)
+    COORD_CACHE_MAX_NODES = 1 << 24
+
     def node_coords(self):
         """[cells, nd, dim] physical node coordinates of this rank's block."""
-        if self._coords is None:
-            cfg = block_config(self.mesh, min(self.degree, 4))
-            out = np.empty((self.ncells, self.nd, self.dim))
-            _lib.check(_lib.load().sg_block_node_coords(C.byref(cfg), self.degree, out.ctypes.data, out.nbytes))
+        if self._coords is not None:
+            return self._coords
+        cfg = block_config(self.mesh, min(self.degree, 4))
+        out = np.empty((self.ncells, self.nd, self.dim))
+        _lib.check(_lib.load().sg_block_node_coords(C.byref(cfg), self.degree, out.ctypes.data, out.nbytes))
+        if self.node_count <= self.COORD_CACHE_MAX_NODES:
             self._coords = out
-        return self._coords
+        return out
 
 
     def node_coords_chunks(self, max_nodes=1 << 22):
@@ -145,7 +150,7 @@ class Function(object):
     def __init__(self, space, name=None):
         self._space = space
         self._name = name
-        self._host = np.zeros((space.ncells, space.nd) + space.value_shape)
+        self._host = None        # host values, allocated on first use (a config-3 stress field is 4 GB)
         self._binding = None     # (HipBlock, field id)
         self.dat = _Dat(self)
 
@@ -163,7 +168,12 @@ class Function(object):
         if self._binding is not None:
             block, field = self._binding
             return block.get_field(field)
+        if self._host is None:
+            self._host = np.zeros(self._shape())
         return self._host
+
+    def _shape(self):
+        return (self._space.ncells, self._space.nd) + self._space.value_shape
 
     def _set(self, arr):
         shape = (self._space.ncells, self._space.nd) + self._space.value_shape
@@ -186,15 +196,32 @@ class Function(object):
 
     def interpolate(self, expression):
         """Nodal interpolation [upstream]: evaluate at the node coordinates."""
-        if callable(expression) and not isinstance(expression, Expression):
-            vals = np.asarray(expression(self._space.node_coords()), dtype=np.float64)
-        else:
+        is_expr = isinstance(expression, Expression) or not callable(expression)
+        if is_expr:
             scalar_ok = expression.value_shape == () and self._space.value_size == 1   # 1-D vector/tensor spaces
             if expression.value_shape != self._space.value_shape and not scalar_ok:
                 raise ValueError("Expression shape %r does not match the function space %r"
                                  % (expression.value_shape, self._space.value_shape))
-            vals = expression.evaluate(self._space.node_coords())
-            vals = vals.reshape(vals.shape[:2] + self._space.value_shape)
+        space = self._space
+        if space.node_count > space.COORD_CACHE_MAX_NODES:
+            # large spaces: slab by slab, straight into the device field (bound) or the host array -
+            # neither the coordinates nor the evaluation temporaries of the whole block ever exist
+            if self._binding is None and self._host is None:
+                self._host = np.empty(self._shape())
+            for cell0, X in space.node_coords_chunks():
+                v = expression.evaluate(X) if is_expr else np.asarray(expression(X), dtype=np.float64)
+                v = np.ascontiguousarray(v, dtype=np.float64).reshape((X.shape[0], space.nd) + space.value_shape)
+                if self._binding is not None:
+                    block, field = self._binding
+                    block.set_field_range(field, cell0, v)
+                else:
+                    self._host[cell0:cell0 + X.shape[0]] = v
+            return self
+        if is_expr:
+            vals = expression.evaluate(space.node_coords())
+            vals = vals.reshape(vals.shape[:2] + space.value_shape)
+        else:
+            vals = np.asarray(expression(space.node_coords()), dtype=np.float64)
         self._set(vals)
         return self
 
@@ -253,5 +280,5 @@ def evaluate_at(function, point, cell_xi=None):
         block, field = function._binding
         vals = block.get_field_range(field, cell, 1)[0]
     else:
-        vals = function._host[cell]
+        vals = function._get()[cell]
     return np.tensordot(phi, vals, axes=(0, 0))

@@ -39,10 +39,13 @@ def _launch(nproc, script_args, timeout=240):
     (4, (16, 4, 4), (1, 2, 2), 4, False),      # four ranks on one device
     (4, (16, 4, 4), (1, 2, 2), 4, True),       # config 4's shape: 3-D source + sponge across blocks
     (2, (6, 4, 4), (2, 1, 2), 4, True),
+    (4, (16, 4, 4), (1, 1, 2), 2, "asym"),     # only rank 0 is handed a non-symmetric source: both must leave symmetric storage
+    (3, (16, 2, 4), (1, 1, 4), 4, "asym"),
 ])
 def test_two_processes_one_gpu_bitwise(gpu, tmp_path, degree, n, grid, world, source):
     r = _launch(world, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(degree), "3",
-                        ",".join(map(str, n)), ",".join(map(str, grid))] + (["source"] if source else []))
+                        ",".join(map(str, n)), ",".join(map(str, grid))] +
+                ([{True: "source", "asym": "asym"}[source]] if source else []))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from dist_worker import run_case

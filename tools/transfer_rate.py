@@ -39,6 +39,13 @@ if __name__ == "__main__":
         blk.get_field_range(_lib.FIELD_U, k * layer, layer * 8)
         blk.get_field_range(_lib.FIELD_S, k * layer, layer * 8)
     t_dn = time.perf_counter() - t0
+    # the same into arrays that exist already (a fresh numpy array costs its page faults on first touch)
+    t0 = time.perf_counter()
+    for k in range(0, n, 8):
+        blk.get_field_range(_lib.FIELD_U, k * layer, layer * 8, out=u)
+        blk.get_field_range(_lib.FIELD_S, k * layer, layer * 8, out=s)
+    t_dn2 = time.perf_counter() - t0
+    print("download into existing arrays: %.2f s = %.1f GB/s" % (t_dn2, nbytes / 1e9 / t_dn2))
     dofs = blk.u_dofs + blk.s_dofs
     print("upload %.2f GB in %.2f s = %.1f GB/s; download %.2f s = %.1f GB/s; step %.2f ms" %
           (nbytes / 1e9, t_up, nbytes / 1e9 / t_up, t_dn, nbytes / 1e9 / t_dn, t_step * 1e3))
