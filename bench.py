@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--n", "--cubes", type=int, default=64, help="cubes per axis per GPU (64 = BASELINE config 3)")
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="f64: the reference's precision (headline); f32: the separately reported FP32 second mode "
+                         "(SURVEY 8d, 32 B per DoF-update)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -212,7 +215,8 @@ def main():
     # weak scaling: the unit cube eigenmode on an (n*gx, n*gy, n*gz) mesh of cell size 1/n
     mesh = BoxMesh(gn[0], gn[1], gn[2], gn[0] / n, gn[1] / n, gn[2] / n)
     mesh.set_partition(Partition(gn, rank, world, grid))
-    elastic = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False)
+    elastic = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False, dtype=args.dtype)
+    esz = 4 if args.dtype == "f32" else 8        # bytes per stored value
     elastic.density, elastic.mu, elastic.l = 1.0, 0.25, 0.5
     elastic.dt = 0.5 * (1.0 / n) / 2 ** (P - 1)
     fill_initial_condition(elastic, elastic.dt)
@@ -298,8 +302,12 @@ def main():
     mfma = os.environ.get("SEIGEN_HIP_PATH", "") not in ("generic", "lane") and (P >= 2 or blk.ncells >= 65536)
     sym = 1 if blk.is_sym() else 0      # symmetric-stress storage (default; SEIGEN_HIP_SYM=0 switches it off)
     if mfma:
-        names = (("sg::mfma_stage_F<%d, 0, %d>" % (P, sym), (0, 4)), ("sg::mfma_stage_F<%d, 1, %d>" % (P, sym), (2,)),
-                 ("sg::mfma_stage_G<%d, 0, %d>" % (P, sym), (1, 3)), ("sg::mfma_stage_G<%d, 1, %d>" % (P, sym), (5,)))
+        # template arguments: <field type, degree, fused combine, symmetric storage(, reads packed remote traces)>
+        ty, gh = ("float" if args.dtype == "f32" else "double"), (1 if world > 1 else 0)
+        names = (("sg::mfma_stage_F<%s, %d, 0, %d, %d>" % (ty, P, sym, gh), (0, 4)),
+                 ("sg::mfma_stage_F<%s, %d, 1, %d, %d>" % (ty, P, sym, gh), (2,)),
+                 ("sg::mfma_stage_G<%s, %d, 0, %d>" % (ty, P, sym), (1, 3)),
+                 ("sg::mfma_stage_G<%s, %d, 1, %d>" % (ty, P, sym), (5,)))
     else:
         names = (("sg::stage_kernel<3, %d, 0>" % P, (0, 2, 4)), ("sg::stage_kernel<3, %d, 1>" % P, (1, 3, 5)))
     if not sym:
@@ -309,8 +317,8 @@ def main():
         tot_ms = sum(ms[i] for i in stages)
         launches = sum(nl[i] for i in stages)
         # bytes per STEP, not per launch: a split stage (multi-GPU: FIRST + SECOND) covers the block once
-        byts = sum(words[i] for i in stages) * nst * nodes * 8.0
-        byts_phys = sum(words_phys[i] for i in stages) * nst * nodes * 8.0
+        byts = sum(words[i] for i in stages) * nst * nodes * float(esz)
+        byts_phys = sum(words_phys[i] for i in stages) * nst * nodes * float(esz)
         kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(launches, 1),
                           gbs=byts / max(tot_ms, 1e-12) / 1e6, gbs_phys=byts_phys / max(tot_ms, 1e-12) / 1e6,
                           bytes_per_launch=byts / max(launches, 1), bytes_phys_per_launch=byts_phys / max(launches, 1))
@@ -319,7 +327,7 @@ def main():
     # calibrated with tools/calib_fetch.hip) - measured separately, see profiles/<round>/*_traffic.json
     traffic = None
     traffic_src = None
-    if world == 1 and n == 64 and P == 4:
+    if world == 1 and n == 64 and P == 4 and args.dtype == "f64":
         for tj in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "config3_traffic.json"))):
             try:
                 t = json.load(open(tj))["kernels"].get(dom, {}).get("bytes")
@@ -340,7 +348,7 @@ def main():
             "avg_launch_ms": k["avg_ms"],
             "kernels": {kk: {"avg_ms": v["avg_ms"], "launches": v["launches"], "algorithmic_GBps": v["gbs"],
                              "physical_GBps": v["gbs_phys"]} for kk, v in kern.items()},
-            "whole_step_algorithmic_GBps": dofs_per_gpu * 64.0 * args.steps / (elapsed * 1e9),
+            "whole_step_algorithmic_GBps": dofs_per_gpu * 8.0 * esz * args.steps / (elapsed * 1e9),
             "stage_avg_ms": [ms[i] / max(nst, 1) for i in range(6)]}
     if mfma:
         # second view of the same kernel: the dense element-local products on the FP64 matrix pipe.
@@ -349,9 +357,12 @@ def main():
         stages_dom = dict(names)[dom]
         flop = 2.0 * (9 * blk.nd ** 2 + 12 * blk.nd * nf) * blk.ncells * len(stages_dom) * nst / max(k["launches"], 1)
         tf = flop / (k["avg_ms"] * 1e-3) / 1e12
-        roof["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                        "sustained_measured": FP64_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": tf / FP64_MFMA_SUSTAINED_TFLOPS,
-                        "algorithmic_flop_per_launch": flop}
+        if args.dtype == "f64":
+            roof["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                            "sustained_measured": FP64_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": tf / FP64_MFMA_SUSTAINED_TFLOPS,
+                            "algorithmic_flop_per_launch": flop}
+        else:   # v_mfma_f32_16x16x4_f32: 157.3 TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md)
+            roof["mfma"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flop_per_launch": flop}
 
     # halo layer, per rank (lists over ranks): device time of the trace packs, bytes handed to the
     # transport, and the time the launch stream (RCCL) or the host (host-staged) waited for traces
@@ -366,12 +377,13 @@ def main():
                 "kernel_ms_per_step": gather(sum(ms) / nst)}
     if rank == 0:
         out = {
-            "metric": "M DoF-updates/sec, 3D elastic P=%d" % P, "value": value, "unit": "M DoF-updates/s",
+            "metric": "M DoF-updates/sec, 3D elastic P=%d" % P + (" (FP32 second mode)" if args.dtype == "f32" else ""),
+            "value": value, "unit": "M DoF-updates/s",
             "n_gpus": ranks_reporting, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D eigenmode, %dx%dx%d cubes x 6 tets (%d^3 per GPU), DG P%d, FP64, LF4"
-                                   % (gn[0], gn[1], gn[2], n, P),
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "3D eigenmode, %dx%dx%d cubes x 6 tets (%d^3 per GPU), DG P%d, %s, LF4"
+                                   % (gn[0], gn[1], gn[2], n, P, "FP32" if args.dtype == "f32" else "FP64"),
                        "cells": int(blk.ncells * world), "dofs": int(total_dofs),
                        "block_grid": list(grid), "dt": elastic.dt},
             "roofline": roof,

@@ -81,6 +81,10 @@ typedef struct sg_config {
   int32_t diagonal;  /* 2-D only: 0 = "left" (Firedrake default), 1 = "right" */
   int32_t nbr_mask;  /* bit (2*axis + side) set: that side touches another block (halo), else free surface */
   int32_t device;    /* HIP device ordinal */
+  int32_t dtype;     /* 0: FP64 storage and arithmetic - the reference's precision (elastic.py:442 'double'),
+                        the parity and headline mode; 1: FP32 storage and arithmetic, the separately reported
+                        second mode of SURVEY 8d (32 B per DoF-update; 3-D blocks on the MFMA path).  The C-ABI
+                        keeps double on the host side in both modes; halo buffers hold the device type. */
   void* stream;      /* hipStream_t to launch on, or NULL for the handle's own stream */
 } sg_config;
 

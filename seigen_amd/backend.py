@@ -11,10 +11,14 @@ def _f64(a):
 
 
 class HipBlock(object):
-    def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None):
+    def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None, dtype="f64"):
         self.lib = _lib.load()
+        if dtype not in ("f64", "f32"):
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        self.dtype = dtype
         cfg = SgConfig()
         cfg.dim, cfg.degree = dim, degree
+        cfg.dtype = 1 if dtype == "f32" else 0
         for a in range(3):
             cfg.n[a] = int(n[a]) if a < dim else 1
             cfg.h[a] = float(h[a]) if a < dim else 1.0

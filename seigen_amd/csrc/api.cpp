@@ -32,6 +32,7 @@ struct sg_handle {
   size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
   bool use_mfma = false;
   bool use_lane = false;
+  int f32 = 0;              // sg_config.dtype = 1: fields, halo buffers, operator tiles and arithmetic are float (MFMA path)
   bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
   int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
   // active (cell group, class) items of each region of a split stage (MFMA / lane paths), by sg_region
@@ -210,6 +211,10 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->use_lane = !h->use_mfma && lane_supported(cfg->dim, cfg->degree) && !force_generic &&
                 (force_lane || ncube_all * h->ncls >= (cfg->degree == 1 ? 196608 : 120000));  // crossovers measured
                                                                      // (tools/path_sweep.py, profiles/r02/lane_split_sweep_negative.txt)
+  if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
+  h->f32 = cfg->dtype;
+  if (h->f32 && !h->use_mfma)
+    return fail(h, SG_ERR_ARG, "dtype f32 is implemented on the MFMA path (3-D blocks; degree 1 from 65536 cells)");
   h->md.gw = h->use_mfma ? 16 : (h->use_lane ? 64 : 1);
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
@@ -255,11 +260,20 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     size_t comps = field_is_stress(f) ? (size_t)d * d : (size_t)d;
     h->field_len[f] = (size_t)h->ncells * nd * comps;
     h->field_alloc[f] = (size_t)h->md.ncube_pad * h->ncls * nd * comps;
-    if (hipMalloc((void**)&h->field[f], h->field_alloc[f] * sizeof(double)) != hipSuccess)
+    const size_t es = h->f32 ? sizeof(float) : sizeof(double);
+    if (hipMalloc((void**)&h->field[f], h->field_alloc[f] * es) != hipSuccess)
       return fail(h, SG_ERR_NOMEM, "hipMalloc of a field buffer failed");
-    HIPCHECK(h, hipMemset(h->field[f], 0, h->field_alloc[f] * sizeof(double)));
+    HIPCHECK(h, hipMemset(h->field[f], 0, h->field_alloc[f] * es));
   }
-  if (h->use_mfma) {
+  if (h->use_mfma && h->f32) {
+    std::vector<float> fF = mfma32_frags_F(h->re), fG = mfma32_frags_G(h->re), fL = mfma32_frags_L(h->re);
+    HIPCHECK(h, hipMalloc((void**)&h->fragF, fF.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&h->fragG, fG.size() * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void**)&h->fragL, fL.size() * sizeof(float)));
+    HIPCHECK(h, hipMemcpy(h->fragF, fF.data(), fF.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else if (h->use_mfma) {
     std::vector<double> fF = mfma_frags_F(h->re), fG = mfma_frags_G(h->re), fL = mfma_frags_L(h->re);
     HIPCHECK(h, hipMalloc((void**)&h->fragF, fF.size() * sizeof(double)));
     HIPCHECK(h, hipMalloc((void**)&h->fragG, fG.size() * sizeof(double)));
@@ -288,7 +302,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     // some of its own slots taken would run the late blocks' static shares one after the other.
     hipDeviceProp_t prop;
     HIPCHECK(h, hipGetDeviceProperties(&prop, cfg->device));
-    const int slots = (h->use_mfma ? mfma_blocks_per_cu(cfg->degree) : 2) * prop.multiProcessorCount;
+    const int slots = (h->use_mfma ? mfma_blocks_per_cu(cfg->degree, h->f32) : 2) * prop.multiProcessorCount;
     h->grid_full = slots / 8 * 8;
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
@@ -465,7 +479,7 @@ static int leave_sym_mode(sg_handle* h) {
   h->epoch += 1;
   if (!h->sym) return SG_OK;
   for (int f : {SG_FIELD_S, SG_FIELD_SH})
-    if (launch_mirror(h->md, h->field[f], h->stream) != 0) return fail(h, SG_ERR_DEVICE, "mirror kernel launch failed");
+    if (launch_mirror(h->md, h->field[f], h->f32, h->stream) != 0) return fail(h, SG_ERR_DEVICE, "mirror kernel launch failed");
   HIPCHECK(h, hipStreamSynchronize(h->stream));
   h->sym = false;
   return SG_OK;
@@ -527,7 +541,7 @@ static int transfer_pipelined(sg_handle* h, int field, int64_t cell0, int64_t nc
           HIPCHECK(h, hipMemcpyAsync(h->field[field] + (size_t)(cell0 + c0) * per_cell, h->pin[sl], nb, hipMemcpyHostToDevice, h->stream));
         } else {
           HIPCHECK(h, hipMemcpyAsync(h->dstage[sl], h->pin[sl], nb, hipMemcpyHostToDevice, h->stream));
-          if (launch_layout(h->md, comps, 0, h->field[field], h->dstage[sl], cell0 + c0, n, 0, flag, h->stream) != 0)
+          if (launch_layout(h->md, comps, 0, h->field[field], h->dstage[sl], cell0 + c0, n, 0, flag, h->f32, h->stream) != 0)
             return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
         }
         HIPCHECK(h, hipEventRecord(h->xfer_ev[sl], h->stream));
@@ -539,7 +553,7 @@ static int transfer_pipelined(sg_handle* h, int field, int64_t cell0, int64_t nc
         if (h->md.gw == 1) {
           HIPCHECK(h, hipMemcpyAsync(h->pin[sl], h->field[field] + (size_t)(cell0 + c0) * per_cell, nb, hipMemcpyDeviceToHost, h->stream));
         } else {
-          if (launch_layout(h->md, comps, 1, h->field[field], h->dstage[sl], cell0 + c0, n, symdl, nullptr, h->stream) != 0)
+          if (launch_layout(h->md, comps, 1, h->field[field], h->dstage[sl], cell0 + c0, n, symdl, nullptr, h->f32, h->stream) != 0)
             return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
           HIPCHECK(h, hipMemcpyAsync(h->pin[sl], h->dstage[sl], nb, hipMemcpyDeviceToHost, h->stream));
         }
@@ -600,12 +614,12 @@ static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, doub
     if (to_device) {
       HIPCHECK(h, hipMemcpy(h->staging, host + (size_t)done * per_cell, nb, hipMemcpyHostToDevice));
       int* flag = (h->sym && field_is_stress(field)) ? h->sym_flag : nullptr;
-      if (launch_layout(h->md, comps, 0, h->field[field], h->staging, cell0 + done, n, 0, flag, h->stream) != 0)
+      if (launch_layout(h->md, comps, 0, h->field[field], h->staging, cell0 + done, n, 0, flag, h->f32, h->stream) != 0)
         return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
       HIPCHECK(h, hipStreamSynchronize(h->stream));
     } else {
       const int symdl = (h->sym && field_is_stress(field)) ? 1 : 0;
-      if (launch_layout(h->md, comps, 1, h->field[field], h->staging, cell0 + done, n, symdl, nullptr, h->stream) != 0)
+      if (launch_layout(h->md, comps, 1, h->field[field], h->staging, cell0 + done, n, symdl, nullptr, h->f32, h->stream) != 0)
         return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
       HIPCHECK(h, hipStreamSynchronize(h->stream));
       HIPCHECK(h, hipMemcpy(host + (size_t)done * per_cell, h->staging, nb, hipMemcpyDeviceToHost));
@@ -878,6 +892,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
   a.sym = h->sym ? 1 : 0;
+  a.f32 = h->f32;
   a.dbg = h->dbg ? h->dbg + 8 * (kind * 2 + (mode ? 1 : 0)) : nullptr;
   a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
   a.sponge_B = h->sponge_B;
@@ -974,7 +989,7 @@ static int add_source(sg_handle* h, int field, double coef, int region = SG_REGI
   }
   if (cnt == 0) return SG_OK;
   const double* vals = h->src_values + ((size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz + off) * d * d;
-  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, h->stream);
+  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, h->f32, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
   return SG_OK;
 }
@@ -1168,7 +1183,7 @@ int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes) {
   for (int a = 0; a < 3; ++a)
     if (a != axis) n2 *= (size_t)h->cfg.n[a];
   // dim components per facet node for every field: a stress trace travels as T_i,axis (kernels.hip pack_one)
-  *nbytes = n2 * h->md.halo_per_cube * h->re.nf * (size_t)d * sizeof(double);
+  *nbytes = n2 * h->md.halo_per_cube * h->re.nf * (size_t)d * (h->f32 ? sizeof(float) : sizeof(double));
   (void)field;
   return SG_OK;
 }
@@ -1206,12 +1221,12 @@ int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   const int d = h->cfg.dim;
   int comps = field_is_stress(field) ? d * d : d;
-  double* out = (double*)dev_out;
+  void* out = dev_out;
   size_t k = 0, nb = 0;
   int rc = pack_begin(h, k);
   if (rc != SG_OK) return rc;
   rc = launch_pack(h->md_dev, h->md, h->field[field], comps, 1, &side, &out,
-                   (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
+                   (h->sym && field_is_stress(field)) ? 1 : 0, h->f32, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
   (void)sg_halo_bytes(h, field, side, &nb);
   return pack_end(h, k, nb);
@@ -1223,18 +1238,18 @@ int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out) {
   const int d = h->cfg.dim;
   int comps = field_is_stress(field) ? d * d : d;
   int sides[6], n = 0;
-  double* outs[6];
+  void* outs[6];
   for (int s = 0; s < 2 * d; ++s)
     if (dev_out[s]) {
       sides[n] = s;
-      outs[n] = (double*)dev_out[s];
+      outs[n] = dev_out[s];
       n += 1;
     }
   size_t k = 0, total = 0;
   int rc = pack_begin(h, k);
   if (rc != SG_OK) return rc;
   rc = launch_pack(h->md_dev, h->md, h->field[field], comps, n, sides, outs,
-                   (h->sym && field_is_stress(field)) ? 1 : 0, h->stream);
+                   (h->sym && field_is_stress(field)) ? 1 : 0, h->f32, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
   for (int i = 0; i < n; ++i) {
     size_t nb = 0;

@@ -338,7 +338,8 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
 // A packed trace has dim components per facet node: the velocity, or - for a stress field - the
 // column T_i,axis of the side's axis: the only part of the neighbour's tensor that f's interior-facet
 // term `avg(s)*n` (elastic.py:206) uses on an axis-aligned block side, where n = +-e_axis.
-__device__ __forceinline__ void pack_one(const MeshDev* md, const double* field, int ncomp, int side, long idx, double* out,
+template <typename T>
+__device__ __forceinline__ void pack_one(const MeshDev* md, const T* field, int ncomp, int side, long idx, T* out,
                                          int sym) {
   const int nd = md->nd, nf = md->nf, ncls = md->ncls, hpc = md->halo_per_cube, d = md->dim;
   const int axis = side >> 1, hi = side & 1;
@@ -378,22 +379,23 @@ __device__ __forceinline__ void pack_one(const MeshDev* md, const double* field,
 struct PackArgs {
   int nside;
   int side[6];
-  double* out[6];
+  void* out[6];
   long start[7];  // element ranges of the sides within the launch
 };
 
 // all sides of a block in one launch (one small launch per side costs more in gaps than in work)
-__global__ void pack_kernel(const MeshDev* md, const double* field, int ncomp, PackArgs P, int sym) {
+template <typename T>
+__global__ void pack_kernel(const MeshDev* md, const T* field, int ncomp, PackArgs P, int sym) {
   const long total = P.start[P.nside];
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     int s = 0;
     while (s + 1 < P.nside && idx >= P.start[s + 1]) ++s;
-    pack_one(md, field, ncomp, P.side[s], idx - P.start[s], P.out[s], sym);
+    pack_one<T>(md, field, ncomp, P.side[s], idx - P.start[s], (T*)P.out[s], sym);
   }
 }
 
-int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const double* field, int ncomp, int nside, const int* sides,
-                double* const* outs, int sym, void* stream) {
+int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const void* field, int ncomp, int nside, const int* sides,
+                void* const* outs, int sym, int f32, void* stream) {
   PackArgs P;
   P.nside = 0;
   P.start[0] = 0;
@@ -413,31 +415,41 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const double* field, i
   if (total <= 0) return 0;
   long grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, field, ncomp, P, sym);
+  if (f32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, (const float*)field, ncomp, P, sym);
+  else
+    hipLaunchKernelGGL(pack_kernel<double>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, md_dev, (const double*)field, ncomp, P, sym);
   return (int)hipGetLastError();
 }
 
 // ---- sparse source ----------------------------------------------------------------------
-__global__ void source_kernel(double* field, int ncomp, int gw, long nnz, const int64_t* offs, const double* values,
+template <typename T>
+__global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64_t* offs, const double* values,
                               double coef) {
   long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= nnz * ncomp) return;
   long k = idx / ncomp;
   int c = (int)(idx - k * ncomp);
-  field[offs[k] + (long)c * gw] += coef * values[idx];
+  field[offs[k] + (long)c * gw] += (T)(coef * values[idx]);
 }
 
-int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
-                  void* stream) {
+int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
+                  int f32, void* stream) {
   if (nnz <= 0) return 0;
   long total = nnz * ncomp;
-  hipLaunchKernelGGL(source_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, field,
-                     ncomp, gw, (long)nnz, offs, values, coef);
+  if (f32)
+    hipLaunchKernelGGL(source_kernel<float>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       (float*)field, ncomp, gw, (long)nnz, offs, values, coef);
+  else
+    hipLaunchKernelGGL(source_kernel<double>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       (double*)field, ncomp, gw, (long)nnz, offs, values, coef);
   return (int)hipGetLastError();
 }
 
 // ---- host <-> device layout ------------------------------------------------------------------
-__global__ void layout_kernel(int dim, int nd, int ncls, int gw, int ncomp, int dir, double* field, double* staging,
+// the staging side is always double (the C-ABI's host type); a float field converts on the way
+template <typename T>
+__global__ void layout_kernel(int dim, int nd, int ncls, int gw, int ncomp, int dir, T* field, double* staging,
                               long cell0, long ncells, int sym, int* flag) {
   const long per_cell = (long)nd * ncomp;
   const long total = ncells * per_cell;
@@ -449,7 +461,7 @@ __global__ void layout_kernel(int dim, int nd, int ncls, int gw, int ncomp, int 
     if (dir == 0) {
       long off = (((cube / gw) * ncls + cls) * per_cell + rem) * gw + cube % gw;
       double v = staging[idx];
-      field[off] = v;
+      field[off] = (T)v;
       if (flag != nullptr && ncomp == dim * dim) {  // tensor upload: report any asymmetry
         int cpt = (int)(rem % ncomp), i = cpt / dim, j = cpt % dim;
         if (i < j && staging[idx - cpt + j * dim + i] != v) *flag = 1;
@@ -466,18 +478,23 @@ __global__ void layout_kernel(int dim, int nd, int ncls, int gw, int ncomp, int 
   }
 }
 
-int launch_layout(const MeshDev& mh, int ncomp, int dir, double* field, double* staging, int64_t cell0, int64_t ncells,
-                  int sym, int* flag, void* stream) {
+int launch_layout(const MeshDev& mh, int ncomp, int dir, void* field, double* staging, int64_t cell0, int64_t ncells,
+                  int sym, int* flag, int f32, void* stream) {
   if (ncells <= 0) return 0;
   long total = ncells * (long)mh.nd * ncomp;
   long grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(layout_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls, mh.gw,
-                     ncomp, dir, field, staging, (long)cell0, (long)ncells, sym, flag);
+  if (f32)
+    hipLaunchKernelGGL(layout_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls,
+                       mh.gw, ncomp, dir, (float*)field, staging, (long)cell0, (long)ncells, sym, flag);
+  else
+    hipLaunchKernelGGL(layout_kernel<double>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls,
+                       mh.gw, ncomp, dir, (double*)field, staging, (long)cell0, (long)ncells, sym, flag);
   return (int)hipGetLastError();
 }
 
-__global__ void mirror_kernel(int dim, int nd, int ncls, int gw, double* field, long ncube_pad) {
+template <typename T>
+__global__ void mirror_kernel(int dim, int nd, int ncls, int gw, T* field, long ncube_pad) {
   const int nc = dim * dim;
   const long total = ncube_pad * ncls * nd * nc;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -489,12 +506,16 @@ __global__ void mirror_kernel(int dim, int nd, int ncls, int gw, double* field, 
   }
 }
 
-int launch_mirror(const MeshDev& mh, double* field, void* stream) {
+int launch_mirror(const MeshDev& mh, void* field, int f32, void* stream) {
   long total = mh.ncube_pad * mh.ncls * (long)mh.nd * mh.dim * mh.dim;
   long grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(mirror_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls, mh.gw,
-                     field, (long)mh.ncube_pad);
+  if (f32)
+    hipLaunchKernelGGL(mirror_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls,
+                       mh.gw, (float*)field, (long)mh.ncube_pad);
+  else
+    hipLaunchKernelGGL(mirror_kernel<double>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, mh.dim, mh.nd, mh.ncls,
+                       mh.gw, (double*)field, (long)mh.ncube_pad);
   return (int)hipGetLastError();
 }
 

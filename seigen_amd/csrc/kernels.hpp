@@ -43,6 +43,7 @@ struct StageArgs {
   int32_t nlist;
   int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
   int32_t grid_blocks;          // MFMA path: size of the persistent grid (a multiple of 8)
+  int32_t f32;                  // MFMA path: fields, halo buffers and operator tables are float (sg_config.dtype = 1)
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)
@@ -50,7 +51,7 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream);
 
 // MFMA path (3-D, degree >= 3; fields in the gw = 16 interleaved layout)
 bool mfma_supported(int dim, int P);
-int mfma_blocks_per_cu(int P);
+int mfma_blocks_per_cu(int P, int f32);
 int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream);
 
 // lane-per-cell path (1-D / 2-D; fields in the gw = 64 interleaved layout; a.Dt = E[r][a][b],
@@ -62,18 +63,19 @@ int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems,
 // dir = 0: staging -> field, 1: field -> staging
 // sym = 1 (stress field in symmetric mode): a download mirrors the lower triangle from the upper;
 // flag (device int, may be null): set to 1 by an upload whose tensors are not exactly symmetric
-int launch_layout(const MeshDev& md_host, int ncomp, int dir, double* field, double* staging, int64_t cell0,
-                  int64_t ncells, int sym, int* flag, void* stream);
+// f32 = 1: the field is float (sg_config.dtype = 1); the staging side is double either way
+int launch_layout(const MeshDev& md_host, int ncomp, int dir, void* field, double* staging, int64_t cell0,
+                  int64_t ncells, int sym, int* flag, int f32, void* stream);
 // copy the upper triangle over the lower one in a whole stress field (leaving symmetric mode)
-int launch_mirror(const MeshDev& md_host, double* field, void* stream);
+int launch_mirror(const MeshDev& md_host, void* field, int f32, void* stream);
 
 // facet traces of a field on `nside` block sides -> one packed device buffer per side, one launch
 // (sym = 1: a stress field stored in symmetric mode; lower-triangle values come from their mirrors)
-int launch_pack(const MeshDev* md_dev, const MeshDev& md_host, const double* field, int ncomp, int nside,
-                const int* sides, double* const* outs, int sym, void* stream);
+int launch_pack(const MeshDev* md_dev, const MeshDev& md_host, const void* field, int ncomp, int nside,
+                const int* sides, void* const* outs, int sym, int f32, void* stream);
 
 // field[off[k] + c*gw] += coef * values[k][c] at the sparse source nodes (off = device offset of comp 0)
-int launch_source(double* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
-                  void* stream);
+int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
+                  int f32, void* stream);
 
 }  // namespace sg

@@ -23,18 +23,44 @@
 
 namespace sg {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+// The kernels are written once for the field type R: double (the parity and headline mode) or float
+// (the second mode of SURVEY 8d: FP32 storage and arithmetic, 32 B per DoF-update).  What differs:
+//   double: v_mfma_f64_16x16x4_f64 (C/D row = 4 reg + (lane >> 4)) for full 16-row tiles and
+//           v_mfma_f64_4x4x4_4b_f64 for the nd % 16 rows left over;
+//   float:  v_mfma_f32_16x16x4_f32 (C/D row = 4 (lane >> 4) + reg) for every row tile, the last one
+//           zero-padded (gfx950 has no 4-row f32 shape with K = 4).  The operator tiles of the float
+//           tables have their rows permuted (mfma_tables.cpp) so that register `reg` of lane group q
+//           holds node 16 t + 4 reg + q in both cases and everything below is type-independent.
+template <typename R>
+struct RT;
+template <>
+struct RT<double> {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  static constexpr bool SMALL = true;
+  static __device__ __forceinline__ v4 big(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  // 4 rows x 16 cells (four 4x4 blocks), same B register as the large shape; lane l of the result holds
+  // row (l >> 4) of cell (l & 15).  About 1/6 of the issue time of the large shape (mfma_tables.hpp).
+  static __device__ __forceinline__ double small(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+};
+template <>
+struct RT<float> {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  static constexpr bool SMALL = false;
+  static __device__ __forceinline__ v4 big(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float small(float, float, float c) { return c; }  // never reached (NSM = 0)
+};
 
-template <int P>
+template <int P, typename R>
 struct MG {
   static constexpr int ND = (P + 1) * (P + 2) * (P + 3) / 6;
   static constexpr int NF = (P + 1) * (P + 2) / 2;
   static constexpr int KS = (ND + 3) / 4;
   static constexpr int KSF = (NF + 3) / 4;
-  static constexpr int MTF = ND / 16;                // full 16-row tiles over the nodes
-  static constexpr int NSM = (ND % 16 + 3) / 4;      // 4-row tiles (4x4x4 MFMA) over the remaining rows
+  static constexpr int MTF = RT<R>::SMALL ? ND / 16 : (ND + 15) / 16;        // 16-row tiles over the nodes
+  static constexpr int NSM = RT<R>::SMALL ? (ND % 16 + 3) / 4 : 0;            // 4-row tiles (4x4x4 MFMA) over the remaining rows
   static constexpr int MTT = MTF + NSM;
   static constexpr int MTFA = MTF > 0 ? MTF : 1;     // array extent (degrees 1 and 2 have no full tile)
+  static constexpr int NSMA = NSM > 0 ? NSM : 1;
   static constexpr int S4 = (ND + 3) / 4;
   static constexpr int NFRAG_F = MTT * 3 * KS;
   static constexpr int NFRAG_G = 3 * MTT * KS;
@@ -59,10 +85,8 @@ struct MG {
 #define SG_PRIO_HI 3
 #endif
 #define SG_PRIO(p) do { if (SG_PRIO_HI) __builtin_amdgcn_s_setprio(p); } while (0)
-#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-// 4 rows x 16 cells (four 4x4 blocks), same B register as MFMA64; lane l of the result holds
-// row (l >> 4) of cell (l & 15).  About 1/6 of the issue time of MFMA64 (mfma_tables.hpp).
-#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+#define MFMA64(a, b, c) RT<R>::big((a), (b), (c))
+#define MFMA4(a, b, c) RT<R>::small((a), (b), (c))
 
 // Diagnostic build only (-DSG_STAMPS, SEIGEN_HIP_STAMPS=1): cycle stamps at the phase boundaries
 // of an item, summed per wave in scalars and added to A.dbg at the end.  Never in the shipped build.
@@ -100,8 +124,8 @@ struct MG {
 // a symmetric tensor, elastic.py:211-219; api.cpp checks what the user uploads), so only the six
 // lines (i <= j) of each node are read and written; the other three keep their slots but are
 // never touched.  Same results, 1/3 less stress traffic.
-template <int SYM>
-__device__ __forceinline__ void load_tensor(const double* p, int stride, double (&T)[9]) {
+template <int SYM, typename R>
+__device__ __forceinline__ void load_tensor(const R* p, int stride, R (&T)[9]) {
   if (SYM) {
     T[0] = p[0];
     T[1] = p[1 * stride];
@@ -129,8 +153,8 @@ __device__ __forceinline__ constexpr bool upper(int ij) { return (ij / 3) <= (ij
 //   full tensor: (i, j) -> i;   pairs i <= j: axis 0 -> j, axis 1 -> i + j - 1 (clamped), axis 2 -> i.
 // `axis` is uniform over the wave (a property of class and facet).  No branch: a divergent branch
 // around the loads costs the F stages a factor two (the hand-pipelined load/MFMA interleaving is lost).
-template <int SYM, int GHOST>
-__device__ __forceinline__ void load_trace(const double* p, bool ghost, int axis, double (&T)[9]) {
+template <int SYM, int GHOST, typename R>
+__device__ __forceinline__ void load_trace(const R* p, bool ghost, int axis, R (&T)[9]) {
   if (!GHOST) {
     load_tensor<SYM>(p, 16, T);
     return;
@@ -163,6 +187,7 @@ __device__ __forceinline__ void load_trace(const double* p, bool ghost, int axis
 __device__ __forceinline__ bool uniform_nonzero(double c) {
   return (__builtin_bit_cast(unsigned long long, c) << 1) != 0ull;
 }
+__device__ __forceinline__ bool uniform_nonzero(float c) { return (__builtin_bit_cast(unsigned, c) << 1) != 0u; }
 
 struct LaneGeo {
   long c;      // linear cube index of this lane's cell
@@ -195,17 +220,19 @@ __device__ __forceinline__ LaneGeo lane_geo(const MeshDev& md, const StageArgs& 
 }
 
 // Where this lane finds its neighbour's trace across facet f.
+template <typename R>
 struct NbrRef {
-  const double* p;  // base pointer of the neighbour cell (or ghost slot)
+  const R* p;  // base pointer of the neighbour cell (or ghost slot)
   int cstride;      // stride between (node, comp) entries: 16 in a field, 1 in a packed ghost buffer
   bool ghost;
   bool physical;    // domain boundary: no neighbour (p then points at the own cell)
 };
 
-template <int ND, int NF, int NC>
-__device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A, const LaneGeo& L, long g, int k, int f,
-                                          int w, const double* own_base) {
-  NbrRef R;
+template <int ND, int NF, int NC, typename R_>
+__device__ __forceinline__ NbrRef<R_> nbr_ref(const MeshDev& md, const StageArgs& A, const LaneGeo& L, long g, int k, int f,
+                                              int w, const R_* own_base) {
+  NbrRef<R_> R;
+  const R_* const fin = reinterpret_cast<const R_*>(A.in);
   R.p = own_base;
   R.cstride = 16;
   R.ghost = false;
@@ -217,7 +244,7 @@ __device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A,
   const int axis = md.nb_axis[k][f];
   const int kn = md.nb_cls[k][f];
   if (axis < 0) {
-    R.p = A.in + ((g * 6 + kn) * (long)ND) * NC * 16 + w;
+    R.p = fin + ((g * 6 + kn) * (long)ND) * NC * 16 + w;
     return R;
   }
   const int dir = md.nb_dir[k][f];
@@ -225,13 +252,13 @@ __device__ __forceinline__ NbrRef nbr_ref(const MeshDev& md, const StageArgs& A,
   const bool inside = L.valid && cn >= 0 && cn < md.n[axis];
   const long stride = (axis == 0) ? 1 : (axis == 1) ? md.n[0] : (long)md.n[0] * md.n[1];
   const long nc = inside ? L.c + dir * stride : L.c;
-  const double* pin = A.in + (((nc >> 4) * 6 + (inside ? kn : k)) * (long)ND) * NC * 16 + (nc & 15);
+  const R_* pin = fin + (((nc >> 4) * 6 + (inside ? kn : k)) * (long)ND) * NC * 16 + (nc & 15);
   const int side = 2 * axis + (dir > 0 ? 1 : 0);
   if (!inside && L.valid && md.has_nbr[side]) {
     long c2 = (axis == 0) ? (L.cc[1] + (long)md.n[1] * L.cc[2])
                           : (axis == 1) ? (L.cc[0] + (long)md.n[0] * L.cc[2]) : (L.cc[0] + (long)md.n[0] * L.cc[1]);
     long slot = c2 * md.halo_per_cube + md.face_ord[kn][md.nb_face[k][f]];
-    R.p = A.ghost[side] + slot * NF * 3;  // packed trace: 3 comps per facet node (velocity, or T_i,axis)
+    R.p = reinterpret_cast<const R_*>(A.ghost[side]) + slot * NF * 3;  // packed trace: 3 comps per facet node (velocity, or T_i,axis)
     R.cstride = 1;
     R.ghost = true;
     return R;
@@ -269,14 +296,14 @@ __device__ __forceinline__ ItemRange item_range(long nitems, int wave, int sprea
 // Operator tiles and mesh tables into LDS, once per block.  All of a thread's loads are issued
 // before the first one is consumed (a plain copy loop compiles to load / wait / write per element:
 // 33 dependent L2 round trips, about 20 us of every launch).
-template <int N>
-__device__ __forceinline__ void copy_to_lds(double* dst, const double* __restrict__ src) {
+template <int N, typename R>
+__device__ __forceinline__ void copy_to_lds(R* dst, const R* __restrict__ src) {
   constexpr int PER = (N + 255) / 256;
-  double v[PER];
+  R v[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int i = threadIdx.x + j * 256;
-    v[j] = (i < N) ? src[i] : 0.0;
+    v[j] = (i < N) ? src[i] : R(0);
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
@@ -285,8 +312,8 @@ __device__ __forceinline__ void copy_to_lds(double* dst, const double* __restric
   }
 }
 
-template <int NV, int NL>
-__device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* sMd, const StageArgs& A) {
+template <int NV, int NL, typename R>
+__device__ __forceinline__ void load_tables(R* sAV, R* sAL, MeshDev* sMd, const StageArgs& A) {
   const int* src = reinterpret_cast<const int*>(A.md);
   int* dst = reinterpret_cast<int*>(sMd);
   constexpr int NI = (int)(sizeof(MeshDev) / sizeof(int)), PERI = (NI + 255) / 256;
@@ -296,8 +323,8 @@ __device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* s
     const int i = threadIdx.x + j * 256;
     w[j] = (i < NI) ? src[i] : 0;
   }
-  copy_to_lds<NV * 64>(sAV, A.fragV);
-  copy_to_lds<NL * 64>(sAL, A.fragL);
+  copy_to_lds<NV * 64>(sAV, reinterpret_cast<const R*>(A.fragV));
+  copy_to_lds<NL * 64>(sAL, reinterpret_cast<const R*>(A.fragL));
 #pragma unroll
   for (int j = 0; j < PERI; ++j) {
     const int i = threadIdx.x + j * 256;
@@ -312,16 +339,17 @@ __device__ __forceinline__ void load_tables(double* sAV, double* sAL, MeshDev* s
 //  tile, m = 4*MTF + s for small tile s), so the three D_r u_i of one node meet in the same lane;
 //  only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
 // --------------------------------------------------------------------------------------------
-template <int P, int MODE, int SYM>
-__global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
-  using M = MG<P>;
+template <typename R, int P, int MODE, int SYM>
+__global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(StageArgs A) {
+  using M = MG<P, R>;
+  typedef typename RT<R>::v4 d4;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
 #ifndef SG_PF
 #define SG_PF 4
 #endif
   constexpr int PF = SG_PF;  // B-operand prefetch distance, in k-steps
-  __shared__ double sAV[M::NFRAG_G * 64];
-  __shared__ double sAL[M::NFRAG_L * 64];
+  __shared__ R sAV[M::NFRAG_G * 64];
+  __shared__ R sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
   load_tables<M::NFRAG_G, M::NFRAG_L>(sAV, sAL, &sMd, A);
 
@@ -331,9 +359,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
   // uniform reads of class constants: constant address space => s_load (scalar cache)
   typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
   const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
-  const double* __restrict__ in = A.in;
-  const double* __restrict__ aux = A.aux;
-  double* __restrict__ out = A.out;
+  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
+  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
+  R* __restrict__ out = reinterpret_cast<R*>(A.out);
+  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
@@ -345,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
-    const double* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    const R* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
     // B row of this lane at k-step ks = node 4 ks + q: one pointer per item plus compile-time
     // offsets (a table of per-k-step offsets is item-invariant, gets hoisted out of the item loop
     // as 64-bit values and spilled; every reload then waits for ALL loads in flight).  Only the last
@@ -353,40 +382,40 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     // do there: clamp instead of branching.
     int qo = q * 3 * 16;
     asm volatile("" : "+v"(qo));
-    const double* ownq = own + qo;
-    const double* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 3 * 16 : own;
+    const R* ownq = own + qo;
+    const R* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 3 * 16 : own;
     auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 3 * 16; };
     // operator tiles are item-invariant: an opaque lane offset keeps the compiler from hoisting
     // all of them into registers (and, unlike a laundered pointer, keeps the reads ds_read_b64)
     int lo = lane;
     asm volatile("" : "+v"(lo));
 
-    double Jm[3][3], cnf[4][3];  // class constants (wave-uniform)
+    R Jm[3][3], cnf[4][3];  // class constants (wave-uniform)
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Jm[r][j] = -md->Jinv[k][r][j];
+      for (int j = 0; j < 3; ++j) Jm[r][j] = (R)(-md->Jinv[k][r][j]);
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) cnf[f][j] = md->cn[k][f][j];
+      for (int j = 0; j < 3; ++j) cnf[f][j] = (R)md->cn[k][f][j];
 
-    double Sd[3][S4], So[3][S4];  // W_ii and W_ij + W_ji for (0,1), (0,2), (1,2)
+    R Sd[3][S4], So[3][S4];  // W_ii and W_ij + W_ji for (0,1), (0,2), (1,2)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = 0.0;
+      for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = R(0);
 
-    double nx[2][KSF][3];  // neighbour traces: facet f in nx[f & 1], facet f + 1 on its way into the other
-    auto request = [&](int f, double (&dst)[KSF][3]) {
-      const NbrRef R = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
+    R nx[2][KSF][3];  // neighbour traces: facet f in nx[f & 1], facet f + 1 on its way into the other
+    auto request = [&](int f, R (&dst)[KSF][3]) {
+      const NbrRef<R> NR = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
         const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
         const int on = sMd.fnode[f][bb];
-        const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
+        const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) dst[ks][i] = R.p[(nn * 3 + i) * R.cstride];
+        for (int i = 0; i < 3; ++i) dst[ks][i] = NR.p[(nn * 3 + i) * NR.cstride];
       }
     };
     SG_PRIO(SG_PRIO_HI);
@@ -397,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     //      through L1/L2); 3*MTF accumulator tiles + 3*NSM values are live next to Sd/So.
     {
       constexpr int NS = 3 * KS;
-      double bq[PF][3];
+      R bq[PF][3];
 #pragma unroll
       for (int s = 0; s < PF; ++s)
 #pragma unroll
@@ -405,18 +434,18 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         d4 acc[M::MTFA][3];
-        double accs[NSM][3];
+        R accs[M::NSMA][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
           for (int t = 0; t < MTF; ++t) acc[t][i] = d4{0, 0, 0, 0};
 #pragma unroll
-          for (int t = 0; t < NSM; ++t) accs[t][i] = 0.0;
+          for (int t = 0; t < NSM; ++t) accs[t][i] = R(0);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int s = r * KS + ks;
-          double b[3];
+          R b[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) b[i] = bq[s % PF][i];
           if (s + PF < NS) {
@@ -425,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
           }
 #pragma unroll
           for (int t = 0; t < MTT; ++t) {
-            const double a = sAV[((r * MTT + t) * KS + ks) * 64 + lo];
+            const R a = sAV[((r * MTT + t) * KS + ks) * 64 + lo];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
               if (t < MTF)
@@ -439,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         // zero columns are skipped with a scalar branch (the class is uniform over the wave)
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
-          const double c = Jm[r][kk];
+          const R c = Jm[r][kk];
           if (uniform_nonzero(c)) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -447,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
               for (int t = 0; t < MTF; ++t)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
+                  if (4 * t + reg >= S4) continue;  // padded rows of the last float tile
                   if (i == kk)
                     Sd[i][4 * t + reg] += c * acc[t][i][reg];
                   else
@@ -485,22 +515,22 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
       request(0, nx[0]);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        double(&flf)[KSF][3] = nx[f & 1];
+        R(&flf)[KSF][3] = nx[f & 1];
 #pragma unroll
         for (int t = 0; t < MTT; ++t) {
           // next facet's traces: asked for a whole facet ahead
           if (t == 0 && f + 1 < 4) request(f + 1, nx[(f + 1) & 1]);
           // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
-          auto fold = [&](int m0, int nm, const double (&v)[3][4]) {
+          auto fold = [&](int m0, int nm, const R (&v)[3][4]) {
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
-              const double c = cnf[f][kk];
+              const R c = cnf[f][kk];
               if (uniform_nonzero(c)) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                   for (int j = 0; j < 4; ++j)
-                    if (j < nm) {
+                    if (j < nm && m0 + j < S4) {
                       if (i == kk)
                         Sd[i][m0 + j] += c * v[i][j];
                       else
@@ -510,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (j < nm) {
+              if (j < nm && m0 + j < S4) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m0 + j]), "+v"(So[i][m0 + j]));
               }
@@ -521,12 +551,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
             for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KSF; ++ks) {
-              const double a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
 #pragma unroll
               for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
             }
             {
-              double v[3][4];
+              R v[3][4];
 #pragma unroll
               for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -534,15 +564,15 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
               fold(4 * t, 4, v);
             }
           } else {
-            double tmp[3] = {0.0, 0.0, 0.0};
+            R tmp[3] = {R(0), R(0), R(0)};
 #pragma unroll
             for (int ks = 0; ks < KSF; ++ks) {
-              const double a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
 #pragma unroll
               for (int i = 0; i < 3; ++i) tmp[i] = MFMA4(a, flf[ks][i], tmp[i]);
             }
             {
-              const double v[3][4] = {{tmp[0], 0, 0, 0}, {tmp[1], 0, 0, 0}, {tmp[2], 0, 0, 0}};
+              const R v[3][4] = {{tmp[0], 0, 0, 0}, {tmp[1], 0, 0, 0}, {tmp[2], 0, 0, 0}};
               fold(4 * MTF + (t - MTF), 1, v);
             }
           }
@@ -559,8 +589,8 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
     //      results in place in Sd/So, and issue the item's stores back to back at the very end.
     {
       const long e = (L.valid ? L.c : 0) * 6 + k;
-      const double lam = A.per_cell ? A.lam[e] : A.lam0;
-      const double mu = A.per_cell ? A.mu[e] : A.mu0;
+      const R lam = (R)(A.per_cell ? A.lam[e] : A.lam0);
+      const R mu = (R)(A.per_cell ? A.mu[e] : A.mu0);
       const long obase = ((g * 6 + k) * (long)ND) * 9 * 16 + w;
       // row-quad m of this lane = node 4 m + q: per-item base + compile-time offsets (see brow)
       int qo9 = q * 9 * 16;
@@ -574,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 #define SG_PDE 4
 #endif
         constexpr int PDE = SG_PDE;      // row-quads of old values in flight (MODE 1)
-        double po[PDE][6], pa[PDE][6];
+        R po[PDE][6], pa[PDE][6];
         auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
         auto fetch_old = [&](int m) {
           const long o1 = orow(m);
@@ -590,20 +620,20 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         }
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
-          const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+          const R tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            Sd[i][m] = 2.0 * mu * Sd[i][m] + tr;
+            Sd[i][m] = R(2) * mu * Sd[i][m] + tr;
             So[i][m] = mu * So[i][m];
           }
           if (MODE == 1) {
             // line order of the six slots: Sd0 So0 So1 Sd1 So2 Sd2
-            Sd[0][m] = A.c_self * po[m % PDE][0] + A.c_aux * pa[m % PDE][0] + A.c_new * Sd[0][m];
-            So[0][m] = A.c_self * po[m % PDE][1] + A.c_aux * pa[m % PDE][1] + A.c_new * So[0][m];
-            So[1][m] = A.c_self * po[m % PDE][2] + A.c_aux * pa[m % PDE][2] + A.c_new * So[1][m];
-            Sd[1][m] = A.c_self * po[m % PDE][3] + A.c_aux * pa[m % PDE][3] + A.c_new * Sd[1][m];
-            So[2][m] = A.c_self * po[m % PDE][4] + A.c_aux * pa[m % PDE][4] + A.c_new * So[2][m];
-            Sd[2][m] = A.c_self * po[m % PDE][5] + A.c_aux * pa[m % PDE][5] + A.c_new * Sd[2][m];
+            Sd[0][m] = c_self * po[m % PDE][0] + c_aux * pa[m % PDE][0] + c_new * Sd[0][m];
+            So[0][m] = c_self * po[m % PDE][1] + c_aux * pa[m % PDE][1] + c_new * So[0][m];
+            So[1][m] = c_self * po[m % PDE][2] + c_aux * pa[m % PDE][2] + c_new * So[1][m];
+            Sd[1][m] = c_self * po[m % PDE][3] + c_aux * pa[m % PDE][3] + c_new * Sd[1][m];
+            So[2][m] = c_self * po[m % PDE][4] + c_aux * pa[m % PDE][4] + c_new * So[2][m];
+            Sd[2][m] = c_self * po[m % PDE][5] + c_aux * pa[m % PDE][5] + c_new * Sd[2][m];
             if (m + PDE < S4) fetch_old(m + PDE);
           }
 #pragma unroll
@@ -634,16 +664,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
         for (int m = 0; m < S4; ++m) {
           const int a = 4 * m + q;
           const long o = orow(m);
-          const double tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
-          double s[9];
-          s[0] = 2.0 * mu * Sd[0][m] + tr;
-          s[4] = 2.0 * mu * Sd[1][m] + tr;
-          s[8] = 2.0 * mu * Sd[2][m] + tr;
+          const R tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+          R s[9];
+          s[0] = R(2) * mu * Sd[0][m] + tr;
+          s[4] = R(2) * mu * Sd[1][m] + tr;
+          s[8] = R(2) * mu * Sd[2][m] + tr;
           s[1] = s[3] = mu * So[0][m];
           s[2] = s[6] = mu * So[1][m];
           s[5] = s[7] = mu * So[2][m];
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij) s[ij] = A.c_self * out[o + ij * 16] + A.c_aux * aux[o + ij * 16] + A.c_new * s[ij];
+          for (int ij = 0; ij < 9; ++ij) s[ij] = c_self * out[o + ij * 16] + c_aux * aux[o + ij * 16] + c_new * s[ij];
           if (L.active && a < ND) {
 #pragma unroll
             for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
@@ -660,12 +690,13 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_G(StageArgs A) {
 // --------------------------------------------------------------------------------------------
 //  F: uh_i = -sum_r D_r (Jinv_rj T_ij) + sum_f L_f [ (c n)_j {T_ij} ] - sponge
 // --------------------------------------------------------------------------------------------
-template <int P, int MODE, int SYM, int GHOST>
-__global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
-  using M = MG<P>;
+template <typename R, int P, int MODE, int SYM, int GHOST>
+__global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(StageArgs A) {
+  using M = MG<P, R>;
+  typedef typename RT<R>::v4 d4;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
-  __shared__ double sAV[M::NFRAG_F * 64];
-  __shared__ double sAL[M::NFRAG_L * 64];
+  __shared__ R sAV[M::NFRAG_F * 64];
+  __shared__ R sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
   load_tables<M::NFRAG_F, M::NFRAG_L>(sAV, sAL, &sMd, A);
 
@@ -674,9 +705,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   const int q = lane >> 4, w = lane & 15;
   typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
   const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
-  const double* __restrict__ in = A.in;
-  const double* __restrict__ aux = A.aux;
-  double* __restrict__ out = A.out;
+  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
+  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
+  R* __restrict__ out = reinterpret_cast<R*>(A.out);
+  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread);
 
@@ -688,34 +720,34 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
     if (!__any(L.active)) continue;
-    const double* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+    const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
     int qo = q * 9 * 16;  // B rows: see mfma_stage_G
     asm volatile("" : "+v"(qo));
-    const double* ownq = own + qo;
-    const double* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 9 * 16 : own;
+    const R* ownq = own + qo;
+    const R* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 9 * 16 : own;
     auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 9 * 16; };
     int lo = lane;
     asm volatile("" : "+v"(lo));
 
-    double Jm[3][3], cnf[4][3];
+    R Jm[3][3], cnf[4][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Jm[r][j] = md->Jinv[k][r][j];
+      for (int j = 0; j < 3; ++j) Jm[r][j] = (R)md->Jinv[k][r][j];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) cnf[f][j] = md->cn[k][f][j];
+      for (int j = 0; j < 3; ++j) cnf[f][j] = (R)md->cn[k][f][j];
 
     // rows 16t + 4reg + q in acc[i][t][reg] (large tiles), row 16*MTF + 4s + q in accs[i][s] (small)
     d4 acc[3][M::MTFA];
-    double accs[3][NSM];
+    R accs[3][M::NSMA];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
       for (int t = 0; t < MTF; ++t) acc[i][t] = d4{0, 0, 0, 0};
 #pragma unroll
-      for (int t = 0; t < NSM; ++t) accs[i][t] = 0.0;
+      for (int t = 0; t < NSM; ++t) accs[i][t] = R(0);
     }
 
     SG_PRIO(SG_PRIO_HI);
@@ -726,12 +758,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #define SG_PFV 1
 #endif
       constexpr int PFV = SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
-      double Tq[PFV][9];
+      R Tq[PFV][9];
 #pragma unroll
       for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        double T[9];
+        R T[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) T[c] = Tq[ks % PFV][c];
         if (ks + PFV < KS) {
@@ -739,12 +771,12 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          double Tt[3];
+          R Tt[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
 #pragma unroll
           for (int t = 0; t < MTT; ++t) {
-            const double a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
+            const R a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
               if (t < MTF)
@@ -767,27 +799,27 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #define SG_PFLF 2
 #endif
     constexpr int PFL = SG_PFLF;  // facet k-steps of neighbour traces in flight
-    const double* np[4];
-    double wf[4];
+    const R* np[4];
+    R wf[4];
     int noff[4][KSF];
     bool gh[4];
     int fax[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      const NbrRef R = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
-      np[f] = R.p;
-      gh[f] = GHOST && R.ghost;
+      const NbrRef<R> NR = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
+      np[f] = NR.p;
+      gh[f] = GHOST && NR.ghost;
       fax[f] = GHOST ? __builtin_amdgcn_readfirstlane(sMd.nb_axis[k][f]) : 0;
-      wf[f] = R.physical ? -1.0 : 1.0;
+      wf[f] = NR.physical ? R(-1) : R(1);
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
         const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
         const int on = sMd.fnode[f][bb];
-        const int nn = R.ghost ? sMd.nb_fnode[k][f][bb] : (R.physical ? on : sMd.nb_node[k][f][bb]);
-        noff[f][ks] = R.ghost ? nn * 3 : nn * 9 * R.cstride;
+        const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
+        noff[f][ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
       }
     }
-    double nq[PFL][9];
+    R nq[PFL][9];
     {
       constexpr int NS = 4 * KSF;
 #pragma unroll
@@ -798,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks) {
           const int s = f * KSF + ks;
-          double fl[3];
+          R fl[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i)
             fl[i] = wf[f] * (cnf[f][0] * nq[s % PFL][i * 3 + 0] + cnf[f][1] * nq[s % PFL][i * 3 + 1] +
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
           }
 #pragma unroll
           for (int t = 0; t < MTT; ++t) {
-            const double a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+            const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
               if (t < MTF)
@@ -836,15 +868,16 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
       const int slot = L.active ? A.sponge_slot[e] : -1;
       if (__any(slot >= 0)) {
         if (slot >= 0) {
-          auto damp = [&](int a, double& r0, double& r1, double& r2) {
+          auto damp = [&](int a, R& r0, R& r1, R& r2) {
             if (a < ND) {
-              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
-              double s0 = 0, s1 = 0, s2 = 0;
+              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;   // sponge matrices stay double
+              const R* ua = reinterpret_cast<const R*>(A.uabs);
+              R s0 = 0, s1 = 0, s2 = 0;
               for (int b = 0; b < ND; ++b) {
-                const double bb = B[b];
-                s0 += bb * A.uabs[ubase + (b * 3 + 0) * 16];
-                s1 += bb * A.uabs[ubase + (b * 3 + 1) * 16];
-                s2 += bb * A.uabs[ubase + (b * 3 + 2) * 16];
+                const R bb = (R)B[b];
+                s0 += bb * ua[ubase + (b * 3 + 0) * 16];
+                s1 += bb * ua[ubase + (b * 3 + 1) * 16];
+                s2 += bb * ua[ubase + (b * 3 + 2) * 16];
               }
               r0 -= s0;
               r1 -= s1;
@@ -855,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
           for (int t = 0; t < MTF; ++t)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-              double r0 = acc[0][t][reg], r1 = acc[1][t][reg], r2 = acc[2][t][reg];
+              R r0 = acc[0][t][reg], r1 = acc[1][t][reg], r2 = acc[2][t][reg];
               damp(16 * t + 4 * reg + q, r0, r1, r2);
               acc[0][t][reg] = r0;
               acc[1][t][reg] = r1;
@@ -870,20 +903,22 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
     // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345).
     //      All loads first (results built in place in the accumulators), all stores last: see G.
     if (MODE == 1) {
-      double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      R cs = c_self, ca = c_aux, cn = c_new;
       if (A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
-        cs = A.rho2[2 * e];
-        ca *= A.rho2[2 * e + 1];
-        cn *= A.rho2[2 * e + 1];
+        cs = (R)A.rho2[2 * e];
+        ca *= (R)A.rho2[2 * e + 1];
+        cn *= (R)A.rho2[2 * e + 1];
       }
       // every old value of the item is requested before the first one is used: one memory latency
       // per item instead of one per row tile (the lifts' registers are free by now)
-      double po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[NSM][3], pas[NSM][3];
+      R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
 #pragma unroll
       for (int t = 0; t < MTF; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
+          // the last float tile is zero-padded: its rows beyond ND read a valid address and are not stored
+          const bool row_ok = RT<R>::SMALL || (16 * t + 4 * reg + q < ND);
+          const long o = row_ok ? ub_q + (long)(16 * t + 4 * reg) * 3 * 16 : ubase;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
@@ -906,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            double v = cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg];
+            R v = cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg];
             asm volatile("" : "+v"(v));
             acc[i][t][reg] = v;
           }
@@ -924,8 +959,10 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
+          if (RT<R>::SMALL || (16 * t + 4 * reg + q < ND)) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], acc[i][t][reg]);
+            for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], acc[i][t][reg]);
+          }
         }
 #pragma unroll
       for (int t = 0; t < NSM; ++t) {
@@ -943,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void mfma_stage_F(StageArgs A) {
   STAMP_FLUSH;
 }
 
-template <int P, int SYM>
+template <typename R, int P, int SYM>
 static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
   // persistent grid, at most 2 blocks per CU; a multiple of 8 (one item range per XCD label)
   const dim3 grid((unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512)), block(256);
@@ -953,27 +990,27 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
     for (int sd = 0; sd < 6; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
     if (a.mode == 0) {
       if (ghosts)
-        hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM, 1>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((mfma_stage_F<R, P, 0, SYM, 1>), grid, block, 0, s, a);
       else
-        hipLaunchKernelGGL((mfma_stage_F<P, 0, SYM, 0>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((mfma_stage_F<R, P, 0, SYM, 0>), grid, block, 0, s, a);
     } else {
       if (ghosts)
-        hipLaunchKernelGGL((mfma_stage_F<P, 1, SYM, 1>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((mfma_stage_F<R, P, 1, SYM, 1>), grid, block, 0, s, a);
       else
-        hipLaunchKernelGGL((mfma_stage_F<P, 1, SYM, 0>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((mfma_stage_F<R, P, 1, SYM, 0>), grid, block, 0, s, a);
     }
   } else {
     if (a.mode == 0)
-      hipLaunchKernelGGL((mfma_stage_G<P, 0, SYM>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((mfma_stage_G<R, P, 0, SYM>), grid, block, 0, s, a);
     else
-      hipLaunchKernelGGL((mfma_stage_G<P, 1, SYM>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((mfma_stage_G<R, P, 1, SYM>), grid, block, 0, s, a);
   }
   return (int)hipGetLastError();
 }
 
-template <int P>
+template <typename R, int P>
 static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
-  return a.sym ? launch_ps<P, 1>(kind, a, s) : launch_ps<P, 0>(kind, a, s);
+  return a.sym ? launch_ps<R, P, 1>(kind, a, s) : launch_ps<R, P, 0>(kind, a, s);
 }
 
 bool mfma_supported(int dim, int P) { return dim == 3 && P >= 1 && P <= 4; }
@@ -981,15 +1018,27 @@ bool mfma_supported(int dim, int P) { return dim == 3 && P >= 1 && P <= 4; }
 // resident blocks per CU the persistent grid is sized for: registers and LDS allow exactly two at
 // degrees 3 and 4 (a third block at degree 3 measured slower); the low orders are memory-bound and
 // light (64 / 166 VGPRs, 12 / 28 KB of tiles) and want more waves in flight
-int mfma_blocks_per_cu(int P) { return P == 1 ? 4 : (P == 2 ? 3 : 2); }
+int mfma_blocks_per_cu(int P, int f32) {
+  if (f32) return 3;   // float kernels: at most 168 VGPRs (launch bound) and half the table bytes
+  return P == 1 ? 4 : (P == 2 ? 3 : 2);
+}
 
 int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.f32) {
+    switch (P) {
+      case 1: return launch_p<float, 1>(kind, a, s);
+      case 2: return launch_p<float, 2>(kind, a, s);
+      case 3: return launch_p<float, 3>(kind, a, s);
+      case 4: return launch_p<float, 4>(kind, a, s);
+    }
+    return -1;
+  }
   switch (P) {
-    case 1: return launch_p<1>(kind, a, s);
-    case 2: return launch_p<2>(kind, a, s);
-    case 3: return launch_p<3>(kind, a, s);
-    case 4: return launch_p<4>(kind, a, s);
+    case 1: return launch_p<double, 1>(kind, a, s);
+    case 2: return launch_p<double, 2>(kind, a, s);
+    case 3: return launch_p<double, 3>(kind, a, s);
+    case 4: return launch_p<double, 4>(kind, a, s);
   }
   return -1;
 }

@@ -79,4 +79,46 @@ std::vector<double> mfma_frags_L(const RefElem& re) {
   return out;
 }
 
+// ---- float tables --------------------------------------------------------------------------------
+static inline int tile_row32(int t, int l) { return 16 * t + 4 * (l & 3) + ((l & 15) >> 2); }
+
+std::vector<float> mfma32_frags_F(const RefElem& re) {
+  const int ks = (re.nd + 3) / 4, mtt = (re.nd + 15) / 16;
+  std::vector<float> out((size_t)mtt * 3 * ks * 64, 0.0f);
+  for (int t = 0; t < mtt; ++t)
+    for (int r = 0; r < 3; ++r)
+      for (int k0 = 0; k0 < ks; ++k0) {
+        size_t frag = (size_t)t * 3 * ks + (size_t)ks * r + k0;
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = (float)-Eval(re, r, tile_row32(t, l), 4 * k0 + (l >> 4));
+      }
+  return out;
+}
+
+std::vector<float> mfma32_frags_G(const RefElem& re) {
+  const int ks = (re.nd + 3) / 4, mtt = (re.nd + 15) / 16;
+  std::vector<float> out((size_t)3 * mtt * ks * 64, 0.0f);
+  for (int r = 0; r < 3; ++r)
+    for (int t = 0; t < mtt; ++t)
+      for (int k0 = 0; k0 < ks; ++k0) {
+        size_t frag = ((size_t)r * mtt + t) * ks + k0;
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = (float)Eval(re, r, tile_row32(t, l), 4 * k0 + (l >> 4));
+      }
+  return out;
+}
+
+std::vector<float> mfma32_frags_L(const RefElem& re) {
+  const int ksf = (re.nf + 3) / 4, mtt = (re.nd + 15) / 16;
+  std::vector<float> out((size_t)re.nfaces * mtt * ksf * 64, 0.0f);
+  for (int f = 0; f < re.nfaces; ++f)
+    for (int t = 0; t < mtt; ++t)
+      for (int k0 = 0; k0 < ksf; ++k0) {
+        size_t frag = ((size_t)f * mtt + t) * ksf + k0;
+        for (int l = 0; l < 64; ++l) {
+          int a = tile_row32(t, l), b = 4 * k0 + (l >> 4);
+          out[frag * 64 + l] = (a < re.nd && b < re.nf) ? (float)(0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b]) : 0.0f;
+        }
+      }
+  return out;
+}
+
 }  // namespace sg

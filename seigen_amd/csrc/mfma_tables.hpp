@@ -45,4 +45,13 @@ std::vector<double> mfma_frags_G(const RefElem& re);
 // (the 1/2 of the central flux average: both kernels lift +-1/2 of a neighbour trace)
 std::vector<double> mfma_frags_L(const RefElem& re);
 
+// The same three tables for the float kernels (v_mfma_f32_16x16x4_f32): every row tile is a
+// 16-row tile (ceil(nd / 16) of them, the last one zero-padded), and lane l of tile t holds the
+// operator row of node 16 t + 4 (l & 3) + ((l & 15) >> 2): the f32 shape returns row 4 q + reg in
+// register reg of lane group q where the f64 shape returns row 4 reg + q, and with this permutation
+// both leave node 16 t + 4 reg + q there.  Fragment order as above with mtt = ceil(nd / 16).
+std::vector<float> mfma32_frags_F(const RefElem& re);
+std::vector<float> mfma32_frags_G(const RefElem& re);
+std::vector<float> mfma32_frags_L(const RefElem& re);
+
 }  // namespace sg

@@ -46,24 +46,26 @@ class ElasticLF4(object):
     Create with ``ElasticLF4.create(mesh, family, degree, dimension, solver)``."""
 
     @staticmethod
-    def create(mesh, family, degree, dimension, solver="explicit", output=True):
+    def create(mesh, family, degree, dimension, solver="explicit", output=True, dtype="f64"):
         """Same signature and solver strings as ``seigen/elastic.py:27-64``; every
         explicit mode ('explicit', 'parloop', 'fusion', 'tiling', and the alias
-        'hip') runs the fused HIP path."""
+        'hip') runs the fused HIP path.  ``dtype`` (not in the reference, which is double
+        throughout, ``:442``): 'f64', or 'f32' for the FP32 second mode (3-D blocks)."""
         if solver == "implicit":
-            return ImplicitElasticLF4(mesh, family, degree, dimension, output=output)
+            return ImplicitElasticLF4(mesh, family, degree, dimension, output=output, dtype=dtype)
         elif solver in ("explicit", "hip"):
-            return ExplicitElasticLF4(mesh, family, degree, dimension, output=output)
+            return ExplicitElasticLF4(mesh, family, degree, dimension, output=output, dtype=dtype)
         elif solver == "parloop":
-            return TilingElasticLF4(mesh, family, degree, dimension, output=output, tiling_mode=None)
+            return TilingElasticLF4(mesh, family, degree, dimension, output=output, dtype=dtype, tiling_mode=None)
         elif solver == "fusion":
-            return TilingElasticLF4(mesh, family, degree, dimension, output=output, tiling_mode="hard")
+            return TilingElasticLF4(mesh, family, degree, dimension, output=output, dtype=dtype, tiling_mode="hard")
         elif solver == "tiling":
-            return TilingElasticLF4(mesh, family, degree, dimension, output=output, tiling_mode="tile")
+            return TilingElasticLF4(mesh, family, degree, dimension, output=output, dtype=dtype, tiling_mode="tile")
         else:
             raise ValueError("Unknown solver mode. Must be one of: implicit, explicit, parloop")
 
-    def __init__(self, mesh, family, degree, dimension, output=True):
+    def __init__(self, mesh, family, degree, dimension, output=True, dtype="f64"):
+        self.dtype = dtype
         with timed_region('function setup'):
             if dimension != mesh.dim:
                 raise ValueError("dimension=%r does not match the mesh (%d-D)" % (dimension, mesh.dim))
@@ -132,7 +134,7 @@ class ElasticLF4(object):
         part = self.mesh.partition
         origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
         block = HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin, self.mesh.diagonal,
-                         part.nbr_mask, device=_device_for_rank())
+                         part.nbr_mask, device=_device_for_rank(), dtype=self.dtype)
         self._torch_stream = None
         if part.world > 1:
             # One process per GPU: the library's launch stream, wrapped for torch, is made current

@@ -85,14 +85,17 @@ class HaloExchanger(object):
         self.hsend, self.hrecv = {}, {}
         self.sides = [s for s in range(2 * partition.dim) if partition.neighbour(s) is not None]
         self.send, self.recv = {}, {}
+        # halo buffers hold the block's device type (float in the FP32 mode)
+        tdt, esz = (torch.float32, 4) if getattr(block, "dtype", "f64") == "f32" else (torch.float64, 8)
+        self.elem_bytes = esz
         for kind, field in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S)):
             for s in self.sides:
-                n = block.halo_bytes(field, s) // 8
-                self.send[(kind, s)] = torch.zeros(n, dtype=torch.float64, device=device)
-                self.recv[(kind, s)] = torch.zeros(n, dtype=torch.float64, device=device)
+                n = block.halo_bytes(field, s) // esz
+                self.send[(kind, s)] = torch.zeros(n, dtype=tdt, device=device)
+                self.recv[(kind, s)] = torch.zeros(n, dtype=tdt, device=device)
                 if self.staged:
-                    self.hsend[(kind, s)] = torch.zeros(n, dtype=torch.float64).pin_memory()
-                    self.hrecv[(kind, s)] = torch.zeros(n, dtype=torch.float64).pin_memory()
+                    self.hsend[(kind, s)] = torch.zeros(n, dtype=tdt).pin_memory()
+                    self.hrecv[(kind, s)] = torch.zeros(n, dtype=tdt).pin_memory()
         # both fields of a kind read the same ghost buffer: a buffer is consumed by the stage
         # that follows its exchange before the next exchange of that kind starts
         for field in (_lib.FIELD_U, _lib.FIELD_UH, _lib.FIELD_S, _lib.FIELD_SH):
@@ -135,7 +138,7 @@ class HaloExchanger(object):
         else:
             for s in self.sides:
                 self.block.halo_pack(field, s, self.send[(kind, s)].data_ptr())
-        self.bytes_sent += sum(self.send[(kind, s)].numel() * 8 for s in self.sides)
+        self.bytes_sent += sum(self.send[(kind, s)].numel() * self.elem_bytes for s in self.sides)
         if not self.sides:
             return (kind, [])
         if self.staged:

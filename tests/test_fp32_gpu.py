@@ -1,0 +1,104 @@
+"""The FP32 second mode (sg_config.dtype = 1; SURVEY 8b `dtype`, 8d "optional second mode, 32 B per
+DoF-update"): float storage and arithmetic on the 3-D MFMA path (v_mfma_f32_16x16x4_f32).
+The reference is FP64 throughout (seigen/elastic.py:442), so this mode is checked against the same
+FP64 oracle with float tolerances, stated here:
+
+  * one operator application: 2e-5 of the largest entry (35-term dot products of float products,
+    operator entries up to about 60);
+  * a few LF4 steps: 5e-5;
+  * eigenmode error functional (eigenmode_3d.py:42-69) after 40 steps: within 2e-5 of the FP64 value.
+
+FP64 stays the parity and headline mode; nothing here relaxes a FP64 tolerance.
+"""
+import numpy as np
+import pytest
+
+from oracle.forms import ElasticOperators
+from oracle.lf4 import OracleLF4
+from tests.util import oracle_mesh, rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(2, (2, 3, 2), (1.0, 1.5, 0.5)), (3, (2, 2, 2), (1.0, 1.0, 1.0)), (4, (2, 2, 2), (1.0, 1.0, 1.0)),
+         (4, (3, 1, 2), (1.0, 1.0, 1.0)), (3, (17, 2, 1), (2.0, 1.0, 1.0))]
+
+
+def _block(degree, n, L, **kw):
+    from seigen_amd.backend import HipBlock
+    return HipBlock(3, degree, n, [L[a] / n[a] for a in range(3)], [0.0] * 3, dtype="f32", **kw)
+
+
+@pytest.mark.parametrize("degree,n,L", CASES)
+def test_fp32_operators_against_the_fp64_oracle(gpu, degree, n, L):
+    from seigen_amd import _lib
+    blk = _block(degree, n, L)
+    E = ElasticOperators(oracle_mesh(3, n, L), degree)
+    T = seeded(blk.field_shape(_lib.FIELD_S), 0)
+    T = 0.5 * (T + np.swapaxes(T, -1, -2))
+    u = seeded(blk.field_shape(_lib.FIELD_U), 1)
+    blk.set_params(1.0, 0.01, 0.7, 0.3)
+    blk.set_field(_lib.FIELD_S, T)
+    blk.set_field(_lib.FIELD_U, u)
+    # fields come back as what float holds
+    assert rel_err(blk.get_field(_lib.FIELD_U), u.astype(np.float32).astype(np.float64)) == 0.0
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    assert rel_err(blk.get_field(_lib.FIELD_UH), E.apply_F(T, u)) < 2e-5
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, 0.7, 0.3)) < 2e-5
+    # the full-tensor kernels (a non-symmetric stress leaves symmetric storage)
+    Ta = seeded(blk.field_shape(_lib.FIELD_S), 5)
+    blk.set_field(_lib.FIELD_S, Ta)
+    assert not blk.is_sym()
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    assert rel_err(blk.get_field(_lib.FIELD_UH), E.apply_F(Ta, u)) < 2e-5
+
+
+@pytest.mark.parametrize("degree,n,L", CASES[:4])
+def test_fp32_full_steps(gpu, degree, n, L):
+    from seigen_amd import _lib
+    blk = _block(degree, n, L)
+    orc = OracleLF4(oracle_mesh(3, n, L), degree)
+    orc.dt = 0.05 * min(L[a] / n[a] for a in range(3)) / degree ** 2
+    orc.l, orc.mu, orc.density = 0.5, 0.25, 1.0
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 2)
+    s0 = seeded(blk.field_shape(_lib.FIELD_S), 3)
+    orc.s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+    blk.set_params(1.0, orc.dt, orc.l, orc.mu)
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(3)
+    for k in range(3):
+        orc.step((k + 1) * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 5e-5
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 5e-5
+
+
+def test_fp32_eigenmode_error_close_to_fp64(gpu):
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    import seigen_amd.harness.eigenmode as he
+    helpers.log = seigen_amd.elastic.log = he.log = lambda s: None
+    N, P = 4, 3
+    dt = 0.5 * (1.0 / N) / 2 ** (P - 1)
+    errs = {}
+    for dtype in ("f64", "f32"):
+        em = he.Eigenmode3DLF4(N, P, dt, output=False)
+        em.elastic = seigen_amd.ElasticLF4.create(em.mesh, "DG", P, dimension=3, solver="explicit", output=False, dtype=dtype)
+        em.elastic.density, em.elastic.dt, em.elastic.mu, em.elastic.l = 1.0, dt, 0.25, 0.5
+        u1, s1 = em.eigenmode3d(T=5.0)
+        errs[dtype] = em.eigenmode_error(u1, s1)
+    assert abs(errs["f32"][0] - errs["f64"][0]) < 2e-5 and abs(errs["f32"][1] - errs["f64"][1]) < 2e-5, errs
+    assert errs["f64"][0] < 2e-3
+
+
+@pytest.mark.parametrize("degree,n,grid", [(4, (4, 2, 4), (2, 1, 2)), (3, (9, 9, 9), (3, 3, 3))])
+def test_fp32_multiblock_equals_single_block_bitwise(gpu, degree, n, grid):
+    from tests.test_harness_gpu import _multiblock_case
+    _multiblock_case(3, degree, n, grid, True, extras=True, dtype="f32")
+
+
+def test_fp32_needs_the_mfma_path(gpu):
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    with pytest.raises(_lib.SeigenHipError, match="f32"):
+        HipBlock(2, 2, (4, 4), (0.25, 0.25), (0.0, 0.0), dtype="f32")

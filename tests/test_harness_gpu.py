@@ -156,9 +156,9 @@ class _LocalExchange(object):
                 for s in range(2 * p.dim):
                     if p.neighbour(s) is None:
                         continue
-                    n = b.halo_bytes(field, s) // 8
-                    snd[(kind, s)] = torch.zeros(n, dtype=torch.float64, device="cuda")
-                    rcv[(kind, s)] = torch.zeros(n, dtype=torch.float64, device="cuda")
+                    n = b.halo_bytes(field, s)          # raw bytes: the library knows what the buffers hold
+                    snd[(kind, s)] = torch.zeros(n, dtype=torch.uint8, device="cuda")
+                    rcv[(kind, s)] = torch.zeros(n, dtype=torch.uint8, device="cuda")
             for field in range(4):
                 kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
                 for s in range(2 * p.dim):
@@ -208,7 +208,7 @@ class _LocalExchange(object):
                 b.end_step()
 
 
-def _multiblock_case(dim, degree, n, grid, pipelined, extras=False):
+def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64"):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -217,7 +217,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False):
     from seigen_amd.mesh import Partition
     L = tuple(1.0 for _ in range(dim))
     h = [L[a] / n[a] for a in range(dim)]
-    single = HipBlock(dim, degree, n, h, [0.0] * dim)
+    single = HipBlock(dim, degree, n, h, [0.0] * dim, dtype=dtype)
     u0 = seeded(single.field_shape(_lib.FIELD_U), 11)
     s0 = seeded(single.field_shape(_lib.FIELD_S), 12)
     dt = 0.02 * min(h) / degree ** 2
@@ -263,7 +263,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False):
     blocks = []
     for p in parts:
         origin = [p.start[a] * h[a] for a in range(dim)]
-        b = HipBlock(dim, degree, p.n, h, origin, "left", p.nbr_mask)
+        b = HipBlock(dim, degree, p.n, h, origin, "left", p.nbr_mask, dtype=dtype)
         sel = cells_of(p)
         b.set_params(1.0, dt, 0.5, 0.25)
         b.set_field(_lib.FIELD_U, u0[sel])
