@@ -188,7 +188,7 @@ def main():
     # RCCL over xGMI, one rank per GPU.  SEIGEN_DIST_BACKEND=gloo (+ SEIGEN_HIP_DEVICE) runs the same
     # multi-process path with host-staged halos, e.g. two ranks on one GPU (tests/test_dist_gpu.py).
     backend = os.environ.get("SEIGEN_DIST_BACKEND", "nccl")
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:      # launched by torch.distributed.run: a process group even for one rank
         import torch
         import torch.distributed as dist
         dev_index = int(os.environ.get("SEIGEN_HIP_DEVICE", local_rank))
@@ -226,13 +226,13 @@ def main():
 
     def sync():
         blk.sync()
-        if world > 1:
+        if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
 
     def reduce_max(x):
-        if world == 1:
+        if dist is None:
             return x
         import torch
         t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -241,7 +241,7 @@ def main():
 
     def gather(x):
         """one float per rank -> list over ranks (on every rank)"""
-        if world == 1:
+        if dist is None:
             return [float(x)]
         import torch
         t = torch.tensor([float(x)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -394,7 +394,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

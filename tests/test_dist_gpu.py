@@ -115,3 +115,32 @@ def test_bench_starts_its_own_ranks(gpu):
     # a rank that cannot run (degree 9 does not exist) makes the whole command fail
     r = subprocess.run(cmd + ["--degree", "9"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rccl_transport_on_one_rank(gpu):
+    """The "nccl" branch of HaloExchanger (RCCL send/receive of device buffers on the launch stream) on the
+    test box's single GPU: one rank that is its own z-neighbour (tests/rccl_self_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("SEIGEN_DIST_BACKEND", "SEIGEN_HIP_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_self_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("rccl self-exchange ok") == 2, r.stdout
+
+
+def test_bench_one_rank_under_torchrun_with_rccl(gpu):
+    """bench.py as the driver launches it for N > 1, with the RCCL process group really initialised
+    (a world of one rank: collectives and the reductions of the line run over RCCL)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("SEIGEN_DIST_BACKEND", "SEIGEN_HIP_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--cubes", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+
