@@ -19,11 +19,8 @@
 namespace sg {
 
 template <int DIM, int P>
-struct Geo {
-  static constexpr int ND = (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
-  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
-  static constexpr int NFACES = DIM + 1;
-  static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
+struct Geo : ElemDims<DIM, P> {
+  using ElemDims<DIM, P>::ND;
   static constexpr int BLOCK = 256;
   static constexpr int EB_RAW = BLOCK / ND;
   static constexpr int EB = EB_RAW > 32 ? 32 : EB_RAW;  // cells per workgroup

@@ -9,6 +9,16 @@ namespace sg {
 // SG_REGION_FIRST of a 3-D block with neighbours on all six sides = half of the interior + six shell slabs
 constexpr int SG_MAX_BOXES = 7;
 
+// Node / facet counts of the P_k simplex element, shared by the three kernel families
+// (kernels.hip `Geo`, kernels_lane.hip `LG`, kernels_mfma.hip `MG`).
+template <int DIM, int P>
+struct ElemDims {
+  static constexpr int ND = (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
+  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
+  static constexpr int NFACES = DIM + 1;
+  static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
+};
+
 struct StageArgs {
   const double* in;    // stress for F, velocity for G           [cell][node][comp]
   double* out;         // result, or in-place target of a fused combine

@@ -22,12 +22,7 @@
 namespace sg {
 
 template <int DIM, int P>
-struct LG {
-  static constexpr int ND = (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
-  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
-  static constexpr int NFACES = DIM + 1;
-  static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
-};
+struct LG : ElemDims<DIM, P> {};
 
 struct LaneCell {
   long c;

@@ -52,8 +52,8 @@ struct RT<float> {
 
 template <int P, typename R>
 struct MG {
-  static constexpr int ND = (P + 1) * (P + 2) * (P + 3) / 6;
-  static constexpr int NF = (P + 1) * (P + 2) / 2;
+  static constexpr int ND = ElemDims<3, P>::ND;
+  static constexpr int NF = ElemDims<3, P>::NF;
   static constexpr int KS = (ND + 3) / 4;
   static constexpr int KSF = (NF + 3) / 4;
   static constexpr int MTF = RT<R>::SMALL ? ND / 16 : (ND + 15) / 16;        // 16-row tiles over the nodes
