@@ -433,3 +433,28 @@ def test_vtu_stream_round_trip(tmp_path):
         ss = VtuStream("stress", directory=str(tmp_path))
         _, sd = read_vtu(str(tmp_path / ss.write(s)))
         assert sd["StressNew"].shape == (ncells * (dim + 1), 9)
+
+
+@pytest.mark.parametrize("mesh,P", [(UnitSquareMesh(5, 4), 3), (UnitCubeMesh(2, 3, 2), 2), (IntervalMesh(7, 2.0), 4)])
+def test_interop_permutation_recovers_a_foreign_numbering(mesh, P):
+    """binding from a host with another cell / node order (Firedrake: DMPlex cells, FIAT nodes)
+    needs one permutation built from node coordinates; DG nodes coincide where cells touch, so it is built cell
+    by cell (seigen_amd/interop.py)."""
+    from seigen_amd.interop import dg_permutation
+    V = FunctionSpace(mesh, "DG", P)
+    ours = V.node_coords()
+    nc, nd, dim = ours.shape
+    rng = np.random.default_rng(3)
+    cell_perm = rng.permutation(nc)
+    theirs = np.empty_like(ours)
+    node_perms = []
+    for c_theirs, c_ours in enumerate(cell_perm):
+        q = rng.permutation(nd)
+        node_perms.append(q)
+        theirs[c_theirs] = ours[c_ours][q]
+    perm = dg_permutation(ours.reshape(-1, dim), theirs.reshape(-1, dim), nd)
+    np.testing.assert_array_equal(theirs.reshape(-1, dim)[perm], ours.reshape(-1, dim))
+    assert sorted(perm) == list(range(nc * nd))
+    with pytest.raises(ValueError):
+        dg_permutation(ours.reshape(-1, dim), (theirs + 0.01).reshape(-1, dim), nd)
+
