@@ -210,7 +210,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   const int64_t ncube_all = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->use_lane = !h->use_mfma && lane_supported(cfg->dim, cfg->degree) && !force_generic &&
                 (force_lane || ncube_all * h->ncls >= (cfg->degree == 1 ? 196608 : 120000));  // crossovers measured
-                                                                     // (tools/path_sweep.py, profiles/r02/lane_split_sweep_negative.txt)
+                                                                     // (tools/path_sweep.py, profiles/r02/small_2d_configs_negative_results.txt)
   if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
   h->f32 = cfg->dtype;
   if (h->f32 && !h->use_mfma)
