@@ -347,7 +347,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
 #ifndef SG_PF
 #define SG_PF 4
 #endif
-  constexpr int PF = SG_PF;  // B-operand prefetch distance, in k-steps
+  // B-operand prefetch distance, in k-steps.  A float k-step is 96 matrix cycles per component against 144 in
+  // double, so the same latency needs more k-steps in flight (measured: G<float,4,0> 1.10 -> 0.97 ms with 6, 0.94 with 8,
+  // which costs the fused kernel more than it gains)
+  constexpr int PF = sizeof(R) == 4 ? 6 : SG_PF;
   __shared__ R sAV[M::NFRAG_G * 64];
   __shared__ R sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #ifndef SG_PFV
 #define SG_PFV 1
 #endif
-      constexpr int PFV = SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
+      constexpr int PFV = sizeof(R) == 4 ? 2 : SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
       R Tq[PFV][9];
 #pragma unroll
       for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #ifndef SG_PFLF
 #define SG_PFLF 2
 #endif
-    constexpr int PFL = SG_PFLF;  // facet k-steps of neighbour traces in flight
+    constexpr int PFL = sizeof(R) == 4 ? 3 : SG_PFLF;  // facet k-steps of neighbour traces in flight
     const R* np[4];
     R wf[4];
     int noff[4][KSF];
