@@ -32,6 +32,7 @@ struct sg_handle {
   size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
   bool use_mfma = false;
   bool use_lane = false;
+  bool use_tile = false;    // 2-D MFMA tile kernels (kernels_tile2d.hip), gw = 16
   int f32 = 0;              // sg_config.dtype = 1: fields, halo buffers, operator tiles and arithmetic are float (MFMA path)
   bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
   int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
@@ -77,6 +78,8 @@ struct sg_handle {
   bool own_stream = false;
   int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
   int grid_full = 0;    // ... and otherwise (every block slot of the device)
+  T2Const t2c;          // 2-D tile kernels: kernarg copy of the mesh tables
+  int tile_grid = 0;    // 2-D tile kernels: cap of the grid in blocks of four waves (SEIGEN_HIP_TILE_GRID)
   // small blocks are launch-bound (config 1: six 5-us launches per step): sg_step replays captured
   // hipGraphs of one and of eight steps there; any setter that changes kernel arguments bumps the epoch
   bool graph_ok = false;
@@ -90,6 +93,9 @@ struct sg_handle {
   sg_counters_t counters;
   std::string err;
 };
+
+// smallest 2-D block (cells) that takes the MFMA tile kernels instead of the generic kernel
+static constexpr int64_t SG_TILE2D_MIN_CELLS = 16384;
 
 static std::string g_create_err;
 static_assert(SG_MAX_BOXES == SG_MAX_REGION_BOXES, "kernels.hpp and seigen_hip.h disagree on the box limit");
@@ -211,13 +217,20 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->use_lane = !h->use_mfma && lane_supported(cfg->dim, cfg->degree) && !force_generic &&
                 (force_lane || ncube_all * h->ncls >= (cfg->degree == 1 ? 196608 : 120000));  // crossovers measured
                                                                      // (tools/path_sweep.py, profiles/r02/small_2d_configs_negative_results.txt)
+  // 2-D: the MFMA tile kernels (16 cells per wave, operators in registers) from SG_TILE2D_MIN_CELLS cells up
+  // (measured crossover against the generic kernel, tools/path_sweep.py); SEIGEN_HIP_PATH=tile forces them
+  const bool force_tile = path_env && std::strcmp(path_env, "tile") == 0;
+  h->use_tile = tile2d_supported(cfg->dim, cfg->degree) && !force_generic && !force_lane &&
+                (force_tile || ncells_all >= SG_TILE2D_MIN_CELLS);
+  if (h->use_tile) h->use_lane = false;
   if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
   h->f32 = cfg->dtype;
   if (h->f32 && !h->use_mfma)
     return fail(h, SG_ERR_ARG, "dtype f32 is implemented on the MFMA path (3-D blocks; degree 1 from 65536 cells)");
-  h->md.gw = h->use_mfma ? 16 : (h->use_lane ? 64 : 1);
+  h->md.gw = (h->use_mfma || h->use_tile) ? 16 : (h->use_lane ? 64 : 1);
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
+  if (h->use_tile) h->t2c = tile2d_const(h->md);
   for (int f = 0; f < 4; ++f)
     for (int s = 0; s < 6; ++s) h->ghost[f][s] = nullptr;
   std::memset(&h->counters, 0, sizeof(h->counters));
@@ -273,8 +286,17 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragF, fF.data(), fF.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(float), hipMemcpyHostToDevice));
-  } else if (h->use_mfma) {
-    std::vector<double> fF = mfma_frags_F(h->re), fG = mfma_frags_G(h->re), fL = mfma_frags_L(h->re);
+  } else if (h->use_mfma || h->use_tile) {
+    std::vector<double> fF, fG, fL;
+    if (h->use_tile) {
+      fF = tile2d_frags_V(h->re, -1.0);
+      fG = tile2d_frags_V(h->re, 1.0);
+      fL = tile2d_frags_L(h->re);
+    } else {
+      fF = mfma_frags_F(h->re);
+      fG = mfma_frags_G(h->re);
+      fL = mfma_frags_L(h->re);
+    }
     HIPCHECK(h, hipMalloc((void**)&h->fragF, fF.size() * sizeof(double)));
     HIPCHECK(h, hipMalloc((void**)&h->fragG, fG.size() * sizeof(double)));
     HIPCHECK(h, hipMalloc((void**)&h->fragL, fL.size() * sizeof(double)));
@@ -282,7 +304,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  if (h->use_mfma || h->use_lane) {
+  if (h->use_mfma || h->use_lane || h->use_tile) {
     // symmetric-stress mode: fields start at zero, g only produces symmetric tensors;
     // left for good as soon as the user uploads a non-symmetric stress or source (SEIGEN_HIP_SYM=0: never entered)
     const char* sym_env = std::getenv("SEIGEN_HIP_SYM");
@@ -307,6 +329,8 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
     if (cfg->nbr_mask == 0) h->grid_full = h->grid_blocks;
+    h->tile_grid = 2048;
+    if (const char* tg = std::getenv("SEIGEN_HIP_TILE_GRID")) h->tile_grid = std::max(8, std::atoi(tg) / 8 * 8);
   }
   {
     const char* ge = std::getenv("SEIGEN_HIP_GRAPH");  // 0/1 overrides (measurements)
@@ -908,7 +932,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.c_new = c_new;
   std::vector<Box> boxes;
   region_boxes(h, region, boxes);
-  if (h->use_mfma || h->use_lane) {
+  if (h->use_mfma || h->use_lane || h->use_tile) {
     // one launch for the whole region: the kernels scan all cell groups and mask lanes by box
     a.nbox = 0;
     for (const Box& b : boxes) {
@@ -924,6 +948,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
     // only launches that run while an exchange is in flight leave block slots to RCCL
     a.grid_blocks = (region == SG_REGION_INTERIOR || region == SG_REGION_SECOND) ? h->grid_blocks : h->grid_full;
+    if (h->use_tile) a.grid_blocks = h->tile_grid;
     a.item_list = nullptr;
     a.nlist = 0;
     if (region != SG_REGION_ALL) {
@@ -957,8 +982,9 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       a.item_list = list;
       a.nlist = nlist;
     }
-    int rc = h->use_mfma ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
-                         : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
+    int rc = h->use_mfma   ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
+             : h->use_tile ? launch_stage_tile2d(kind, h->cfg.degree, a, h->t2c, (long)(h->md.ncube_pad / 16) * h->ncls, h->stream)
+                           : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
     if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
     return SG_OK;
   }

@@ -1,0 +1,447 @@
+// MFMA tile stage kernels for 2-D blocks, P1..P4 (gfx950, FP64).
+//
+// Same data layout idea as the 3-D MFMA path (kernels_mfma.hip): gw = 16, i.e. the 16 values of one
+// (node, component) of 16 consecutive squares' cells of one class form one 128-byte line, and one
+// wavefront owns one such 16-cell group (an "item") at a time.  Lane l: cell l & 15, k / row-quad l >> 4.
+// The element-local contractions of seigen/elastic.py:204-219 (+ the inverse mass of :358-367) are
+//
+//     [operator tile (nd rows) x 4]  x  [4 nodes x 16 cells]  ->  [nd rows x 16 cells]
+//
+// With nd <= 15 every operator is at most ONE 16-row tile per k-step (P3, P4: v_mfma_f64_16x16x4_f64)
+// or one / two 4-row tiles (P1, P2: v_mfma_f64_4x4x4_4b_f64), so the whole operator set of a degree is
+// 5..14 doubles per lane and lives in REGISTERS for the life of the wave: no LDS, no barrier.
+//
+// These kernels exist for blocks of 10^4..10^6 cells, where a stage is a few microseconds of data and the
+// time goes into DEPENDENT memory round trips, not bandwidth.  Hence:
+//  * everything the kernel needs to know about the mesh (sizes, class constants, neighbour rules, node
+//    permutations packed four to a word) travels BY VALUE in the kernarg segment (T2Const): no load
+//    whose address depends on another load, except the data themselves;
+//  * a wave's items all have the same class (item = 2 group + class and every stride is even), so the
+//    class constants are selected once per wave;
+//  * all of an item's operands - own rows, the three neighbour traces, old values of the fused combine,
+//    per-cell coefficients - are requested before the first MFMA: one memory latency per item.
+//
+//   F:  uh_i  = -sum_r E_r (Jinv_rj T_ij) + sum_f (1/2 L_f) [ w_f (c n)_f,j T(nbr)_ij ]  - sponge
+//   G:  W_ik  = -Jinv_rk (E_r u_i) + sum_f (c n)_f,k (1/2 L_f) u(nbr)_i ;  sh = lam tr(W) I + mu (W + W^T)
+// E_r = D_r - C_r folds the own-trace half of the central flux into the volume operator
+// (mfma_tables.cpp); a boundary lane's "neighbour" is its own cell (w_f = -1 in F: T.n = 0; the missing
+// half of the own trace in G).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace sg {
+
+template <int P>
+struct TG : ElemDims<2, P> {
+  using ElemDims<2, P>::ND;
+  using ElemDims<2, P>::NF;
+  static constexpr int KS = (ND + 3) / 4;    // k-steps over the element nodes
+  static constexpr int KSF = (NF + 3) / 4;   // k-steps over the facet nodes
+  static constexpr int S4 = (ND + 3) / 4;    // row-quads of the result
+  static constexpr bool LARGE = ND > 8;      // one 16-row tile (P3, P4) or S4 4-row tiles (P1, P2)
+  static constexpr int RT = LARGE ? 1 : S4;  // A fragments per (operator, k-step)
+  static constexpr int NFRAG_V = 2 * KS * RT;
+  static constexpr int NFRAG_L = 3 * KSF * RT;
+};
+
+typedef double t2d4 __attribute__((ext_vector_type(4)));
+
+// acc (rows 4 reg + q of the 16 cells) += A x B.  LARGE: a[0] is the 16-row fragment; else a[t] is the
+// 4-row fragment of row-quad t (lane l of its result holds row l >> 4 of cell l & 15).
+template <bool LARGE, int S4>
+__device__ __forceinline__ void t2_mma(const double* a, double b, t2d4& acc) {
+  if constexpr (LARGE) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < S4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t], b, acc[t], 0, 0, 0);
+  }
+}
+
+// row q of a packed table word (four byte entries: the rows 4 ks + q, q = 0..3, of one k-step)
+__device__ __forceinline__ int t2_row(uint32_t word, int q) { return (int)((word >> (8 * q)) & 0xffu); }
+
+template <int P, int KIND, int MODE, int SYM, int GHOST>
+__global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2Const C) {
+  using G = TG<P>;
+  constexpr int ND = G::ND, NF = G::NF, KS = G::KS, KSF = G::KSF, S4 = G::S4, RT = G::RT;
+  constexpr bool LARGE = G::LARGE;
+  constexpr int NC = (KIND == 0) ? 4 : 2;  // input components per node
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, w = lane & 15;
+  const double* __restrict__ in = A.in;
+  const double* aux = A.aux;
+  double* out = A.out;
+
+  const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (api.cpp)
+  const long nitems = listed ? (long)A.nlist : (long)C.ngroups * 2;
+  // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2); ranges start on
+  // even items and every stride is even, so a wave keeps its class
+  const long nblk = gridDim.x, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const long blocks_here = (nblk - xcd + 7) / 8, ipx = ((nitems + 15) / 16) * 2;
+  const long lo = xcd * ipx, hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
+  const long i0 = A.spread ? (long)blockIdx.x * 4 + wave : lo + slot * 4 + wave;
+  const long i1 = A.spread ? nitems : hi;
+  const long istep = A.spread ? (long)gridDim.x * 4 : blocks_here * 4;
+  if (i0 >= i1) return;
+  const int k = (int)(i0 & 1);  // class of every item of this wave (item lists hold (group, 0), (group, 1) pairs)
+
+  // ---- operator fragments: registers, once per wave -----------------------------------------
+  double Av[G::NFRAG_V], Al[G::NFRAG_L];
+#pragma unroll
+  for (int j = 0; j < G::NFRAG_V; ++j) Av[j] = A.fragV[j * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = A.fragL[j * 64 + lane];
+
+  // ---- class constants (scalar registers) ----------------------------------------------------
+  double Jv[2][2], cnv[3][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) Jv[r][j] = k ? C.Jinv[1][r][j] : C.Jinv[0][r][j];
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cnv[f][j] = k ? C.cn[1][f][j] : C.cn[0][f][j];
+  int f_axis[3], f_dir[3], f_kn[3], f_ord[3];
+  uint32_t f_tf[3][KSF], f_tg[3][KSF];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    f_axis[f] = k ? C.nb_axis[1][f] : C.nb_axis[0][f];
+    f_dir[f] = k ? C.nb_dir[1][f] : C.nb_dir[0][f];
+    f_kn[f] = k ? C.nb_cls[1][f] : C.nb_cls[0][f];
+    f_ord[f] = k ? C.slot_ord[1][f] : C.slot_ord[0][f];
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+      f_tf[f][ks] = k ? C.tfw[1][f][ks] : C.tfw[0][f][ks];
+      f_tg[f][ks] = k ? C.tgw[1][f][ks] : C.tgw[0][f][ks];
+    }
+  }
+  const int n0 = C.n0, n1 = C.n1;
+
+  for (long it = i0; it < i1; it += istep) {
+    const int item = __builtin_amdgcn_readfirstlane(listed ? A.item_list[it] : (int)it);
+    const int g = item >> 1;
+    // ---- this lane's cell ----------------------------------------------------------------------
+    const int c = g * 16 + w;
+    const bool valid = c < C.ncube;
+    const unsigned cl = valid ? (unsigned)c : 0u;
+    const unsigned cy = cl / (unsigned)n0;
+    const int cc[2] = {(int)(cl - cy * (unsigned)n0), (int)cy};
+    bool inbox = false;
+    for (int bx = 0; bx < A.nbox; ++bx)
+      inbox = inbox || (cc[0] >= A.boxes_o[bx][0] && cc[0] < A.boxes_o[bx][0] + A.boxes_n[bx][0] &&
+                        cc[1] >= A.boxes_o[bx][1] && cc[1] < A.boxes_o[bx][1] + A.boxes_n[bx][1]);
+    const bool active = valid && inbox;
+    if (!__any(active)) continue;
+    const double* own = in + ((long)item * ND) * NC * 16 + w;
+    const int e = (int)cl * 2 + k;  // cell index in the host numbering
+
+    // ---- own rows: requested first.  B row of this lane at k-step ks = node 4 ks + q; rows past ND meet
+    //      all-zero operator columns, so any finite value will do: clamp to node 0
+    double ub[KS][NC];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int orow = ((4 * ks + q < ND) ? 4 * ks + q : 0) * NC * 16;
+      if (KIND == 0) {
+        ub[ks][0] = own[orow + 0 * 16];
+        ub[ks][1] = own[orow + 1 * 16];
+        ub[ks][3] = own[orow + 3 * 16];
+        ub[ks][2] = SYM ? ub[ks][1] : own[orow + 2 * 16];
+      } else {
+        ub[ks][0] = own[orow];
+        ub[ks][1] = own[orow + 16];
+      }
+    }
+
+    // ---- neighbour traces --------------------------------------------------------------------
+    double tn[3][KSF][NC];
+    double wf[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const int axis = f_axis[f], kn = f_kn[f], dir = f_dir[f];
+      const double* p;
+      bool ghost = false, physical = false;
+      if (axis < 0) {
+        p = in + ((long)(g * 2 + kn) * ND) * NC * 16 + w;
+      } else {
+        const int cn = cc[axis] + dir;
+        const bool inside = valid && cn >= 0 && cn < (axis == 0 ? n0 : n1);
+        const int nc = inside ? (int)cl + dir * (axis == 0 ? 1 : n0) : (int)cl;
+        p = in + ((long)((nc >> 4) * 2 + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15);
+        physical = !inside;
+        if (GHOST) {
+          const int side = 2 * axis + (dir > 0 ? 1 : 0);
+          if (!inside && valid && C.has_nbr[side]) {
+            const long slot2 = (long)(axis == 0 ? cc[1] : cc[0]) * C.halo_per_cube + f_ord[f];
+            p = A.ghost[side] + slot2 * NF * 2;  // packed trace: 2 comps per facet node (velocity, or T_i,axis)
+            ghost = true;
+            physical = false;
+          }
+        }
+      }
+      // F: +1/2 neighbour flux inside, -1/2 own flux on the boundary (cancels the folded half: T.n = 0);
+      // G: 1/2 of the neighbour, or the missing 1/2 of the own trace; the 1/2 is part of the lift tiles
+      wf[f] = (KIND == 0 && physical) ? -1.0 : 1.0;
+#pragma unroll
+      for (int ks = 0; ks < KSF; ++ks) {
+        // facet-trace row: the neighbour's node inside the block's field, the own node on the domain
+        // boundary, the position in the neighbour's facet list in a packed remote trace
+        const int off = (GHOST && ghost) ? t2_row(f_tg[f][ks], q) * 2
+                                         : t2_row(physical ? C.tpw[f][ks] : f_tf[f][ks], q) * NC * 16;
+        if (KIND == 0) {
+          // a packed remote trace holds g_i = T_i,axis only; the columns j != axis meet (c n)_j = 0 there,
+          // so any finite value serves: pairs (i <= j): axis 0 -> g_j, axis 1 -> g_i; full tensor: g_i
+          auto at = [&](int i, int j) {
+            const int og = SYM ? (axis == 0 ? j : i) : i;
+            return p[off + ((GHOST && ghost) ? og : (SYM && i > j ? j * 2 + i : i * 2 + j) * 16)];
+          };
+          tn[f][ks][0] = at(0, 0);
+          tn[f][ks][1] = at(0, 1);
+          tn[f][ks][3] = at(1, 1);
+          tn[f][ks][2] = SYM ? tn[f][ks][1] : at(1, 0);
+        } else {
+          const int cst = (GHOST && ghost) ? 1 : 16;
+          tn[f][ks][0] = p[off];
+          tn[f][ks][1] = p[off + cst];
+        }
+      }
+    }
+
+    if (KIND == 0) {
+      // ---- F ---------------------------------------------------------------------------------
+      const long ubase = ((long)item * ND) * 2 * 16 + w;
+      int sslot = -1;
+      if (A.sponge_slot != nullptr && active) sslot = A.sponge_slot[e];
+      double cs = A.c_self, ca = A.c_aux, cnw = A.c_new;
+      if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
+        const double r0 = A.rho2[2 * e], r1 = A.rho2[2 * e + 1];
+        cs = r0;
+        ca *= r1;
+        cnw *= r1;
+      }
+      // in-place combine operands, requested before the arithmetic
+      double po[S4][2], pa[S4][2];
+      if (MODE == 1) {
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          const int a = (4 * m + q < ND) ? 4 * m + q : 0;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            po[m][i] = out[ubase + (a * 2 + i) * 16];
+            pa[m][i] = aux[ubase + (a * 2 + i) * 16];
+          }
+        }
+      }
+      t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
+      // volume: B = T~_ir = Jinv_rj T_ij (the fragments hold -E_r)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const double tt = Jv[r][0] * ub[ks][i * 2 + 0] + Jv[r][1] * ub[ks][i * 2 + 1];
+            t2_mma<LARGE, S4>(&Av[(r * KS + ks) * RT], tt, acc[i]);
+          }
+      // lifts of w_f (c n)_j T(nbr)_ij
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const double fl = wf[f] * (cnv[f][0] * tn[f][ks][i * 2 + 0] + cnv[f][1] * tn[f][ks][i * 2 + 1]);
+            t2_mma<LARGE, S4>(&Al[(f * KSF + ks) * RT], fl, acc[i]);
+          }
+      // sponge (elastic.py:207-208): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
+      // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
+      // wave runs in program order, so these reads precede the stores below.
+      if (__any(sslot >= 0)) {
+        if (sslot >= 0) {
+          const double* ua = A.uabs + ubase;
+          const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND
+          double s[S4][2];
+#pragma unroll
+          for (int m = 0; m < S4; ++m) s[m][0] = s[m][1] = 0.0;
+#pragma unroll 2
+          for (int b = 0; b < ND; ++b) {
+            const double u0 = ua[(b * 2 + 0) * 16], u1 = ua[(b * 2 + 1) * 16];
+#pragma unroll
+            for (int m = 0; m < S4; ++m) {
+              const double bb = (4 * m + q < ND) ? B[m * 4 * ND + b] : 0.0;
+              s[m][0] += bb * u0;
+              s[m][1] += bb * u1;
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < S4; ++m) {
+            acc[0][m] -= s[m][0];
+            acc[1][m] -= s[m][1];
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < S4; ++m) {
+        const int a = 4 * m + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          double v = acc[i][m];
+          if (MODE == 1) v = cs * po[m][i] + ca * pa[m][i] + cnw * v;
+          if (active && a < ND) out[ubase + (a * 2 + i) * 16] = v;
+        }
+      }
+    } else {
+      // ---- G ---------------------------------------------------------------------------------
+      const double lam = A.per_cell ? A.lam[e] : A.lam0;
+      const double mu = A.per_cell ? A.mu[e] : A.mu0;
+      const long sbase = ((long)item * ND) * 4 * 16 + w;
+      double po[S4][3], pa[S4][3], pl[S4], pal[S4];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
+      if (MODE == 1) {
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          const int a = (4 * m + q < ND) ? 4 * m + q : 0;
+          po[m][0] = out[sbase + (a * 4 + 0) * 16];
+          po[m][1] = out[sbase + (a * 4 + 1) * 16];
+          po[m][2] = out[sbase + (a * 4 + 3) * 16];
+          pa[m][0] = aux[sbase + (a * 4 + 0) * 16];
+          pa[m][1] = aux[sbase + (a * 4 + 1) * 16];
+          pa[m][2] = aux[sbase + (a * 4 + 3) * 16];
+          if (!SYM) {
+            pl[m] = out[sbase + (a * 4 + 2) * 16];
+            pal[m] = aux[sbase + (a * 4 + 2) * 16];
+          }
+        }
+      }
+      // W_00, W_11 and W_01 + W_10 per row-quad
+      t2d4 Sd[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}}, So = t2d4{0, 0, 0, 0};
+      auto fold = [&](const double c0, const double c1, const t2d4 (&v)[2]) {
+        // W_ik += c_k v_i
+        Sd[0] += c0 * v[0];
+        Sd[1] += c1 * v[1];
+        So += c1 * v[0] + c0 * v[1];
+      };
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) t2_mma<LARGE, S4>(&Av[(r * KS + ks) * RT], ub[ks][i], acc[i]);
+        fold(-Jv[r][0], -Jv[r][1], acc);
+      }
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) t2_mma<LARGE, S4>(&Al[(f * KSF + ks) * RT], tn[f][ks][i], acc[i]);
+        fold(cnv[f][0], cnv[f][1], acc);
+      }
+#pragma unroll
+      for (int m = 0; m < S4; ++m) {
+        const int a = 4 * m + q;
+        const double tr = lam * (Sd[0][m] + Sd[1][m]);
+        double v00 = 2.0 * mu * Sd[0][m] + tr, v11 = 2.0 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
+        if (MODE == 1) {
+          v00 = A.c_self * po[m][0] + A.c_aux * pa[m][0] + A.c_new * v00;
+          v11 = A.c_self * po[m][2] + A.c_aux * pa[m][2] + A.c_new * v11;
+          if (!SYM) v10 = A.c_self * pl[m] + A.c_aux * pal[m] + A.c_new * v01;
+          v01 = A.c_self * po[m][1] + A.c_aux * pa[m][1] + A.c_new * v01;
+        }
+        if (active && a < ND) {
+          out[sbase + (a * 4 + 0) * 16] = v00;
+          out[sbase + (a * 4 + 1) * 16] = v01;
+          if (!SYM) out[sbase + (a * 4 + 2) * 16] = v10;
+          out[sbase + (a * 4 + 3) * 16] = v11;
+        }
+      }
+    }
+  }
+}
+
+// kernarg copy of what the kernels need from the mesh tables
+T2Const tile2d_const(const MeshDev& md) {
+  T2Const C;
+  C.n0 = md.n[0];
+  C.n1 = md.n[1];
+  C.ncube = (int32_t)md.ncube;
+  C.ngroups = (int32_t)(md.ncube_pad / 16);
+  C.halo_per_cube = md.halo_per_cube;
+  for (int s = 0; s < 4; ++s) C.has_nbr[s] = md.has_nbr[s];
+  const int ksf = (md.nf + 3) / 4;
+  auto pack = [&](auto entry, int ks) {
+    uint32_t wd = 0;
+    for (int qq = 0; qq < 4; ++qq) {
+      const int bb = (4 * ks + qq < md.nf) ? 4 * ks + qq : 0;  // padded rows meet zero lift columns
+      wd |= (uint32_t)entry(bb) << (8 * qq);
+    }
+    return wd;
+  };
+  for (int f = 0; f < 3; ++f) {
+    for (int ks = 0; ks < 2; ++ks) C.tpw[f][ks] = ks < ksf ? pack([&](int bb) { return md.fnode[f][bb]; }, ks) : 0u;
+    for (int k = 0; k < 2; ++k) {
+      C.nb_axis[k][f] = md.nb_axis[k][f];
+      C.nb_dir[k][f] = md.nb_dir[k][f];
+      C.nb_cls[k][f] = md.nb_cls[k][f];
+      const int ord = md.face_ord[md.nb_cls[k][f]][md.nb_face[k][f]];
+      C.slot_ord[k][f] = ord < 0 ? 0 : ord;
+      for (int ks = 0; ks < 2; ++ks) {
+        C.tfw[k][f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_node[k][f][bb]; }, ks) : 0u;
+        C.tgw[k][f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_fnode[k][f][bb]; }, ks) : 0u;
+      }
+      for (int j = 0; j < 2; ++j) C.cn[k][f][j] = md.cn[k][f][j];
+    }
+  }
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 2; ++r)
+      for (int j = 0; j < 2; ++j) C.Jinv[k][r][j] = md.Jinv[k][r][j];
+  return C;
+}
+
+template <int P, int SYM, int GHOST>
+static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
+  long blocks = (nitems + 3) / 4;
+  const long cap = a.grid_blocks > 0 ? a.grid_blocks : 2048;
+  if (blocks > cap) blocks = cap;
+  blocks = (blocks + 7) / 8 * 8;  // every XCD label needs a block
+  const dim3 grid((unsigned)blocks), block(256);
+  if (kind == 0) {
+    if (a.mode == 0)
+      hipLaunchKernelGGL((tile2d_stage<P, 0, 0, SYM, GHOST>), grid, block, 0, s, a, c);
+    else
+      hipLaunchKernelGGL((tile2d_stage<P, 0, 1, SYM, GHOST>), grid, block, 0, s, a, c);
+  } else {
+    if (a.mode == 0)
+      hipLaunchKernelGGL((tile2d_stage<P, 1, 0, SYM, GHOST>), grid, block, 0, s, a, c);
+    else
+      hipLaunchKernelGGL((tile2d_stage<P, 1, 1, SYM, GHOST>), grid, block, 0, s, a, c);
+  }
+  return (int)hipGetLastError();
+}
+
+template <int P>
+static int launch_t2p(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
+  bool ghosts = false;
+  for (int sd = 0; sd < 4; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
+  if (a.sym) return ghosts ? launch_t2<P, 1, 1>(kind, a, c, nitems, s) : launch_t2<P, 1, 0>(kind, a, c, nitems, s);
+  return ghosts ? launch_t2<P, 0, 1>(kind, a, c, nitems, s) : launch_t2<P, 0, 0>(kind, a, c, nitems, s);
+}
+
+bool tile2d_supported(int dim, int P) { return dim == 2 && P >= 1 && P <= 4; }
+
+int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, long nitems, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (P) {
+    case 1: return launch_t2p<1>(kind, a, c, nitems, s);
+    case 2: return launch_t2p<2>(kind, a, c, nitems, s);
+    case 3: return launch_t2p<3>(kind, a, c, nitems, s);
+    case 4: return launch_t2p<4>(kind, a, c, nitems, s);
+  }
+  return -1;
+}
+
+}  // namespace sg

@@ -25,12 +25,14 @@ MfmaGeom mfma_geom(const RefElem& re) {
 //   sum_f L_f [ (c n)_f . 1/2 T+ ]   is   sum_r C_r (Jinv_r . T),
 // i.e. it has the shape of the volume term.  The facet lifts then only carry the
 // NEIGHBOUR half (and a correction on domain-boundary facets, kernels_mfma.hip).
+// In d dimensions (c n)_f = -grad(lambda_f)/(d-1)!, so the factor is 1/(2 (d-1)!): 1/4 on tetrahedra, 1/2 on triangles.
 static inline double Eval(const RefElem& re, int r, int a, int b) {
   if (a >= re.nd || b >= re.nd) return 0.0;
+  const double cfold = (re.dim == 3) ? 0.25 : 0.5;
   double v = re.D[((size_t)r * re.nd + a) * re.nd + b];
   for (int bf = 0; bf < re.nf; ++bf) {
-    if (re.fnode[(size_t)0 * re.nf + bf] == b) v -= 0.25 * re.L[((size_t)0 * re.nd + a) * re.nf + bf];
-    if (re.fnode[(size_t)(r + 1) * re.nf + bf] == b) v += 0.25 * re.L[((size_t)(r + 1) * re.nd + a) * re.nf + bf];
+    if (re.fnode[(size_t)0 * re.nf + bf] == b) v -= cfold * re.L[((size_t)0 * re.nd + a) * re.nf + bf];
+    if (re.fnode[(size_t)(r + 1) * re.nf + bf] == b) v += cfold * re.L[((size_t)(r + 1) * re.nd + a) * re.nf + bf];
   }
   return v;
 }
@@ -116,6 +118,40 @@ std::vector<float> mfma32_frags_L(const RefElem& re) {
         for (int l = 0; l < 64; ++l) {
           int a = tile_row32(t, l), b = 4 * k0 + (l >> 4);
           out[frag * 64 + l] = (a < re.nd && b < re.nf) ? (float)(0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b]) : 0.0f;
+        }
+      }
+  return out;
+}
+
+// ---- 2-D tile kernels ---------------------------------------------------------------------------
+static inline int tile2d_row(bool large, int t, int l) { return large ? (l & 15) : 4 * t + (l & 3); }
+
+std::vector<double> tile2d_frags_V(const RefElem& re, double sign) {
+  const int ks = (re.nd + 3) / 4, s4 = (re.nd + 3) / 4;
+  const bool large = re.nd > 8;
+  const int rt = large ? 1 : s4;
+  std::vector<double> out((size_t)2 * ks * rt * 64, 0.0);
+  for (int r = 0; r < 2; ++r)
+    for (int k0 = 0; k0 < ks; ++k0)
+      for (int t = 0; t < rt; ++t) {
+        size_t frag = ((size_t)r * ks + k0) * rt + t;
+        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = sign * Eval(re, r, tile2d_row(large, t, l), 4 * k0 + (l >> 4));
+      }
+  return out;
+}
+
+std::vector<double> tile2d_frags_L(const RefElem& re) {
+  const int ksf = (re.nf + 3) / 4, s4 = (re.nd + 3) / 4;
+  const bool large = re.nd > 8;
+  const int rt = large ? 1 : s4;
+  std::vector<double> out((size_t)re.nfaces * ksf * rt * 64, 0.0);
+  for (int f = 0; f < re.nfaces; ++f)
+    for (int k0 = 0; k0 < ksf; ++k0)
+      for (int t = 0; t < rt; ++t) {
+        size_t frag = ((size_t)f * ksf + k0) * rt + t;
+        for (int l = 0; l < 64; ++l) {
+          int a = tile2d_row(large, t, l), b = 4 * k0 + (l >> 4);
+          out[frag * 64 + l] = (a < re.nd && b < re.nf) ? 0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
         }
       }
   return out;

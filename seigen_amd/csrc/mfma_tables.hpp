@@ -54,4 +54,13 @@ std::vector<float> mfma32_frags_F(const RefElem& re);
 std::vector<float> mfma32_frags_G(const RefElem& re);
 std::vector<float> mfma32_frags_L(const RefElem& re);
 
+// ---- 2-D tile kernels (kernels_tile2d.hip) ----------------------------------------------------
+// nd <= 15: one 16-row fragment per (operator, k-step) at degrees 3 and 4 (lane l: A[row = l & 15][k = l >> 4]),
+// ceil(nd / 4) 4-row fragments at degrees 1 and 2 (lane l: A[row = 4 t + (l & 3)][k = l >> 4]).
+//   V: frag ((r*ks + k0)*rt + t): sign * E_r[row][4 k0 + col]   (sign = -1 for F, +1 for G)
+//   L: frag ((f*ksf + k0)*rt + t): 1/2 L_f[row][4 k0 + col]
+// with E_r = D_r - 1/2 (L_0 R_0 - L_{r+1} R_{r+1}) (the fold of mfma_tables.cpp with the 2-D normal scale).
+std::vector<double> tile2d_frags_V(const RefElem& re, double sign);
+std::vector<double> tile2d_frags_L(const RefElem& re);
+
 }  // namespace sg
