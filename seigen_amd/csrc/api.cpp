@@ -94,8 +94,9 @@ struct sg_handle {
   std::string err;
 };
 
-// smallest 2-D block (cells) that takes the MFMA tile kernels instead of the generic kernel
-static constexpr int64_t SG_TILE2D_MIN_CELLS = 16384;
+// smallest 2-D block (cells) that takes the MFMA tile kernels instead of the generic kernel: they win at every
+// size measured, 40 x 40 squares included (tools/path_sweep2d.py, profiles/r02/path_sweep2d_tile_v2.txt)
+static constexpr int64_t SG_TILE2D_MIN_CELLS = 0;
 
 static std::string g_create_err;
 static_assert(SG_MAX_BOXES == SG_MAX_REGION_BOXES, "kernels.hpp and seigen_hip.h disagree on the box limit");
@@ -329,7 +330,9 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
     if (cfg->nbr_mask == 0) h->grid_full = h->grid_blocks;
-    h->tile_grid = 2048;
+    // 251 blocks per XCD label: with an odd (prime) stride of 4 * 251 items a wave's items do not keep falling on
+    // the same column of the mesh, e.g. on the sponge strips at both ends of every row (config 2: 0.240 -> 0.232 ms)
+    h->tile_grid = 2008;
     if (const char* tg = std::getenv("SEIGEN_HIP_TILE_GRID")) h->tile_grid = std::max(8, std::atoi(tg) / 8 * 8);
   }
   {

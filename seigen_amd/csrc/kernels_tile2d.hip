@@ -266,15 +266,25 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           double s[S4][2];
 #pragma unroll
           for (int m = 0; m < S4; ++m) s[m][0] = s[m][1] = 0.0;
-#pragma unroll 2
-          for (int b = 0; b < ND; ++b) {
-            const double u0 = ua[(b * 2 + 0) * 16], u1 = ua[(b * 2 + 1) * 16];
+          // chunks of CH columns: all of a chunk's loads are in flight together (one round trip per chunk)
+          constexpr int CH = ND <= 6 ? ND : 5;
+#pragma nounroll
+          for (int b0 = 0; b0 < ND; b0 += CH) {
+            double uu[CH][2], bb[S4][CH];
 #pragma unroll
-            for (int m = 0; m < S4; ++m) {
-              const double bb = (4 * m + q < ND) ? B[m * 4 * ND + b] : 0.0;
-              s[m][0] += bb * u0;
-              s[m][1] += bb * u1;
+            for (int j = 0; j < CH; ++j) {
+              uu[j][0] = ua[((b0 + j) * 2 + 0) * 16];
+              uu[j][1] = ua[((b0 + j) * 2 + 1) * 16];
+#pragma unroll
+              for (int m = 0; m < S4; ++m) bb[m][j] = B[((4 * m + q < ND) ? m * 4 * ND : 0) + b0 + j];
             }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+              for (int m = 0; m < S4; ++m) {
+                s[m][0] += bb[m][j] * uu[j][0];
+                s[m][1] += bb[m][j] * uu[j][1];
+              }
           }
 #pragma unroll
           for (int m = 0; m < S4; ++m) {

@@ -290,8 +290,10 @@ def test_kernel_families_agree_on_random_blocks(gpu, monkeypatch, seed):
     diagonal = "right" if (dim == 2 and rng.integers(0, 2)) else "left"
     dt = 0.05 * min(h) / degree ** 2
     results = {}
-    for path in ("generic", "lane", "mfma"):
+    for path in ("generic", "lane", "mfma", "tile"):
         if path == "mfma" and dim != 3:
+            continue
+        if path == "tile" and dim != 2:
             continue
         if path == "lane" and dim == 3 and degree > 2:
             continue

@@ -29,6 +29,9 @@ import seigen_amd.harness.explosive_source as _hx  # noqa: E402
 _he.log = _hx.log = lambda s: None
 
 
+STAGES = False
+
+
 def timed(elastic, steps, warmup):
     elastic.setup()
     blk = elastic.block
@@ -47,7 +50,16 @@ def timed(elastic, steps, warmup):
     dev_ms = blk.last_step_ms()
     dofs = blk.u_dofs + blk.s_dofs
     u = blk.get_field_range(0, 0, 4)
-    return dict(dofs=dofs, cells=blk.ncells, ms_per_step=dev_ms / steps, wall_ms_per_step=wall / steps * 1e3,
+    stage_us = None
+    if STAGES:     # a second pass with an event pair around every stage (slower: no graph replay, events between launches)
+        blk.enable_timing(True)
+        c0 = blk.counters()
+        blk.step(steps)
+        blk.sync()
+        c1 = blk.counters()
+        blk.enable_timing(False)
+        stage_us = [round((c1["kernel_ms"][i] - c0["kernel_ms"][i]) / steps * 1e3, 2) for i in range(6)]
+    return dict(stage_us=stage_us, dofs=dofs, cells=blk.ncells, ms_per_step=dev_ms / steps, wall_ms_per_step=wall / steps * 1e3,
                 value=dofs * steps / (dev_ms * 1e-3) / 1e6, finite=bool(np.isfinite(u).all()))
 
 
@@ -123,7 +135,9 @@ if __name__ == "__main__":
     ap.add_argument("configs", nargs="*", default=["c2", "c5", "c1"])
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--stages", action="store_true", help="also report device microseconds per stage (UH1 STEMP U1 SH1 UTEMP S1)")
     args = ap.parse_args()
+    STAGES = args.stages
     for c in args.configs:
         r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share}[c](args.steps, args.warmup)
         r["algorithmic_GBps"] = r["value"] * 1e6 * 64 / 1e9
