@@ -73,16 +73,21 @@ int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems,
 // T2Const is the part of MeshDev these kernels use, passed by value in the kernarg segment so that no load
 // depends on another one (kernels_tile2d.hip): sizes, class constants, neighbour rules, and the node
 // permutations packed four byte entries to a word (entry q of word [ks] = row 4 ks + q).
+struct T2Class {            // everything that depends on the triangle class, contiguous: one batch of scalar loads
+  double Jinv[2][2], cn[3][2];
+  int32_t nb_axis[3], nb_dir[3], nb_cls[3];
+  int32_t slot_ord[3];      // ordinal of the matching facet among the neighbour cube's facets on that side
+  uint32_t tfw[3][2];       // neighbour ELEMENT node matching my facet node (MeshDev::nb_node)
+  uint32_t tgw[3][2];       // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
+};
 struct T2Const {
   int32_t n0, n1, ncube, ngroups;
   int32_t has_nbr[4];
   int32_t halo_per_cube;
-  int32_t nb_axis[2][3], nb_dir[2][3], nb_cls[2][3];
-  int32_t slot_ord[2][3];   // ordinal of the matching facet among the neighbour cube's facets on that side
-  uint32_t tfw[2][3][2];    // neighbour ELEMENT node matching my facet node (MeshDev::nb_node)
-  uint32_t tgw[2][3][2];    // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
+  int32_t gpr;              // groups of 16 squares that cover at least one row of the block (+1: a group may straddle rows)
+  double inv_n0;            // 1 / n0
   uint32_t tpw[3][2];       // my element node of facet node (MeshDev::fnode)
-  double Jinv[2][2][2], cn[2][3][2];
+  T2Class cls[2];
 };
 T2Const tile2d_const(const MeshDev& md_host);
 bool tile2d_supported(int dim, int P);

@@ -59,6 +59,15 @@ __device__ __forceinline__ void t2_mma(const double* a, double b, t2d4& acc) {
   }
 }
 
+// Access through a wave-uniform base and a 32-bit lane offset in bytes: global_load/store with an SGPR base,
+// no 64-bit lane arithmetic (each 64-bit lane pointer costs two VALU adds and two registers).
+__device__ __forceinline__ double t2_ld(const double* ubase, unsigned boff) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ubase) + boff);
+}
+__device__ __forceinline__ void t2_st(double* ubase, unsigned boff, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + boff) = v;
+}
+
 // row q of a packed table word (four byte entries: the rows 4 ks + q, q = 0..3, of one k-step)
 __device__ __forceinline__ int t2_row(uint32_t word, int q) { return (int)((word >> (8 * q)) & 0xffu); }
 
@@ -76,17 +85,17 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   double* out = A.out;
 
   const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (api.cpp)
-  const long nitems = listed ? (long)A.nlist : (long)C.ngroups * 2;
+  const int nitems = listed ? A.nlist : C.ngroups * 2;
   // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2); ranges start on
   // even items and every stride is even, so a wave keeps its class
-  const long nblk = gridDim.x, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-  const long blocks_here = (nblk - xcd + 7) / 8, ipx = ((nitems + 15) / 16) * 2;
-  const long lo = xcd * ipx, hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
-  const long i0 = A.spread ? (long)blockIdx.x * 4 + wave : lo + slot * 4 + wave;
-  const long i1 = A.spread ? nitems : hi;
-  const long istep = A.spread ? (long)gridDim.x * 4 : blocks_here * 4;
-  if (i0 >= i1) return;
-  const int k = (int)(i0 & 1);  // class of every item of this wave (item lists hold (group, 0), (group, 1) pairs)
+  const int nblk = (int)gridDim.x, xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+  const int blocks_here = (nblk - xcd + 7) >> 3, ipx = ((nitems + 15) >> 4) * 2;
+  const int hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
+  const int i0 = A.spread ? (int)blockIdx.x * 4 + wave : xcd * ipx + slot * 4 + wave;
+  const int i1 = A.spread ? nitems : hi;
+  const int istep = A.spread ? nblk * 4 : blocks_here * 4;
+  const int k = i0 & 1;  // class of every item of this wave (item lists hold (group, 0), (group, 1) pairs)
+  const T2Class& K = C.cls[k];
 
   // ---- operator fragments: registers, once per wave -----------------------------------------
   double Av[G::NFRAG_V], Al[G::NFRAG_L];
@@ -95,48 +104,60 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
   for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = A.fragL[j * 64 + lane];
 
-  // ---- class constants (scalar registers) ----------------------------------------------------
+  // ---- class constants: one batch of scalar loads from the kernarg segment at an offset that depends on k only
   double Jv[2][2], cnv[3][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) Jv[r][j] = k ? C.Jinv[1][r][j] : C.Jinv[0][r][j];
+    for (int j = 0; j < 2; ++j) Jv[r][j] = K.Jinv[r][j];
 #pragma unroll
   for (int f = 0; f < 3; ++f)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) cnv[f][j] = k ? C.cn[1][f][j] : C.cn[0][f][j];
+    for (int j = 0; j < 2; ++j) cnv[f][j] = K.cn[f][j];
   int f_axis[3], f_dir[3], f_kn[3], f_ord[3];
   uint32_t f_tf[3][KSF], f_tg[3][KSF];
 #pragma unroll
   for (int f = 0; f < 3; ++f) {
-    f_axis[f] = k ? C.nb_axis[1][f] : C.nb_axis[0][f];
-    f_dir[f] = k ? C.nb_dir[1][f] : C.nb_dir[0][f];
-    f_kn[f] = k ? C.nb_cls[1][f] : C.nb_cls[0][f];
-    f_ord[f] = k ? C.slot_ord[1][f] : C.slot_ord[0][f];
+    f_axis[f] = K.nb_axis[f];
+    f_dir[f] = K.nb_dir[f];
+    f_kn[f] = K.nb_cls[f];
+    f_ord[f] = K.slot_ord[f];
 #pragma unroll
     for (int ks = 0; ks < KSF; ++ks) {
-      f_tf[f][ks] = k ? C.tfw[1][f][ks] : C.tfw[0][f][ks];
-      f_tg[f][ks] = k ? C.tgw[1][f][ks] : C.tgw[0][f][ks];
+      f_tf[f][ks] = K.tfw[f][ks];
+      f_tg[f][ks] = K.tgw[f][ks];
     }
   }
   const int n0 = C.n0, n1 = C.n1;
 
-  for (long it = i0; it < i1; it += istep) {
-    const int item = __builtin_amdgcn_readfirstlane(listed ? A.item_list[it] : (int)it);
+  for (int it = i0; it < i1; it += istep) {
+    const int item = __builtin_amdgcn_readfirstlane(listed ? A.item_list[it] : it);
     const int g = item >> 1;
-    // ---- this lane's cell ----------------------------------------------------------------------
+    // ---- this lane's cell (a padding lane stands in for the group's first square, masked) -------------
     const int c = g * 16 + w;
     const bool valid = c < C.ncube;
-    const unsigned cl = valid ? (unsigned)c : 0u;
-    const unsigned cy = cl / (unsigned)n0;
-    const int cc[2] = {(int)(cl - cy * (unsigned)n0), (int)cy};
-    bool inbox = false;
-    for (int bx = 0; bx < A.nbox; ++bx)
-      inbox = inbox || (cc[0] >= A.boxes_o[bx][0] && cc[0] < A.boxes_o[bx][0] + A.boxes_n[bx][0] &&
-                        cc[1] >= A.boxes_o[bx][1] && cc[1] < A.boxes_o[bx][1] + A.boxes_n[bx][1]);
-    const bool active = valid && inbox;
-    if (!__any(active)) continue;
-    const double* own = in + ((long)item * ND) * NC * 16 + w;
+    const unsigned cl = valid ? (unsigned)c : (unsigned)(g * 16);
+    // cl / n0 through the reciprocal (exact after one correction step; the integer division is 25 instructions)
+    unsigned cy = (unsigned)((double)cl * C.inv_n0);
+    int cx = (int)(cl - cy * (unsigned)n0);
+    if (cx < 0) {
+      cx += n0;
+      cy -= 1;
+    } else if (cx >= n0) {
+      cx -= n0;
+      cy += 1;
+    }
+    const int cc[2] = {cx, (int)cy};
+    bool active = valid;
+    if (listed) {  // a region of a split stage: mask by its boxes (REGION_ALL has no list and covers the block)
+      bool inbox = false;
+      for (int bx = 0; bx < A.nbox; ++bx)
+        inbox = inbox || (cc[0] >= A.boxes_o[bx][0] && cc[0] < A.boxes_o[bx][0] + A.boxes_n[bx][0] &&
+                          cc[1] >= A.boxes_o[bx][1] && cc[1] < A.boxes_o[bx][1] + A.boxes_n[bx][1]);
+      active = valid && inbox;
+      if (!__any(active)) continue;
+    }
+    const double* ownb = in + ((long)item * ND) * NC * 16;   // wave-uniform
     const int e = (int)cl * 2 + k;  // cell index in the host numbering
 
     // ---- own rows: requested first.  B row of this lane at k-step ks = node 4 ks + q; rows past ND meet
@@ -144,39 +165,45 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
     double ub[KS][NC];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int orow = ((4 * ks + q < ND) ? 4 * ks + q : 0) * NC * 16;
+      const unsigned orow = (unsigned)((((4 * ks + q < ND) ? 4 * ks + q : 0) * NC * 16 + w) * 8);
       if (KIND == 0) {
-        ub[ks][0] = own[orow + 0 * 16];
-        ub[ks][1] = own[orow + 1 * 16];
-        ub[ks][3] = own[orow + 3 * 16];
-        ub[ks][2] = SYM ? ub[ks][1] : own[orow + 2 * 16];
+        ub[ks][0] = t2_ld(ownb, orow + 0 * 128);
+        ub[ks][1] = t2_ld(ownb, orow + 1 * 128);
+        ub[ks][3] = t2_ld(ownb, orow + 3 * 128);
+        ub[ks][2] = SYM ? ub[ks][1] : t2_ld(ownb, orow + 2 * 128);
       } else {
-        ub[ks][0] = own[orow];
-        ub[ks][1] = own[orow + 16];
+        ub[ks][0] = t2_ld(ownb, orow);
+        ub[ks][1] = t2_ld(ownb, orow + 128);
       }
     }
 
-    // ---- neighbour traces --------------------------------------------------------------------
+    // ---- neighbour traces.  Inside the block's field every neighbour lies at most one row of squares
+    //      away: offsets are taken from the uniform base of group g - gpr (gpr groups >= one row), so
+    //      they are small and non-negative.  GHOST = 1 lanes may read a packed remote trace instead:
+    //      a lane pointer then.
+    const int g0 = (g > C.gpr) ? g - C.gpr : 0;
+    const double* nbb = in + ((long)g0 * 2 * ND) * NC * 16;  // wave-uniform
     double tn[3][KSF][NC];
     double wf[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
       const int axis = f_axis[f], kn = f_kn[f], dir = f_dir[f];
-      const double* p;
+      unsigned noff;  // bytes from nbb to the neighbour cell (component 0 of node 0, this lane's column)
+      const double* gp = nullptr;
       bool ghost = false, physical = false;
       if (axis < 0) {
-        p = in + ((long)(g * 2 + kn) * ND) * NC * 16 + w;
+        noff = (unsigned)(((((g - g0) * 2 + kn) * ND) * NC * 16 + w) * 8);
       } else {
         const int cn = cc[axis] + dir;
-        const bool inside = valid && cn >= 0 && cn < (axis == 0 ? n0 : n1);
+        const bool inside = cn >= 0 && cn < (axis == 0 ? n0 : n1);
         const int nc = inside ? (int)cl + dir * (axis == 0 ? 1 : n0) : (int)cl;
-        p = in + ((long)((nc >> 4) * 2 + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15);
+        noff = (unsigned)((((((nc >> 4) - g0) * 2 + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15)) * 8);
         physical = !inside;
         if (GHOST) {
           const int side = 2 * axis + (dir > 0 ? 1 : 0);
-          if (!inside && valid && C.has_nbr[side]) {
+          if (!inside && C.has_nbr[side]) {
             const long slot2 = (long)(axis == 0 ? cc[1] : cc[0]) * C.halo_per_cube + f_ord[f];
-            p = A.ghost[side] + slot2 * NF * 2;  // packed trace: 2 comps per facet node (velocity, or T_i,axis)
+            gp = A.ghost[side] + slot2 * NF * 2;  // packed trace: 2 comps per facet node (velocity, or T_i,axis)
             ghost = true;
             physical = false;
           }
@@ -189,30 +216,39 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       for (int ks = 0; ks < KSF; ++ks) {
         // facet-trace row: the neighbour's node inside the block's field, the own node on the domain
         // boundary, the position in the neighbour's facet list in a packed remote trace
-        const int off = (GHOST && ghost) ? t2_row(f_tg[f][ks], q) * 2
-                                         : t2_row(physical ? C.tpw[f][ks] : f_tf[f][ks], q) * NC * 16;
+        const unsigned roff = noff + (unsigned)(t2_row(physical ? C.tpw[f][ks] : f_tf[f][ks], q) * NC * 128);
+        const int grow = GHOST ? t2_row(f_tg[f][ks], q) * 2 : 0;
+        const double* fp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(nbb) + roff);
         if (KIND == 0) {
           // a packed remote trace holds g_i = T_i,axis only; the columns j != axis meet (c n)_j = 0 there,
           // so any finite value serves: pairs (i <= j): axis 0 -> g_j, axis 1 -> g_i; full tensor: g_i
           auto at = [&](int i, int j) {
+            const int cidx = (SYM && i > j) ? j * 2 + i : i * 2 + j;
+            if (!GHOST) return t2_ld(nbb, roff + cidx * 128);
             const int og = SYM ? (axis == 0 ? j : i) : i;
-            return p[off + ((GHOST && ghost) ? og : (SYM && i > j ? j * 2 + i : i * 2 + j) * 16)];
+            return ghost ? gp[grow + og] : fp[cidx * 16];
           };
           tn[f][ks][0] = at(0, 0);
           tn[f][ks][1] = at(0, 1);
           tn[f][ks][3] = at(1, 1);
           tn[f][ks][2] = SYM ? tn[f][ks][1] : at(1, 0);
         } else {
-          const int cst = (GHOST && ghost) ? 1 : 16;
-          tn[f][ks][0] = p[off];
-          tn[f][ks][1] = p[off + cst];
+          if (!GHOST) {
+            tn[f][ks][0] = t2_ld(nbb, roff);
+            tn[f][ks][1] = t2_ld(nbb, roff + 128);
+          } else {
+            tn[f][ks][0] = ghost ? gp[grow] : fp[0];
+            tn[f][ks][1] = ghost ? gp[grow + 1] : fp[16];
+          }
         }
       }
     }
 
     if (KIND == 0) {
       // ---- F ---------------------------------------------------------------------------------
-      const long ubase = ((long)item * ND) * 2 * 16 + w;
+      const long ubase = ((long)item * ND) * 2 * 16;
+      double* outb = out + ubase;            // wave-uniform
+      const double* auxb = aux + ubase;
       int sslot = -1;
       if (A.sponge_slot != nullptr && active) sslot = A.sponge_slot[e];
       double cs = A.c_self, ca = A.c_aux, cnw = A.c_new;
@@ -227,11 +263,11 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       if (MODE == 1) {
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
-          const int a = (4 * m + q < ND) ? 4 * m + q : 0;
+          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 2 * 16 + w) * 8);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            po[m][i] = out[ubase + (a * 2 + i) * 16];
-            pa[m][i] = aux[ubase + (a * 2 + i) * 16];
+            po[m][i] = t2_ld(outb, ro + i * 128);
+            pa[m][i] = t2_ld(auxb, ro + i * 128);
           }
         }
       }
@@ -261,7 +297,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       // wave runs in program order, so these reads precede the stores below.
       if (__any(sslot >= 0)) {
         if (sslot >= 0) {
-          const double* ua = A.uabs + ubase;
+          const double* ua = A.uabs + ubase + w;
           const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND
           double s[S4][2];
 #pragma unroll
@@ -296,32 +332,35 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
       for (int m = 0; m < S4; ++m) {
         const int a = 4 * m + q;
+        const unsigned ro = (unsigned)((a * 2 * 16 + w) * 8);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           double v = acc[i][m];
           if (MODE == 1) v = cs * po[m][i] + ca * pa[m][i] + cnw * v;
-          if (active && a < ND) out[ubase + (a * 2 + i) * 16] = v;
+          if (active && a < ND) t2_st(outb, ro + i * 128, v);
         }
       }
     } else {
       // ---- G ---------------------------------------------------------------------------------
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
-      const long sbase = ((long)item * ND) * 4 * 16 + w;
+      const long sbase = ((long)item * ND) * 4 * 16;
+      double* outb = out + sbase;            // wave-uniform
+      const double* auxb = aux + sbase;
       double po[S4][3], pa[S4][3], pl[S4], pal[S4];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
       if (MODE == 1) {
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
-          const int a = (4 * m + q < ND) ? 4 * m + q : 0;
-          po[m][0] = out[sbase + (a * 4 + 0) * 16];
-          po[m][1] = out[sbase + (a * 4 + 1) * 16];
-          po[m][2] = out[sbase + (a * 4 + 3) * 16];
-          pa[m][0] = aux[sbase + (a * 4 + 0) * 16];
-          pa[m][1] = aux[sbase + (a * 4 + 1) * 16];
-          pa[m][2] = aux[sbase + (a * 4 + 3) * 16];
+          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 4 * 16 + w) * 8);
+          po[m][0] = t2_ld(outb, ro + 0 * 128);
+          po[m][1] = t2_ld(outb, ro + 1 * 128);
+          po[m][2] = t2_ld(outb, ro + 3 * 128);
+          pa[m][0] = t2_ld(auxb, ro + 0 * 128);
+          pa[m][1] = t2_ld(auxb, ro + 1 * 128);
+          pa[m][2] = t2_ld(auxb, ro + 3 * 128);
           if (!SYM) {
-            pl[m] = out[sbase + (a * 4 + 2) * 16];
-            pal[m] = aux[sbase + (a * 4 + 2) * 16];
+            pl[m] = t2_ld(outb, ro + 2 * 128);
+            pal[m] = t2_ld(auxb, ro + 2 * 128);
           }
         }
       }
@@ -329,9 +368,12 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       t2d4 Sd[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}}, So = t2d4{0, 0, 0, 0};
       auto fold = [&](const double c0, const double c1, const t2d4 (&v)[2]) {
         // W_ik += c_k v_i
-        Sd[0] += c0 * v[0];
-        Sd[1] += c1 * v[1];
-        So += c1 * v[0] + c0 * v[1];
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          Sd[0][m] += c0 * v[0][m];
+          Sd[1][m] += c1 * v[1][m];
+          So[m] += c1 * v[0][m] + c0 * v[1][m];
+        }
       };
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
       for (int m = 0; m < S4; ++m) {
         const int a = 4 * m + q;
+        const unsigned ro = (unsigned)((a * 4 * 16 + w) * 8);
         const double tr = lam * (Sd[0][m] + Sd[1][m]);
         double v00 = 2.0 * mu * Sd[0][m] + tr, v11 = 2.0 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
         if (MODE == 1) {
@@ -363,10 +406,10 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           v01 = A.c_self * po[m][1] + A.c_aux * pa[m][1] + A.c_new * v01;
         }
         if (active && a < ND) {
-          out[sbase + (a * 4 + 0) * 16] = v00;
-          out[sbase + (a * 4 + 1) * 16] = v01;
-          if (!SYM) out[sbase + (a * 4 + 2) * 16] = v10;
-          out[sbase + (a * 4 + 3) * 16] = v11;
+          t2_st(outb, ro + 0 * 128, v00);
+          t2_st(outb, ro + 1 * 128, v01);
+          if (!SYM) t2_st(outb, ro + 2 * 128, v10);
+          t2_st(outb, ro + 3 * 128, v11);
         }
       }
     }
@@ -381,6 +424,8 @@ T2Const tile2d_const(const MeshDev& md) {
   C.ncube = (int32_t)md.ncube;
   C.ngroups = (int32_t)(md.ncube_pad / 16);
   C.halo_per_cube = md.halo_per_cube;
+  C.gpr = (md.n[0] + 15) / 16 + 1;
+  C.inv_n0 = 1.0 / (double)md.n[0];
   for (int s = 0; s < 4; ++s) C.has_nbr[s] = md.has_nbr[s];
   const int ksf = (md.nf + 3) / 4;
   auto pack = [&](auto entry, int ks) {
@@ -394,21 +439,22 @@ T2Const tile2d_const(const MeshDev& md) {
   for (int f = 0; f < 3; ++f) {
     for (int ks = 0; ks < 2; ++ks) C.tpw[f][ks] = ks < ksf ? pack([&](int bb) { return md.fnode[f][bb]; }, ks) : 0u;
     for (int k = 0; k < 2; ++k) {
-      C.nb_axis[k][f] = md.nb_axis[k][f];
-      C.nb_dir[k][f] = md.nb_dir[k][f];
-      C.nb_cls[k][f] = md.nb_cls[k][f];
+      T2Class& K = C.cls[k];
+      K.nb_axis[f] = md.nb_axis[k][f];
+      K.nb_dir[f] = md.nb_dir[k][f];
+      K.nb_cls[f] = md.nb_cls[k][f];
       const int ord = md.face_ord[md.nb_cls[k][f]][md.nb_face[k][f]];
-      C.slot_ord[k][f] = ord < 0 ? 0 : ord;
+      K.slot_ord[f] = ord < 0 ? 0 : ord;
       for (int ks = 0; ks < 2; ++ks) {
-        C.tfw[k][f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_node[k][f][bb]; }, ks) : 0u;
-        C.tgw[k][f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_fnode[k][f][bb]; }, ks) : 0u;
+        K.tfw[f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_node[k][f][bb]; }, ks) : 0u;
+        K.tgw[f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_fnode[k][f][bb]; }, ks) : 0u;
       }
-      for (int j = 0; j < 2; ++j) C.cn[k][f][j] = md.cn[k][f][j];
+      for (int j = 0; j < 2; ++j) K.cn[f][j] = md.cn[k][f][j];
     }
   }
   for (int k = 0; k < 2; ++k)
     for (int r = 0; r < 2; ++r)
-      for (int j = 0; j < 2; ++j) C.Jinv[k][r][j] = md.Jinv[k][r][j];
+      for (int j = 0; j < 2; ++j) C.cls[k].Jinv[r][j] = md.Jinv[k][r][j];
   return C;
 }
 
