@@ -71,6 +71,10 @@ struct sg_handle {
   int64_t src_nsteps = 0;
   int64_t src_step = 0;
   bool src_static = false;  // one time slice that holds at every step
+  // 2-D tile path: the source is added inside the G stage kernels (StageArgs::src_slot / src_idx)
+  bool src_fused = false;
+  int32_t* src_slot_d = nullptr;
+  int32_t* src_idx_d = nullptr;
   // halo
   const double* ghost[4][6];
   // execution
@@ -161,6 +165,8 @@ void sg_destroy(sg_handle* h) {
   if (h->sponge_B) (void)hipFree(h->sponge_B);
   if (h->src_nodes) (void)hipFree(h->src_nodes);
   if (h->src_values) (void)hipFree(h->src_values);
+  if (h->src_slot_d) (void)hipFree(h->src_slot_d);
+  if (h->src_idx_d) (void)hipFree(h->src_idx_d);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -769,6 +775,15 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
     (void)hipFree(h->src_values);
     h->src_values = nullptr;
   }
+  if (h->src_slot_d) {
+    (void)hipFree(h->src_slot_d);
+    h->src_slot_d = nullptr;
+  }
+  if (h->src_idx_d) {
+    (void)hipFree(h->src_idx_d);
+    h->src_idx_d = nullptr;
+  }
+  h->src_fused = false;
   h->src_nnz = 0;
   h->src_nsteps = 0;
   h->src_step = 0;
@@ -831,6 +846,33 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
       std::memcpy(&vals[((size_t)k * nnz + j) * d * d], &values[((size_t)k * nnz + order[(size_t)j]) * d * d], sizeof(double) * d * d);
   HIPCHECK(h, hipMemcpy(h->src_nodes, offs.data(), (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
   HIPCHECK(h, hipMemcpy(h->src_values, vals.data(), vbytes, hipMemcpyHostToDevice));
+  if (h->use_tile && !std::getenv("SEIGEN_HIP_SOURCE_LAUNCH")) {
+    // tile kernels: item (16 squares of one class) -> slot, and per slot a dense (node, cell) -> value-row table, so
+    // that the G stages add the source themselves (one launch less per G stage).  A node listed twice keeps the
+    // separate launch (which adds both entries).
+    const int64_t nd = h->re.nd, nitems = h->md.ncube_pad / 16 * 2;
+    std::vector<int32_t> slot((size_t)nitems, -1), idx;
+    bool dup = false;
+    for (int64_t j = 0; j < nnz && !dup; ++j) {
+      const int64_t node = nodes[order[(size_t)j]];
+      const int64_t e = node / nd, b = node % nd, cube = e / 2, cls = e % 2;
+      const int64_t item = (cube / 16) * 2 + cls;
+      if (slot[(size_t)item] < 0) {
+        slot[(size_t)item] = (int32_t)(idx.size() / (size_t)(nd * 16));
+        idx.resize(idx.size() + (size_t)(nd * 16), -1);
+      }
+      int32_t& cell = idx[((size_t)slot[(size_t)item] * nd + b) * 16 + cube % 16];
+      dup = cell >= 0;
+      cell = (int32_t)j;
+    }
+    if (!dup) {
+      HIPCHECK(h, hipMalloc((void**)&h->src_slot_d, slot.size() * sizeof(int32_t)));
+      HIPCHECK(h, hipMalloc((void**)&h->src_idx_d, idx.size() * sizeof(int32_t)));
+      HIPCHECK(h, hipMemcpy(h->src_slot_d, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HIPCHECK(h, hipMemcpy(h->src_idx_d, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      h->src_fused = true;
+    }
+  }
   h->src_nnz = nnz;
   h->src_nsteps = nsteps;
   h->src_static = is_static;
@@ -899,8 +941,12 @@ static void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], in
   }
 }
 
+static bool source_active(const sg_handle* h) {
+  return h->src_nnz != 0 && (h->src_static || h->src_step < h->src_nsteps);
+}
+
 static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mode, double c_self, double c_aux,
-                  double c_new, int region, int uabs_f = SG_FIELD_U) {
+                  double c_new, int region, int uabs_f = SG_FIELD_U, bool with_source = false) {
   StageArgs a;
   std::memset(&a, 0, sizeof(a));
   a.in = h->field[in_f];
@@ -933,6 +979,11 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.c_self = c_self;
   a.c_aux = c_aux;
   a.c_new = c_new;
+  if (with_source && h->src_fused && source_active(h)) {  // tile path: the G kernel adds this step's source values
+    a.src_slot = h->src_slot_d;
+    a.src_idx = h->src_idx_d;
+    a.src_vals = h->src_values + (size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz * h->cfg.dim * h->cfg.dim;
+  }
   std::vector<Box> boxes;
   region_boxes(h, region, boxes);
   if (h->use_mfma || h->use_lane || h->use_tile) {
@@ -1008,6 +1059,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
 // the source lives on single nodes: added to each part of a split stage right after the launch
 // that wrote it (INTERIOR + BOUNDARY: all of it after the second launch)
 static int add_source(sg_handle* h, int field, double coef, int region = SG_REGION_ALL) {
+  if (h->src_fused) return SG_OK;  // added by the stage kernel (run_op with_source)
   if (h->src_nnz == 0 || (!h->src_static && h->src_step >= h->src_nsteps) || region == SG_REGION_INTERIOR) return SG_OK;
   const int d = h->cfg.dim;
   int64_t off = 0, cnt = h->src_nnz;
@@ -1030,7 +1082,7 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
     case SG_STAGE_UH1:
       return run_op(h, 0, SG_FIELD_S, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
     case SG_STAGE_STEMP:
-      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_SH, -1, 0, 0, 0, 0, region, SG_FIELD_U, true);
       if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
       return rc;
     case SG_STAGE_U1:
@@ -1040,13 +1092,13 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
       if (h->rho_physical) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt / h->rho, c3 / h->rho, region);
       return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, h->rho, dt, c3, region);
     case SG_STAGE_SH1:
-      rc = run_op(h, 1, SG_FIELD_U, SG_FIELD_SH, -1, 0, 0, 0, 0, region);
+      rc = run_op(h, 1, SG_FIELD_U, SG_FIELD_SH, -1, 0, 0, 0, 0, region, SG_FIELD_U, true);
       if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
       return rc;
     case SG_STAGE_UTEMP:
       return run_op(h, 0, SG_FIELD_SH, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
     case SG_STAGE_S1:
-      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, SG_FIELD_SH, 1, 1.0, dt, c3, region);
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, SG_FIELD_SH, 1, 1.0, dt, c3, region, SG_FIELD_U, true);
       if (rc == SG_OK) rc = add_source(h, SG_FIELD_S, c3, region);
       return rc;
   }
@@ -1197,7 +1249,7 @@ int sg_apply_G(sg_handle* h, int u_in, int s_out, int use_source) {
     return fail(h, SG_ERR_ARG, "sg_apply_G: u_in must be a velocity field, s_out a stress field");
   if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called first");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  int rc = run_op(h, 1, u_in, s_out, -1, 0, 0, 0, 0, SG_REGION_ALL);
+  int rc = run_op(h, 1, u_in, s_out, -1, 0, 0, 0, 0, SG_REGION_ALL, SG_FIELD_U, use_source != 0);
   if (rc == SG_OK && use_source) rc = add_source(h, s_out, 1.0);
   return rc;
 }

@@ -54,6 +54,12 @@ struct StageArgs {
   int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
   int32_t grid_blocks;          // MFMA path: size of the persistent grid (a multiple of 8)
   int32_t f32;                  // MFMA path: fields, halo buffers and operator tables are float (sg_config.dtype = 1)
+  // 2-D tile path, G stages: the sparse nodal source (elastic.py:217-218) added inside the stage kernel instead of
+  // by a launch of its own.  src_slot[item] = slot of an item (16 cells of one class) that holds source nodes, or -1;
+  // src_idx[slot][node][cell] = row of that node in this step's value table src_vals[row][dim*dim], or -1.
+  const int32_t* src_slot;
+  const int32_t* src_idx;
+  const double* src_vals;
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)

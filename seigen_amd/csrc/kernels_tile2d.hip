@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
     }
     const double* ownb = in + ((long)item * ND) * NC * 16;   // wave-uniform
     const int e = (int)cl * 2 + k;  // cell index in the host numbering
+    // G: does this item hold source nodes?  (a scalar load that is consumed only in the epilogue)
+    const int sslot_src = (KIND == 1 && A.src_slot != nullptr) ? A.src_slot[item] : -1;
 
     // ---- own rows: requested first.  B row of this lane at k-step ks = node 4 ks + q; rows past ND meet
     //      all-zero operator columns, so any finite value will do: clamp to node 0
@@ -399,10 +401,20 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         const unsigned ro = (unsigned)((a * 4 * 16 + w) * 8);
         const double tr = lam * (Sd[0][m] + Sd[1][m]);
         double v00 = 2.0 * mu * Sd[0][m] + tr, v11 = 2.0 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
+        if (sslot_src >= 0) {  // wave-uniform, a handful of items: + S_ij at the source nodes (elastic.py:217-218)
+          const int ix = (a < ND) ? A.src_idx[(sslot_src * ND + a) * 16 + w] : -1;
+          if (ix >= 0) {
+            const double* sv = A.src_vals + (long)ix * 4;
+            v00 += sv[0];
+            v01 += sv[1];
+            v10 += sv[2];
+            v11 += sv[3];
+          }
+        }
         if (MODE == 1) {
           v00 = A.c_self * po[m][0] + A.c_aux * pa[m][0] + A.c_new * v00;
           v11 = A.c_self * po[m][2] + A.c_aux * pa[m][2] + A.c_new * v11;
-          if (!SYM) v10 = A.c_self * pl[m] + A.c_aux * pal[m] + A.c_new * v01;
+          if (!SYM) v10 = A.c_self * pl[m] + A.c_aux * pal[m] + A.c_new * v10;
           v01 = A.c_self * po[m][1] + A.c_aux * pa[m][1] + A.c_new * v01;
         }
         if (active && a < ND) {
