@@ -122,6 +122,12 @@ int sg_sync(sg_handle* h);
  * makes it the current stream around its torch.distributed calls, which order themselves against
  * the current stream (the role PyOP2's implicit halo/compute ordering has, elastic.py:404-436) */
 int sg_get_stream(const sg_handle* h, void** stream);
+/* Blocks with neighbours launch SG_REGION_SECOND of a split stage on a second, lower-priority stream beside
+ * SG_REGION_FIRST of the same stage (it depends on the stage before, not on FIRST; SEIGEN_HIP_OVERLAP=0 switches
+ * this off); everything queued later on the main stream waits for it.  NULL if the handle has no such stream.
+ * For instrumentation: the host layer records an event on it to tell how long the next stage really waited
+ * for traces (what ParLoopHaloEnd times in the reference, tests/tiling/utils.py:144). */
+int sg_get_second_stream(const sg_handle* h, void** stream);
 
 /* physical coordinates of the DG nodes, [cell][node][dim]; `degree` may differ
  * from the solver's (e.g. 4 for the DG4 sponge space of

@@ -43,6 +43,7 @@ SYMBOLS = {
     "sg_get_info": (C.c_int, [_P, C.POINTER(SgInfo)]),
     "sg_sync": (C.c_int, [_P]),
     "sg_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "sg_get_second_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "sg_node_coords": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "sg_block_node_coords": (C.c_int, [C.POINTER(SgConfig), C.c_int, _P, C.c_size_t]),
     "sg_set_params": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, C.c_int]),

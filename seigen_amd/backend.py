@@ -48,6 +48,12 @@ class HipBlock(object):
         check(self.lib.sg_get_stream(self.h, C.byref(p)), self.h)
         return p.value or 0
 
+    def stream2_ptr(self):
+        """hipStream_t of the stream that SG_REGION_SECOND launches of a split stage run on, or 0."""
+        p = C.c_void_p()
+        check(self.lib.sg_get_second_stream(self.h, C.byref(p)), self.h)
+        return p.value or 0
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.sg_destroy(self.h)

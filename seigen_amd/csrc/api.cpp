@@ -80,6 +80,14 @@ struct sg_handle {
   // execution
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // Split stages (blocks with neighbours): SG_REGION_SECOND of a stage depends on the stage before it, not on the
+  // FIRST launch of its own stage, so it may run on a second (lower-priority) stream and fill the slots that FIRST's
+  // persistent blocks free as they drain (default; SEIGEN_HIP_OVERLAP=0: one stream).  ev_stage: everything before this stage's FIRST;
+  // ev_second: the SECOND launch, which every later piece of work on `stream` waits for.
+  bool overlap = false;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_stage = nullptr, ev_second = nullptr;
+  bool second_pending = false;
   int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
   int grid_full = 0;    // ... and otherwise (every block slot of the device)
   T2Const t2c;          // 2-D tile kernels: kernarg copy of the mesh tables
@@ -93,7 +101,7 @@ struct sg_handle {
   double last_ms = 0.0;
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;   // per-launch event pairs, resolved lazily (no sync in the hot loop)
-  std::vector<int> ev_stage;         // stage of pair k = events 2k, 2k+1
+  std::vector<int> ev_stage_ids;         // stage of pair k = events 2k, 2k+1
   sg_counters_t counters;
   std::string err;
 };
@@ -121,6 +129,25 @@ static int fail(sg_handle* h, int code, const std::string& msg) {
 
 static bool field_is_stress(int f) { return f == SG_FIELD_S || f == SG_FIELD_SH; }
 
+// work queued on `stream` from here on comes after the SECOND launch that may still run on stream2
+static int join_second(sg_handle* h) {
+  if (h->second_pending) {
+    HIPCHECK(h, hipStreamWaitEvent(h->stream, h->ev_second, 0));
+    h->second_pending = false;
+  }
+  return SG_OK;
+}
+
+// the host waits for everything the handle has queued (both streams)
+static hipError_t sync_all(sg_handle* h) {
+  if (h->second_pending) {
+    hipError_t e = hipStreamWaitEvent(h->stream, h->ev_second, 0);
+    if (e != hipSuccess) return e;
+    h->second_pending = false;
+  }
+  return hipStreamSynchronize(h->stream);
+}
+
 extern "C" {
 
 const char* sg_last_error(const sg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -128,7 +155,7 @@ const char* sg_last_error(const sg_handle* h) { return h ? h->err.c_str() : g_cr
 void sg_destroy(sg_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream) (void)sync_all(h);
   for (int f = 0; f < 4; ++f)
     if (h->field[f]) (void)hipFree(h->field[f]);
   if (h->md_dev) (void)hipFree(h->md_dev);
@@ -170,6 +197,12 @@ void sg_destroy(sg_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+  }
+  if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
+  if (h->ev_second) (void)hipEventDestroy(h->ev_second);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -346,11 +379,22 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     const int64_t dofs = h->ncells * (int64_t)h->re.nd * (cfg->dim + cfg->dim * cfg->dim);
     h->graph_ok = ge ? (std::strcmp(ge, "0") != 0) : (!h->use_mfma && dofs <= (int64_t)1 << 23);
   }
+  {
+    const char* ov = std::getenv("SEIGEN_HIP_OVERLAP");
+    h->overlap = cfg->nbr_mask != 0 && !(ov && std::strcmp(ov, "0") == 0);
+  }
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHECK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   if (cfg->stream) {
     h->stream = (hipStream_t)cfg->stream;
   } else {
-    HIPCHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHECK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, h->overlap ? prio_hi : 0));
     h->own_stream = true;
+  }
+  if (h->overlap) {
+    HIPCHECK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+    HIPCHECK(h, hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+    HIPCHECK(h, hipEventCreateWithFlags(&h->ev_second, hipEventDisableTiming));
   }
   HIPCHECK(h, hipEventCreate(&h->ev0));
   HIPCHECK(h, hipEventCreate(&h->ev1));
@@ -378,6 +422,12 @@ int sg_create(const sg_config* cfg, sg_handle** out) {
 int sg_get_stream(const sg_handle* h, void** stream) {
   if (!h || !stream) return SG_ERR_ARG;
   *stream = (void*)h->stream;
+  return SG_OK;
+}
+
+int sg_get_second_stream(const sg_handle* h, void** stream) {
+  if (!h || !stream) return SG_ERR_ARG;
+  *stream = (void*)h->stream2;
   return SG_OK;
 }
 
@@ -410,7 +460,8 @@ int sg_get_info(const sg_handle* h, sg_info_t* out) {
 int sg_sync(sg_handle* h) {
   if (!h) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (int rc = join_second(h)) return rc;
+  HIPCHECK(h, sync_all(h));
   return SG_OK;
 }
 
@@ -457,7 +508,7 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
   h->rho = density;
   h->rho_physical = 0;
   if (h->rho2_d) {
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, sync_all(h));
     (void)hipFree(h->rho2_d);
     h->rho2_d = nullptr;
   }
@@ -467,7 +518,7 @@ int sg_set_params(sg_handle* h, double density, double dt, const double* lambda,
     size_t nb = (size_t)h->ncells * sizeof(double);
     if (!h->lam_d) HIPCHECK(h, hipMalloc((void**)&h->lam_d, nb));
     if (!h->mu_d) HIPCHECK(h, hipMalloc((void**)&h->mu_d, nb));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, sync_all(h));
     HIPCHECK(h, hipMemcpy(h->lam_d, lambda, nb, hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->mu_d, mu, nb, hipMemcpyHostToDevice));
     h->lam0 = lambda[0];
@@ -484,7 +535,7 @@ int sg_set_density(sg_handle* h, const double* rho, int per_cell, int physical) 
   if (h) h->epoch += 1;
   if (!h || !rho) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, sync_all(h));
   if (h->rho2_d) {
     (void)hipFree(h->rho2_d);
     h->rho2_d = nullptr;
@@ -513,7 +564,7 @@ static int leave_sym_mode(sg_handle* h) {
   if (!h->sym) return SG_OK;
   for (int f : {SG_FIELD_S, SG_FIELD_SH})
     if (launch_mirror(h->md, h->field[f], h->f32, h->stream) != 0) return fail(h, SG_ERR_DEVICE, "mirror kernel launch failed");
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, sync_all(h));
   h->sym = false;
   return SG_OK;
 }
@@ -599,7 +650,7 @@ static int transfer_pipelined(sg_handle* h, int field, int64_t cell0, int64_t nc
       }
     }
   }
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, sync_all(h));
   return SG_OK;
 }
 
@@ -607,7 +658,8 @@ static int transfer_pipelined(sg_handle* h, int field, int64_t cell0, int64_t nc
 // field.  gw == 1: the layouts coincide; otherwise go through a staging buffer + layout kernel.
 static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, bool to_device) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  if (int rc = join_second(h)) return rc;
+  HIPCHECK(h, sync_all(h));
   const size_t per_cell = h->field_len[field] / (size_t)h->ncells;
   // downloads only: uploads from pageable memory already run at 47 GB/s inside the runtime (measured,
   // tools/transfer_rate.py: 35 GB/s through this pipeline)
@@ -649,12 +701,12 @@ static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, doub
       int* flag = (h->sym && field_is_stress(field)) ? h->sym_flag : nullptr;
       if (launch_layout(h->md, comps, 0, h->field[field], h->staging, cell0 + done, n, 0, flag, h->f32, h->stream) != 0)
         return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
-      HIPCHECK(h, hipStreamSynchronize(h->stream));
+      HIPCHECK(h, sync_all(h));
     } else {
       const int symdl = (h->sym && field_is_stress(field)) ? 1 : 0;
       if (launch_layout(h->md, comps, 1, h->field[field], h->staging, cell0 + done, n, symdl, nullptr, h->f32, h->stream) != 0)
         return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
-      HIPCHECK(h, hipStreamSynchronize(h->stream));
+      HIPCHECK(h, sync_all(h));
       HIPCHECK(h, hipMemcpy(host + (size_t)done * per_cell, h->staging, nb, hipMemcpyDeviceToHost));
     }
   }
@@ -708,7 +760,7 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   if (h) h->epoch += 1;
   if (!h) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, sync_all(h));
   if (h->sponge_slot) {
     (void)hipFree(h->sponge_slot);
     h->sponge_slot = nullptr;
@@ -766,7 +818,7 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   if (h) h->epoch += 1;
   if (!h || nnz < 0) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
+  HIPCHECK(h, sync_all(h));
   if (h->src_nodes) {
     (void)hipFree(h->src_nodes);
     h->src_nodes = nullptr;
@@ -1106,17 +1158,18 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
 }
 
 static int resolve_timing(sg_handle* h) {
-  if (h->ev_stage.empty()) return SG_OK;
-  HIPCHECK(h, hipStreamSynchronize(h->stream));
-  for (size_t k = 0; k < h->ev_stage.size(); ++k) {
+  if (h->ev_stage_ids.empty()) return SG_OK;
+  if (int rc = join_second(h)) return rc;
+  HIPCHECK(h, sync_all(h));
+  for (size_t k = 0; k < h->ev_stage_ids.size(); ++k) {
     float ms = 0;
     HIPCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]));
-    if (h->ev_stage[k] == 6)
+    if (h->ev_stage_ids[k] == 6)
       h->counters.halo_pack_ms += ms;
     else
-      h->counters.kernel_ms[h->ev_stage[k]] += ms;
+      h->counters.kernel_ms[h->ev_stage_ids[k]] += ms;
   }
-  h->ev_stage.clear();
+  h->ev_stage_ids.clear();
   return SG_OK;
 }
 
@@ -1126,26 +1179,44 @@ int sg_run_stage(sg_handle* h, int stage, int region) {
   if (region < 0 || region > 4) return fail(h, SG_ERR_ARG, "unknown region");
   if (stage < 0 || stage > 5) return fail(h, SG_ERR_ARG, "unknown stage");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  size_t k = h->ev_stage.size();
+  const bool second = h->overlap && region == SG_REGION_SECOND;
+  hipStream_t const main_stream = h->stream;
+  if (second) {
+    // depends on everything before this stage's FIRST (ev_stage), not on FIRST itself
+    HIPCHECK(h, hipStreamWaitEvent(h->stream2, h->ev_stage, 0));
+    h->stream = h->stream2;
+  } else {
+    if (int rc = join_second(h)) return rc;
+    if (h->overlap && region == SG_REGION_FIRST) HIPCHECK(h, hipEventRecord(h->ev_stage, h->stream));
+  }
+  size_t k = h->ev_stage_ids.size();
+  int rc = SG_OK;
   if (h->timing) {
     if (k >= 8192) {
-      int rc = resolve_timing(h);
+      h->stream = main_stream;
+      rc = resolve_timing(h);
       if (rc != SG_OK) return rc;
+      if (second) h->stream = h->stream2;
       k = 0;
     }
-    while (h->ev_pool.size() < 2 * k + 2) {
+    while (rc == SG_OK && h->ev_pool.size() < 2 * k + 2) {
       hipEvent_t e;
-      HIPCHECK(h, hipEventCreate(&e));
-      h->ev_pool.push_back(e);
+      if (hipEventCreate(&e) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventCreate failed");
+      else h->ev_pool.push_back(e);
     }
-    HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k], h->stream));
+    if (rc == SG_OK && hipEventRecord(h->ev_pool[2 * k], h->stream) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
   }
-  int rc = run_stage_impl(h, stage, region);
+  if (rc == SG_OK) rc = run_stage_impl(h, stage, region);
+  if (rc == SG_OK && h->timing) {
+    if (hipEventRecord(h->ev_pool[2 * k + 1], h->stream) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
+    else h->ev_stage_ids.push_back(stage);
+  }
+  if (second) {
+    if (rc == SG_OK && hipEventRecord(h->ev_second, h->stream2) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
+    h->second_pending = rc == SG_OK;
+    h->stream = main_stream;
+  }
   if (rc != SG_OK) return rc;
-  if (h->timing) {
-    HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k + 1], h->stream));
-    h->ev_stage.push_back(stage);
-  }
   h->counters.launches[stage] += 1;
   return SG_OK;
 }
@@ -1271,7 +1342,8 @@ int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes) {
 
 // pack launches are timed like stage launches (event pairs resolved lazily; stage id 6 = halo pack)
 static int pack_begin(sg_handle* h, size_t& k) {
-  k = h->ev_stage.size();
+  if (int rc = join_second(h)) return rc;
+  k = h->ev_stage_ids.size();
   if (!h->timing) return SG_OK;
   if (k >= 8192) {
     int rc = resolve_timing(h);
@@ -1290,7 +1362,7 @@ static int pack_begin(sg_handle* h, size_t& k) {
 static int pack_end(sg_handle* h, size_t k, size_t nbytes) {
   if (h->timing) {
     HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k + 1], h->stream));
-    h->ev_stage.push_back(6);
+    h->ev_stage_ids.push_back(6);
   }
   h->counters.halo_pack_launches += 1;
   h->counters.halo_bytes_packed += (int64_t)nbytes;

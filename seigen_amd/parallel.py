@@ -80,6 +80,11 @@ class HaloExchanger(object):
         self.part = partition
         self.group = group
         self.stream = stream      # torch.cuda.Stream the block launches on (None: CPU tensors / gloo)
+        # the block's second stream (SECOND launches of a split stage run there beside FIRST, include/seigen_hip.h):
+        # only to time how long a stage really waited for traces
+        self.stream2 = None
+        if stream is not None and hasattr(block, "stream2_ptr") and block.stream2_ptr():
+            self.stream2 = torch.cuda.ExternalStream(block.stream2_ptr(), device=stream.device)
         on_gpu = torch.device(device).type == "cuda"
         self.staged = on_gpu and dist.get_backend(group) != "nccl"
         self.hsend, self.hrecv = {}, {}
@@ -112,7 +117,8 @@ class HaloExchanger(object):
     # ---- instrumentation: what PyOP2's ParLoopHaloEnd timer measures in the reference (tests/tiling/utils.py:144)
     def reset_stats(self, timing=False):
         """timing=True: measure how long the consumer waits for each exchange - on the launch stream
-        (event pair around the wait) with a device-aware transport, on the host otherwise."""
+        (event pair around the wait; with a second stream: from the end of the SECOND launch, which
+        runs beside the exchange, to the end of the wait) with a device-aware transport, on the host otherwise."""
         self.timing = bool(timing)
         self.exchanges = 0
         self._wait_host_s = 0.0
@@ -121,8 +127,9 @@ class HaloExchanger(object):
 
     def _resolve_wait_events(self):
         for a, b in self._wait_events:
+            a.synchronize()
             b.synchronize()
-            self._wait_dev_ms += a.elapsed_time(b)
+            self._wait_dev_ms += max(0.0, a.elapsed_time(b))
         self._wait_events = []
 
     def stats(self):
@@ -183,7 +190,8 @@ class HaloExchanger(object):
                 self._wait_host_s += time.perf_counter() - t0
         if self.timing:
             a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
-            a.record(self.stream)
+            # the wait only costs what it lasts beyond the SECOND launch that was queued just before it
+            a.record(self.stream2 if self.stream2 is not None else self.stream)
             self._finish(kind, reqs)
             b.record(self.stream)
             self._wait_events.append((a, b))

@@ -23,16 +23,21 @@ def main():
     from seigen_amd.mesh import Partition
     from seigen_amd.parallel import HaloExchanger
     torch.cuda.set_device(0)
+    # started without torchrun (e.g. under rocprofv3, which must not see a launcher): a one-rank rendezvous of our own
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 
     class SelfNeighbour(Partition):
         def neighbour(self, side):
             return 0 if side >> 1 == 2 else None
 
-    n, P, steps = (64, 64, 64), 4, 60
+    n, P, steps = (64, 64, 64), 4, int(os.environ.get("SEIGEN_BENCH_STEPS", "60"))
     h = [1.0 / 64] * 3
     rng = np.random.default_rng(0)
-    for grid_env in (None, "512", "496"):
+    for grid_env in (None, "512", "496")[:int(os.environ.get("SEIGEN_BENCH_GRIDS", "3"))]:
         if grid_env:
             os.environ["SEIGEN_HIP_GRID_BLOCKS"] = grid_env
         part = SelfNeighbour(n, 0, 1)
