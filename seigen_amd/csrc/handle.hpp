@@ -1,0 +1,164 @@
+// The handle behind the C-ABI (include/seigen_hip.h) and what its translation units share:
+//   api.cpp      create / destroy, parameters, sponge, source, table exports
+//   transfer.cpp host <-> device field transfers (layout conversion, pinned pipeline)
+//   stages.cpp   regions, stage launches, the LF4 step, graphs, halo packs, timing
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/seigen_hip.h"
+#include "kernels.hpp"
+#include "mesh_tables.hpp"
+#include "mfma_tables.hpp"
+#include "refelem.hpp"
+
+using namespace sg;
+
+struct sg_handle {
+  sg_config cfg;
+  RefElem re;
+  MeshDev md;
+  MeshDev* md_dev = nullptr;
+  double* Dt = nullptr;
+  double* Lt = nullptr;
+  double* field[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t field_len[4] = {0, 0, 0, 0};    // doubles, host layout (ncells * nd * comps)
+  size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
+  bool use_mfma = false;
+  bool use_lane = false;
+  bool use_tile = false;    // 2-D MFMA tile kernels (kernels_tile2d.hip), gw = 16
+  int f32 = 0;              // sg_config.dtype = 1: fields, halo buffers, operator tiles and arithmetic are float (MFMA path)
+  bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
+  int* sym_flag = nullptr;  // device word set by an upload that is not symmetric
+  // active (cell group, class) items of each region of a split stage (MFMA / lane paths), by sg_region
+  int32_t* region_items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t region_nitems[5] = {-1, -1, -1, -1, -1};  // -1: not built yet
+  double* fragF = nullptr;  // MFMA operator fragment tables (device)
+  double* fragG = nullptr;
+  double* fragL = nullptr;
+  double* staging = nullptr;  // host-layout staging buffer for layout conversion
+  // large transfers: two pinned host slots + two device slots, so that the DMA of one chunk, the
+  // layout kernel of the next and the host-side copy of the previous one overlap
+  double* pin[2] = {nullptr, nullptr};
+  double* dstage[2] = {nullptr, nullptr};
+  hipEvent_t xfer_ev[2] = {nullptr, nullptr};
+  unsigned long long* dbg = nullptr;  // SEIGEN_HIP_STAMPS=1 (diagnostic builds): [kind][8] cycle sums
+  size_t staging_len = 0;
+  int64_t ncells = 0;
+  int ncls = 0;
+  // parameters
+  bool params_set = false;
+  double rho = 1.0, dt = 0.0, lam0 = 0.0, mu0 = 0.0;
+  int per_cell = 0;
+  double* lam_d = nullptr;
+  double* mu_d = nullptr;
+  double* rho2_d = nullptr;  // per-cell density factors [cell][2] (kernels.hpp), or null
+  int rho_physical = 0;      // scalar density: 0 = rho*u0 + ..., 1 = u0 + (...)/rho
+  // sponge
+  int32_t* sponge_slot = nullptr;
+  double* sponge_B = nullptr;
+  // source
+  int64_t src_nnz = 0;
+  int64_t src_nfirst = 0;  // source nodes are stored with those in cells of SG_REGION_FIRST first
+  int64_t* src_nodes = nullptr;
+  double* src_values = nullptr;  // [nsteps][nnz][dim*dim]
+  int64_t src_nsteps = 0;
+  int64_t src_step = 0;
+  bool src_static = false;  // one time slice that holds at every step
+  // 2-D tile path: the source is added inside the G stage kernels (StageArgs::src_slot / src_idx)
+  bool src_fused = false;
+  int32_t* src_slot_d = nullptr;
+  int32_t* src_idx_d = nullptr;
+  // halo
+  const double* ghost[4][6];
+  // execution
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // Split stages (blocks with neighbours): SG_REGION_SECOND of a stage depends on the stage before it, not on the
+  // FIRST launch of its own stage, so it may run on a second (lower-priority) stream and fill the slots that FIRST's
+  // persistent blocks free as they drain (default; SEIGEN_HIP_OVERLAP=0: one stream).  ev_stage: everything before this stage's FIRST;
+  // ev_second: the SECOND launch, which every later piece of work on `stream` waits for.
+  bool overlap = false;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_stage = nullptr, ev_second = nullptr;
+  bool second_pending = false;
+  int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
+  int grid_full = 0;    // ... and otherwise (every block slot of the device)
+  T2Const t2c;          // 2-D tile kernels: kernarg copy of the mesh tables
+  int tile_grid = 0;    // 2-D tile kernels: cap of the grid in blocks of four waves (SEIGEN_HIP_TILE_GRID)
+  // small blocks are launch-bound (config 1: six 5-us launches per step): sg_step replays captured
+  // hipGraphs of one and of eight steps there; any setter that changes kernel arguments bumps the epoch
+  bool graph_ok = false;
+  uint64_t epoch = 0, graph_epoch = ~0ull;
+  hipGraphExec_t graph1 = nullptr, graph8 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;   // per-launch event pairs, resolved lazily (no sync in the hot loop)
+  std::vector<int> ev_stage_ids;         // stage of pair k = events 2k, 2k+1
+  sg_counters_t counters;
+  std::string err;
+};
+
+// smallest 2-D block (cells) that takes the MFMA tile kernels instead of the generic kernel: they win at every
+// size measured, 40 x 40 squares included (tools/path_sweep2d.py, profiles/r02/path_sweep2d_tile_v2.txt)
+static constexpr int64_t SG_TILE2D_MIN_CELLS = 0;
+
+extern std::string g_create_err;   // message of the last failed sg_create (api.cpp)
+static_assert(SG_MAX_BOXES == SG_MAX_REGION_BOXES, "kernels.hpp and seigen_hip.h disagree on the box limit");
+
+#define HIPCHECK(h, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                              \
+      return SG_ERR_DEVICE;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+inline int fail(sg_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+inline bool field_is_stress(int f) { return f == SG_FIELD_S || f == SG_FIELD_SH; }
+
+// work queued on `stream` from here on comes after the SECOND launch that may still run on stream2
+inline int join_second(sg_handle* h) {
+  if (h->second_pending) {
+    HIPCHECK(h, hipStreamWaitEvent(h->stream, h->ev_second, 0));
+    h->second_pending = false;
+  }
+  return SG_OK;
+}
+
+// the host waits for everything the handle has queued (both streams)
+inline hipError_t sync_all(sg_handle* h) {
+  if (h->second_pending) {
+    hipError_t e = hipStreamWaitEvent(h->stream, h->ev_second, 0);
+    if (e != hipSuccess) return e;
+    h->second_pending = false;
+  }
+  return hipStreamSynchronize(h->stream);
+}
+
+// transfer.cpp: make the (i > j) lines of both stress buffers valid again and continue with the full-tensor kernels
+int leave_sym_mode(sg_handle* h);
+
+// stages.cpp
+struct Box {
+  int o[3], n[3];
+};
+void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out);
+inline void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
+  region_boxes(h->cfg.dim, h->cfg.n, h->md.has_nbr, region, out);
+}
+int resolve_timing(sg_handle* h);

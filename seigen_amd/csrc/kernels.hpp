@@ -1,4 +1,4 @@
-// Launch interface between the C-ABI host code (api.cpp) and the HIP kernels.
+// Launch interface between the C-ABI host code (api.cpp, transfer.cpp, stages.cpp) and the HIP kernels.
 #pragma once
 #include <cstdint>
 

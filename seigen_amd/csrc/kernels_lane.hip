@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
   double* __restrict__ out = A.out;
 
   const long ngroups = md->ncube_pad >> 6;
-  const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (api.cpp)
+  const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (stages.cpp)
   const long nitems = listed ? (long)A.nlist : ngroups * NCLS;
   // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2)
   const long nblk = gridDim.x, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;

@@ -121,7 +121,7 @@ struct MG {
 #endif
 
 // Symmetric-stress mode (SYM = 1): every stress field of the run is symmetric (g always produces
-// a symmetric tensor, elastic.py:211-219; api.cpp checks what the user uploads), so only the six
+// a symmetric tensor, elastic.py:211-219; transfer.cpp checks what the user uploads), so only the six
 // lines (i <= j) of each node are read and written; the other three keep their slots but are
 // never touched.  Same results, 1/3 less stress traffic.
 template <int SYM, typename R>

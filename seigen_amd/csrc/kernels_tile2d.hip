@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   const double* aux = A.aux;
   double* out = A.out;
 
-  const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (api.cpp)
+  const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (stages.cpp)
   const int nitems = listed ? A.nlist : C.ngroups * 2;
   // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2); ranges start on
   // even items and every stride is even, so a wave keeps its class

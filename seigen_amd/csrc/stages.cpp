@@ -1,0 +1,529 @@
+// Stage launches of the C-ABI: regions of a split stage, the six fused launches of an LF4 step
+// (seigen/elastic.py:283-313), hipGraph replay, un-fused operator applications, halo packs, timing.
+#include "handle.hpp"
+
+// ---- stage launches --------------------------------------------------------------------
+
+void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out) {
+  out.clear();
+  int lo[3] = {0, 0, 0}, hi[3];
+  for (int a = 0; a < 3; ++a) hi[a] = n[a];
+  if (region == SG_REGION_ALL) {
+    out.push_back(Box{{0, 0, 0}, {hi[0], hi[1], hi[2]}});
+    return;
+  }
+  // interior: peel one cube off every side that has a neighbour block
+  int ilo[3] = {0, 0, 0}, ihi[3] = {hi[0], hi[1], hi[2]};
+  for (int a = 0; a < d; ++a) {
+    if (has_nbr[2 * a]) ilo[a] = 1;
+    if (has_nbr[2 * a + 1]) ihi[a] = hi[a] - 1;
+    if (ihi[a] < ilo[a]) ihi[a] = ilo[a];
+  }
+  if (region == SG_REGION_INTERIOR) {
+    out.push_back(Box{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}});
+    return;
+  }
+  // FIRST / SECOND: the interior cut in two along the slowest axis (whole runs of the layout)
+  const int ax = d - 1, mid = ilo[ax] + (ihi[ax] - ilo[ax]) / 2;
+  if (region == SG_REGION_SECOND) {
+    Box b{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}};
+    b.o[ax] = mid;
+    b.n[ax] = ihi[ax] - mid;
+    out.push_back(b);
+    return;
+  }
+  if (region == SG_REGION_FIRST) {
+    Box b{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}};
+    b.n[ax] = mid - ilo[ax];
+    out.push_back(b);
+  }
+  // boundary shell = all \ interior, as disjoint slabs: peel axis by axis
+  int clo[3] = {lo[0], lo[1], lo[2]}, chi[3] = {hi[0], hi[1], hi[2]};
+  for (int a = 0; a < d; ++a) {
+    if (ilo[a] > clo[a]) {
+      Box b;
+      for (int k = 0; k < 3; ++k) {
+        b.o[k] = clo[k];
+        b.n[k] = chi[k] - clo[k];
+      }
+      b.n[a] = ilo[a] - clo[a];
+      out.push_back(b);
+      clo[a] = ilo[a];
+    }
+    if (ihi[a] < chi[a] && ihi[a] >= clo[a]) {
+      Box b;
+      for (int k = 0; k < 3; ++k) {
+        b.o[k] = clo[k];
+        b.n[k] = chi[k] - clo[k];
+      }
+      b.o[a] = ihi[a];
+      b.n[a] = chi[a] - ihi[a];
+      out.push_back(b);
+      chi[a] = ihi[a];
+    }
+  }
+}
+
+static bool source_active(const sg_handle* h) {
+  return h->src_nnz != 0 && (h->src_static || h->src_step < h->src_nsteps);
+}
+
+static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mode, double c_self, double c_aux,
+                  double c_new, int region, int uabs_f = SG_FIELD_U, bool with_source = false) {
+  StageArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = h->field[in_f];
+  a.out = h->field[out_f];
+  a.aux = aux_f >= 0 ? h->field[aux_f] : nullptr;
+  a.uabs = h->field[uabs_f];
+  for (int s = 0; s < 6; ++s) {
+    a.ghost[s] = h->ghost[in_f][s];
+    // required for interior launches too: masked boundary lanes still form (and load through) the pointer
+    if (h->md.has_nbr[s] && !a.ghost[s])
+      return fail(h, SG_ERR_STATE, "stage needs a halo buffer that was not attached (sg_halo_attach)");
+  }
+  a.Dt = h->Dt;
+  a.Lt = h->Lt;
+  a.md = h->md_dev;
+  a.fragV = (kind == 0) ? h->fragF : h->fragG;
+  a.fragL = h->fragL;
+  a.sym = h->sym ? 1 : 0;
+  a.f32 = h->f32;
+  a.dbg = h->dbg ? h->dbg + 8 * (kind * 2 + (mode ? 1 : 0)) : nullptr;
+  a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
+  a.sponge_B = h->sponge_B;
+  a.lam = h->lam_d;
+  a.mu = h->mu_d;
+  a.lam0 = h->lam0;
+  a.mu0 = h->mu0;
+  a.per_cell = h->per_cell;
+  a.rho2 = (kind == 0 && mode == 1) ? h->rho2_d : nullptr;
+  a.mode = mode;
+  a.c_self = c_self;
+  a.c_aux = c_aux;
+  a.c_new = c_new;
+  if (with_source && h->src_fused && source_active(h)) {  // tile path: the G kernel adds this step's source values
+    a.src_slot = h->src_slot_d;
+    a.src_idx = h->src_idx_d;
+    a.src_vals = h->src_values + (size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz * h->cfg.dim * h->cfg.dim;
+  }
+  std::vector<Box> boxes;
+  region_boxes(h, region, boxes);
+  if (h->use_mfma || h->use_lane || h->use_tile) {
+    // one launch for the whole region: the kernels scan all cell groups and mask lanes by box
+    a.nbox = 0;
+    for (const Box& b : boxes) {
+      if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;
+      if (a.nbox >= SG_MAX_BOXES) return fail(h, SG_ERR_STATE, "region has more boxes than a launch can carry");
+      for (int k = 0; k < 3; ++k) {
+        a.boxes_o[a.nbox][k] = b.o[k];
+        a.boxes_n[a.nbox][k] = b.n[k];
+      }
+      a.nbox += 1;
+    }
+    if (a.nbox == 0) return SG_OK;
+    a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
+    // only launches that run while an exchange is in flight leave block slots to RCCL
+    a.grid_blocks = (region == SG_REGION_INTERIOR || region == SG_REGION_SECOND) ? h->grid_blocks : h->grid_full;
+    if (h->use_tile) a.grid_blocks = h->tile_grid;
+    a.item_list = nullptr;
+    a.nlist = 0;
+    if (region != SG_REGION_ALL) {
+      // Both regions of a split stage are static: list the (cell group, class) items that have
+      // an active cube once.  The interior launch then splits ACTIVE items evenly over the XCDs
+      // (a shell is whole z-layers of groups, i.e. the first items of XCD 0 and the last of XCD 7:
+      // skipping them inside an even split of all items would leave the launch as long as before);
+      // the shell launch deals its few items round-robin over all waves.
+      int32_t*& list = h->region_items[region];
+      int32_t& nlist = h->region_nitems[region];
+      if (nlist < 0) {
+        const int64_t gw = h->md.gw, ngroups = h->md.ncube_pad / gw;
+        std::vector<char> hit((size_t)ngroups, 0);
+        for (int bx = 0; bx < a.nbox; ++bx)
+          for (int ck = a.boxes_o[bx][2]; ck < a.boxes_o[bx][2] + a.boxes_n[bx][2]; ++ck)
+            for (int cj = a.boxes_o[bx][1]; cj < a.boxes_o[bx][1] + a.boxes_n[bx][1]; ++cj)
+              for (int ci = a.boxes_o[bx][0]; ci < a.boxes_o[bx][0] + a.boxes_n[bx][0]; ++ci) {
+                int64_t cube = ci + (int64_t)h->cfg.n[0] * (cj + (int64_t)h->cfg.n[1] * ck);
+                hit[(size_t)(cube / gw)] = 1;
+              }
+        std::vector<int32_t> items;
+        for (int64_t g = 0; g < ngroups; ++g)
+          if (hit[(size_t)g])
+            for (int k = 0; k < h->ncls; ++k) items.push_back((int32_t)(g * h->ncls + k));
+        nlist = (int32_t)items.size();
+        if (!items.empty()) {
+          HIPCHECK(h, hipMalloc((void**)&list, items.size() * sizeof(int32_t)));
+          HIPCHECK(h, hipMemcpy(list, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+      }
+      a.item_list = list;
+      a.nlist = nlist;
+    }
+    int rc = h->use_mfma   ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
+             : h->use_tile ? launch_stage_tile2d(kind, h->cfg.degree, a, h->t2c, (long)(h->md.ncube_pad / 16) * h->ncls, h->stream)
+                           : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
+    if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+    return SG_OK;
+  }
+  for (const Box& b : boxes) {
+    bool empty = false;
+    for (int k = 0; k < 3; ++k) {
+      a.box_o[k] = b.o[k];
+      a.box_n[k] = b.n[k];
+      empty = empty || (b.n[k] <= 0);
+    }
+    if (empty) continue;
+    int rc = launch_stage(kind, h->cfg.dim, h->cfg.degree, a, h->stream);
+    if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
+  }
+  return SG_OK;
+}
+
+// the source lives on single nodes: added to each part of a split stage right after the launch
+// that wrote it (INTERIOR + BOUNDARY: all of it after the second launch)
+static int add_source(sg_handle* h, int field, double coef, int region = SG_REGION_ALL) {
+  if (h->src_fused) return SG_OK;  // added by the stage kernel (run_op with_source)
+  if (h->src_nnz == 0 || (!h->src_static && h->src_step >= h->src_nsteps) || region == SG_REGION_INTERIOR) return SG_OK;
+  const int d = h->cfg.dim;
+  int64_t off = 0, cnt = h->src_nnz;
+  if (region == SG_REGION_FIRST) cnt = h->src_nfirst;
+  if (region == SG_REGION_SECOND) {
+    off = h->src_nfirst;
+    cnt = h->src_nnz - h->src_nfirst;
+  }
+  if (cnt == 0) return SG_OK;
+  const double* vals = h->src_values + ((size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz + off) * d * d;
+  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, h->f32, h->stream);
+  if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
+  return SG_OK;
+}
+
+static int run_stage_impl(sg_handle* h, int stage, int region) {
+  const double dt = h->dt, c3 = dt * dt * dt / 24.0;
+  int rc = SG_OK;
+  switch (stage) {
+    case SG_STAGE_UH1:
+      return run_op(h, 0, SG_FIELD_S, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
+    case SG_STAGE_STEMP:
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_SH, -1, 0, 0, 0, 0, region, SG_FIELD_U, true);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
+      return rc;
+    case SG_STAGE_U1:
+      // explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (elastic.py:341-345, :354-356);
+      // sg_set_density(physical = 1): u1 = u0 + (dt*uh1 + dt^3/24*uh2)/rho; per-cell density: factors in rho2
+      if (h->rho2_d) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt, c3, region);
+      if (h->rho_physical) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt / h->rho, c3 / h->rho, region);
+      return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, h->rho, dt, c3, region);
+    case SG_STAGE_SH1:
+      rc = run_op(h, 1, SG_FIELD_U, SG_FIELD_SH, -1, 0, 0, 0, 0, region, SG_FIELD_U, true);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
+      return rc;
+    case SG_STAGE_UTEMP:
+      return run_op(h, 0, SG_FIELD_SH, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
+    case SG_STAGE_S1:
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, SG_FIELD_SH, 1, 1.0, dt, c3, region, SG_FIELD_U, true);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_S, c3, region);
+      return rc;
+  }
+  return fail(h, SG_ERR_ARG, "unknown stage");
+}
+
+int resolve_timing(sg_handle* h) {
+  if (h->ev_stage_ids.empty()) return SG_OK;
+  if (int rc = join_second(h)) return rc;
+  HIPCHECK(h, sync_all(h));
+  for (size_t k = 0; k < h->ev_stage_ids.size(); ++k) {
+    float ms = 0;
+    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]));
+    if (h->ev_stage_ids[k] == 6)
+      h->counters.halo_pack_ms += ms;
+    else
+      h->counters.kernel_ms[h->ev_stage_ids[k]] += ms;
+  }
+  h->ev_stage_ids.clear();
+  return SG_OK;
+}
+
+extern "C" {
+
+int sg_run_stage(sg_handle* h, int stage, int region) {
+  if (!h) return SG_ERR_ARG;
+  if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
+  if (region < 0 || region > 4) return fail(h, SG_ERR_ARG, "unknown region");
+  if (stage < 0 || stage > 5) return fail(h, SG_ERR_ARG, "unknown stage");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  const bool second = h->overlap && region == SG_REGION_SECOND;
+  hipStream_t const main_stream = h->stream;
+  if (second) {
+    // depends on everything before this stage's FIRST (ev_stage), not on FIRST itself
+    HIPCHECK(h, hipStreamWaitEvent(h->stream2, h->ev_stage, 0));
+    h->stream = h->stream2;
+  } else {
+    if (int rc = join_second(h)) return rc;
+    if (h->overlap && region == SG_REGION_FIRST) HIPCHECK(h, hipEventRecord(h->ev_stage, h->stream));
+  }
+  size_t k = h->ev_stage_ids.size();
+  int rc = SG_OK;
+  if (h->timing) {
+    if (k >= 8192) {
+      h->stream = main_stream;
+      rc = resolve_timing(h);
+      if (rc != SG_OK) return rc;
+      if (second) h->stream = h->stream2;
+      k = 0;
+    }
+    while (rc == SG_OK && h->ev_pool.size() < 2 * k + 2) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventCreate failed");
+      else h->ev_pool.push_back(e);
+    }
+    if (rc == SG_OK && hipEventRecord(h->ev_pool[2 * k], h->stream) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
+  }
+  if (rc == SG_OK) rc = run_stage_impl(h, stage, region);
+  if (rc == SG_OK && h->timing) {
+    if (hipEventRecord(h->ev_pool[2 * k + 1], h->stream) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
+    else h->ev_stage_ids.push_back(stage);
+  }
+  if (second) {
+    if (rc == SG_OK && hipEventRecord(h->ev_second, h->stream2) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
+    h->second_pending = rc == SG_OK;
+    h->stream = main_stream;
+  }
+  if (rc != SG_OK) return rc;
+  h->counters.launches[stage] += 1;
+  return SG_OK;
+}
+
+int sg_end_step(sg_handle* h) {
+  if (!h) return SG_ERR_ARG;
+  h->src_step += 1;
+  h->counters.steps += 1;
+  return SG_OK;
+}
+
+// one LF4 step = six launches on the handle's stream (elastic.py:291-304)
+static int enqueue_step(sg_handle* h) {
+  for (int st = 0; st < 6; ++st) {
+    int rc = run_stage_impl(h, st, SG_REGION_ALL);
+    if (rc != SG_OK) return rc;
+  }
+  return SG_OK;
+}
+
+// capture `steps` steps into an executable graph; on any failure graphs are switched off for the handle
+static hipGraphExec_t capture_steps(sg_handle* h, int steps) {
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+  int rc = SG_OK;
+  for (int k = 0; k < steps && rc == SG_OK; ++k) rc = enqueue_step(h);
+  hipError_t e = hipStreamEndCapture(h->stream, &g);
+  if (rc == SG_OK && e == hipSuccess && g) {
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr;
+  }
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  return ge;
+}
+
+int sg_step(sg_handle* h, int64_t nsteps) {
+  if (!h || nsteps < 0) return SG_ERR_ARG;
+  if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
+  for (int s = 0; s < 6; ++s)
+    if (h->md.has_nbr[s]) return fail(h, SG_ERR_STATE, "sg_step on a block with neighbours: drive stages + halo from the host");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  int64_t k = 0;
+  // launch-bound blocks: replay captured graphs (no per-stage timing, no per-step source values)
+  const bool graphs = h->graph_ok && !h->timing && h->src_nnz == 0 && nsteps >= 2;
+  if (graphs && h->graph_epoch != h->epoch) {
+    if (h->graph1) (void)hipGraphExecDestroy(h->graph1);
+    if (h->graph8) (void)hipGraphExecDestroy(h->graph8);
+    h->graph1 = capture_steps(h, 1);
+    h->graph8 = h->graph1 ? capture_steps(h, 8) : nullptr;
+    h->graph_epoch = h->epoch;
+    if (!h->graph1 || !h->graph8) h->graph_ok = false;  // same kernels, launched one by one below
+  }
+  HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
+  if (graphs && h->graph_ok) {
+    for (; k + 8 <= nsteps; k += 8) HIPCHECK(h, hipGraphLaunch(h->graph8, h->stream));
+    for (; k < nsteps; ++k) HIPCHECK(h, hipGraphLaunch(h->graph1, h->stream));
+    for (int st = 0; st < 6; ++st) h->counters.launches[st] += nsteps;
+    h->counters.steps += nsteps;
+    h->src_step += nsteps;
+  }
+  for (; k < nsteps; ++k) {
+    for (int st = 0; st < 6; ++st) {
+      if (h->timing) {
+        int rc = sg_run_stage(h, st, SG_REGION_ALL);
+        if (rc != SG_OK) return rc;
+      } else {
+        int rc = run_stage_impl(h, st, SG_REGION_ALL);
+        if (rc != SG_OK) return rc;
+        h->counters.launches[st] += 1;
+      }
+    }
+    h->src_step += 1;
+    h->counters.steps += 1;
+  }
+  HIPCHECK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHECK(h, hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->last_ms = ms;
+  return SG_OK;
+}
+
+int sg_last_step_ms(sg_handle* h, double* ms) {
+  if (!h || !ms) return SG_ERR_ARG;
+  *ms = h->last_ms;
+  return SG_OK;
+}
+
+int sg_apply_F(sg_handle* h, int s_in, int u_abs, int u_out) {
+  if (!h) return SG_ERR_ARG;
+  if (!field_is_stress(s_in) || field_is_stress(u_out) || field_is_stress(u_abs) || u_abs == u_out)
+    return fail(h, SG_ERR_ARG, "sg_apply_F: s_in must be a stress field, u_abs/u_out distinct velocity fields");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return run_op(h, 0, s_in, u_out, -1, 0, 0, 0, 0, SG_REGION_ALL, u_abs);
+}
+
+int sg_apply_G(sg_handle* h, int u_in, int s_out, int use_source) {
+  if (!h) return SG_ERR_ARG;
+  if (field_is_stress(u_in) || !field_is_stress(s_out))
+    return fail(h, SG_ERR_ARG, "sg_apply_G: u_in must be a velocity field, s_out a stress field");
+  if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called first");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  int rc = run_op(h, 1, u_in, s_out, -1, 0, 0, 0, 0, SG_REGION_ALL, SG_FIELD_U, use_source != 0);
+  if (rc == SG_OK && use_source) rc = add_source(h, s_out, 1.0);
+  return rc;
+}
+
+// ---- halo ---------------------------------------------------------------------------------
+
+int sg_halo_bytes(const sg_handle* h, int field, int side, size_t* nbytes) {
+  if (!h || !nbytes || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
+  const int d = h->cfg.dim;
+  int axis = side >> 1;
+  size_t n2 = 1;
+  for (int a = 0; a < 3; ++a)
+    if (a != axis) n2 *= (size_t)h->cfg.n[a];
+  // dim components per facet node for every field: a stress trace travels as T_i,axis (kernels.hip pack_one)
+  *nbytes = n2 * h->md.halo_per_cube * h->re.nf * (size_t)d * (h->f32 ? sizeof(float) : sizeof(double));
+  (void)field;
+  return SG_OK;
+}
+
+// pack launches are timed like stage launches (event pairs resolved lazily; stage id 6 = halo pack)
+static int pack_begin(sg_handle* h, size_t& k) {
+  if (int rc = join_second(h)) return rc;
+  k = h->ev_stage_ids.size();
+  if (!h->timing) return SG_OK;
+  if (k >= 8192) {
+    int rc = resolve_timing(h);
+    if (rc != SG_OK) return rc;
+    k = 0;
+  }
+  while (h->ev_pool.size() < 2 * k + 2) {
+    hipEvent_t e;
+    HIPCHECK(h, hipEventCreate(&e));
+    h->ev_pool.push_back(e);
+  }
+  HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k], h->stream));
+  return SG_OK;
+}
+
+static int pack_end(sg_handle* h, size_t k, size_t nbytes) {
+  if (h->timing) {
+    HIPCHECK(h, hipEventRecord(h->ev_pool[2 * k + 1], h->stream));
+    h->ev_stage_ids.push_back(6);
+  }
+  h->counters.halo_pack_launches += 1;
+  h->counters.halo_bytes_packed += (int64_t)nbytes;
+  return SG_OK;
+}
+
+int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out) {
+  if (!h || !dev_out || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  const int d = h->cfg.dim;
+  int comps = field_is_stress(field) ? d * d : d;
+  void* out = dev_out;
+  size_t k = 0, nb = 0;
+  int rc = pack_begin(h, k);
+  if (rc != SG_OK) return rc;
+  rc = launch_pack(h->md_dev, h->md, h->field[field], comps, 1, &side, &out,
+                   (h->sym && field_is_stress(field)) ? 1 : 0, h->f32, h->stream);
+  if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
+  (void)sg_halo_bytes(h, field, side, &nb);
+  return pack_end(h, k, nb);
+}
+
+int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out) {
+  if (!h || !dev_out || field < 0 || field > 3) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  const int d = h->cfg.dim;
+  int comps = field_is_stress(field) ? d * d : d;
+  int sides[6], n = 0;
+  void* outs[6];
+  for (int s = 0; s < 2 * d; ++s)
+    if (dev_out[s]) {
+      sides[n] = s;
+      outs[n] = dev_out[s];
+      n += 1;
+    }
+  size_t k = 0, total = 0;
+  int rc = pack_begin(h, k);
+  if (rc != SG_OK) return rc;
+  rc = launch_pack(h->md_dev, h->md, h->field[field], comps, n, sides, outs,
+                   (h->sym && field_is_stress(field)) ? 1 : 0, h->f32, h->stream);
+  if (rc != 0) return fail(h, SG_ERR_DEVICE, "pack kernel launch failed");
+  for (int i = 0; i < n; ++i) {
+    size_t nb = 0;
+    (void)sg_halo_bytes(h, field, sides[i], &nb);
+    total += nb;
+  }
+  return pack_end(h, k, total);
+}
+
+// ---- instrumentation ----------------------------------------------------------------------------
+
+int sg_enable_timing(sg_handle* h, int on) {
+  if (!h) return SG_ERR_ARG;
+  if (!on) {
+    int rc = resolve_timing(h);
+    if (rc != SG_OK) return rc;
+  }
+  h->timing = on != 0;
+  return SG_OK;
+}
+
+int sg_get_counters(sg_handle* h, sg_counters_t* out) {
+  if (!h || !out) return SG_ERR_ARG;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  int rc = resolve_timing(h);
+  if (rc != SG_OK) return rc;
+  *out = h->counters;
+  return SG_OK;
+}
+
+int sg_region_boxes(const sg_config* cfg, int region, int32_t* boxes, int max_boxes) {
+  if (!cfg || !boxes || cfg->dim < 1 || cfg->dim > 3 || region < 0 || region > 4 || max_boxes < 0) return SG_ERR_ARG;
+  int32_t n[3] = {1, 1, 1}, has_nbr[6] = {0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < cfg->dim; ++a) n[a] = cfg->n[a];
+  for (int s2 = 0; s2 < 2 * cfg->dim; ++s2) has_nbr[s2] = (cfg->nbr_mask >> s2) & 1;
+  std::vector<Box> out;
+  region_boxes(cfg->dim, n, has_nbr, region, out);
+  int cnt = 0;
+  for (const Box& b : out) {
+    if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;
+    if (cnt < max_boxes)
+      for (int k = 0; k < 3; ++k) {
+        boxes[6 * cnt + k] = b.o[k];
+        boxes[6 * cnt + 3 + k] = b.n[k];
+      }
+    cnt += 1;
+  }
+  return cnt;
+}
+
+}  // extern "C"

@@ -300,7 +300,7 @@ def test_region_boxes_partition_the_block_for_every_neighbour_mask(dim, n):
     block sides with a neighbour, all six included (a 3x3x3 process grid's centre block): the boxes
     of a region are disjoint, INTERIOR + BOUNDARY = FIRST + SECOND = ALL, the shell is exactly the
     cubes with a neighbour across one of their faces, and no region needs more boxes than a stage
-    launch can carry (SG_MAX_REGION_BOXES; api.cpp refuses beyond that)."""
+    launch can carry (SG_MAX_REGION_BOXES; stages.cpp refuses beyond that)."""
     hdr = open(os.path.join(ROOT, "include", "seigen_hip.h")).read()
     max_boxes = int(re.search(r"#define SG_MAX_REGION_BOXES (\d+)", hdr).group(1))
     full = tuple(n) + (1,) * (3 - dim)
