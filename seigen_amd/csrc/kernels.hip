@@ -427,7 +427,8 @@ __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64
   if (idx >= nnz * ncomp) return;
   long k = idx / ncomp;
   int c = (int)(idx - k * ncomp);
-  field[offs[k] + (long)c * gw] += (T)(coef * values[idx]);
+  // a node may be listed more than once (its entries add up): atomic, the table is tiny
+  atomicAdd(&field[offs[k] + (long)c * gw], (T)(coef * values[idx]));
 }
 
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,

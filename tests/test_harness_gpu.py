@@ -300,6 +300,14 @@ def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
     _multiblock_case(dim, degree, n, grid, pipelined)
 
 
+@pytest.mark.parametrize("dim,degree,n,grid", [(3, 4, (4, 2, 4), (2, 1, 2)), (2, 3, (10, 9), (1, 3))])
+def test_multiblock_single_stream(gpu, monkeypatch, dim, degree, n, grid):
+    """SEIGEN_HIP_OVERLAP=0: both halves of a split stage on the main stream (the default launches the second
+    half on its own stream beside the first); same bitwise result."""
+    monkeypatch.setenv("SEIGEN_HIP_OVERLAP", "0")
+    _multiblock_case(dim, degree, n, grid, True, extras=True)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SEIGEN_TEST_RANDOM_CASES", "8"))))
 def test_multiblock_random_grids(gpu, seed):
     """Random block grids, x splits and one-cube-thin blocks included (the shell then covers the whole

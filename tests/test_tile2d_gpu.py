@@ -135,3 +135,38 @@ def test_tile_multiblock_equals_single_block(gpu, tile, degree, n, grid, pipelin
     sponge and a scattered source on top."""
     from tests.test_harness_gpu import _multiblock_case
     _multiblock_case(2, degree, n, grid, pipelined, extras=True)
+
+
+def test_tile_source_fused_equals_source_launch(gpu, monkeypatch):
+    """The source added inside the G stage kernels (default) against the same run with the source as a launch of
+    its own after every G stage (SEIGEN_HIP_SOURCE_LAUNCH=1): same nodes, same values, rounding-level agreement;
+    a node listed twice keeps the separate launch and adds both entries."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    monkeypatch.setenv("SEIGEN_HIP_PATH", "tile")
+    n, degree = (23, 7), 3
+    h = (1.0 / n[0], 1.0 / n[1])
+    res = {}
+    for mode in ("fused", "launch", "duplicate"):
+        if mode == "launch":
+            monkeypatch.setenv("SEIGEN_HIP_SOURCE_LAUNCH", "1")
+        else:
+            monkeypatch.delenv("SEIGEN_HIP_SOURCE_LAUNCH", raising=False)
+        blk = HipBlock(2, degree, n, h, (0.0, 0.0), "left")
+        r = np.random.default_rng(9)
+        blk.set_params(1.0, 0.05 * min(h) / degree ** 2, 0.5, 0.25)
+        nodes = np.unique(r.integers(0, blk.ncells * blk.nd, size=60))
+        sv = r.uniform(-1, 1, size=(4, len(nodes), 2, 2))
+        sv = 0.5 * (sv + np.swapaxes(sv, -1, -2))
+        if mode == "duplicate":      # every node twice with half the value: the same source
+            nodes = np.concatenate([nodes, nodes])
+            sv = np.concatenate([0.5 * sv, 0.5 * sv], axis=1)
+        blk.set_source(nodes, sv)
+        blk.set_field(_lib.FIELD_U, r.uniform(-1, 1, blk.field_shape(_lib.FIELD_U)))
+        blk.step(4)
+        res[mode] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    for mode in ("launch", "duplicate"):
+        assert rel_err(res[mode][0], res["fused"][0]) < 1e-13
+        assert rel_err(res[mode][1], res["fused"][1]) < 1e-13
+    assert np.abs(res["fused"][1]).max() > 0.1
