@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
+#include "mfma_tables.hpp"   // SG_T2_LARGE_FROM
 
 namespace sg {
 
@@ -39,7 +40,7 @@ struct TG : ElemDims<2, P> {
   static constexpr int KS = (ND + 3) / 4;    // k-steps over the element nodes
   static constexpr int KSF = (NF + 3) / 4;   // k-steps over the facet nodes
   static constexpr int S4 = (ND + 3) / 4;    // row-quads of the result
-  static constexpr bool LARGE = ND > 8;      // one 16-row tile (P3, P4) or S4 4-row tiles (P1, P2)
+  static constexpr bool LARGE = ND > SG_T2_LARGE_FROM;     // one 16-row tile (P3, P4) or S4 4-row tiles (P1, P2)
   static constexpr int RT = LARGE ? 1 : S4;  // A fragments per (operator, k-step)
   static constexpr int NFRAG_V = 2 * KS * RT;
   static constexpr int NFRAG_L = 3 * KSF * RT;

@@ -128,7 +128,7 @@ static inline int tile2d_row(bool large, int t, int l) { return large ? (l & 15)
 
 std::vector<double> tile2d_frags_V(const RefElem& re, double sign) {
   const int ks = (re.nd + 3) / 4, s4 = (re.nd + 3) / 4;
-  const bool large = re.nd > 8;
+  const bool large = re.nd > SG_T2_LARGE_FROM;
   const int rt = large ? 1 : s4;
   std::vector<double> out((size_t)2 * ks * rt * 64, 0.0);
   for (int r = 0; r < 2; ++r)
@@ -142,7 +142,7 @@ std::vector<double> tile2d_frags_V(const RefElem& re, double sign) {
 
 std::vector<double> tile2d_frags_L(const RefElem& re) {
   const int ksf = (re.nf + 3) / 4, s4 = (re.nd + 3) / 4;
-  const bool large = re.nd > 8;
+  const bool large = re.nd > SG_T2_LARGE_FROM;
   const int rt = large ? 1 : s4;
   std::vector<double> out((size_t)re.nfaces * ksf * rt * 64, 0.0);
   for (int f = 0; f < re.nfaces; ++f)

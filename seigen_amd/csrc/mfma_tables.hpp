@@ -21,6 +21,12 @@
 
 namespace sg {
 
+// 2-D tile kernels: elements with more nodes than this use one 16-row tile per k-step, the others 4-row tiles
+// (kernels_tile2d.hip, tile2d_frags_*)
+#ifndef SG_T2_LARGE_FROM
+#define SG_T2_LARGE_FROM 8
+#endif
+
 struct MfmaGeom {
   int nd, nf;
   int ks;    // k-steps over the element nodes  = ceil(nd / 4)
