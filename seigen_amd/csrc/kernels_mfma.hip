@@ -755,107 +755,132 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 
     SG_PRIO(SG_PRIO_HI);
     STAMP(st1);
-    // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
-    {
+    // Phase order by class parity (-DSG_PHASE_PARITY): the six Kuhn classes of a cube form a ring of intra-cube face
+    // neighbours 0-1-4-5-3-2-0, i.e. two sets {0, 3, 4} and {1, 2, 5} whose intra-cube neighbours all lie in the
+    // other set (cross-cube neighbours lie in the same one).  One set runs volume -> lifts, the other lifts -> volume:
+    // a wave then asks for its intra-cube neighbours' traces (half of all trace reads) while the waves that own those
+    // cells stream the same lines as their B rows, instead of half an item (~12 us, more than the 4 MiB L2 holds)
+    // later.  Same sums in a different order for the second set.
+    auto do_volume = [&]() {
+      // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
+      {
 #ifndef SG_PFV
 #define SG_PFV 1
 #endif
-      constexpr int PFV = sizeof(R) == 4 ? 2 : SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
-      R Tq[PFV][9];
+        constexpr int PFV = sizeof(R) == 4 ? 2 : SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
+        R Tq[PFV][9];
 #pragma unroll
-      for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
+        for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        R T[9];
+        for (int ks = 0; ks < KS; ++ks) {
+          R T[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) T[c] = Tq[ks % PFV][c];
-        if (ks + PFV < KS) {
-          load_tensor<SYM>(brow(ks + PFV), 16, Tq[ks % PFV]);
-        }
+          for (int c = 0; c < 9; ++c) T[c] = Tq[ks % PFV][c];
+          if (ks + PFV < KS) {
+            load_tensor<SYM>(brow(ks + PFV), 16, Tq[ks % PFV]);
+          }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          R Tt[3];
+          for (int r = 0; r < 3; ++r) {
+            R Tt[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
+            for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
 #pragma unroll
-          for (int t = 0; t < MTT; ++t) {
-            const R a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
+            for (int t = 0; t < MTT; ++t) {
+              const R a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              if (t < MTF)
-                acc[i][t < MTF ? t : 0] = MFMA64(a, Tt[i], acc[i][t < MTF ? t : 0]);
-              else
-                accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, Tt[i], accs[i][t < MTF ? 0 : t - MTF]);
+              for (int i = 0; i < 3; ++i) {
+                if (t < MTF)
+                  acc[i][t < MTF ? t : 0] = MFMA64(a, Tt[i], acc[i][t < MTF ? t : 0]);
+                else
+                  accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, Tt[i], accs[i][t < MTF ? 0 : t - MTF]);
+              }
             }
           }
         }
       }
-    }
 
-    STAMP(st2);
-    // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary
-    //      (elastic.py:206).  The own half of {T} is part of the volume tiles (E_r), so the lift
-    //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
-    //      cancels the folded half): wf * (c n).T of whatever np[f] points at, the 1/2 being part
-    //      of the lift tiles.
+    };
+    auto do_lifts = [&]() {
+      // ---- facet lifts of (c n)_j {T_ij}; no ds term in f => zero flux on the boundary
+      //      (elastic.py:206).  The own half of {T} is part of the volume tiles (E_r), so the lift
+      //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
+      //      cancels the folded half): wf * (c n).T of whatever np[f] points at, the 1/2 being part
+      //      of the lift tiles.
 #ifndef SG_PFLF
 #define SG_PFLF 2
 #endif
-    constexpr int PFL = sizeof(R) == 4 ? 3 : SG_PFLF;  // facet k-steps of neighbour traces in flight
-    const R* np[4];
-    R wf[4];
-    int noff[4][KSF];
-    bool gh[4];
-    int fax[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const NbrRef<R> NR = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
-      np[f] = NR.p;
-      gh[f] = GHOST && NR.ghost;
-      fax[f] = GHOST ? __builtin_amdgcn_readfirstlane(sMd.nb_axis[k][f]) : 0;
-      wf[f] = NR.physical ? R(-1) : R(1);
-#pragma unroll
-      for (int ks = 0; ks < KSF; ++ks) {
-        const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
-        const int on = sMd.fnode[f][bb];
-        const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
-        noff[f][ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
-      }
-    }
-    R nq[PFL][9];
-    {
-      constexpr int NS = 4 * KSF;
-#pragma unroll
-      for (int s = 0; s < PFL; ++s)
-        load_trace<SYM, GHOST>(np[s / KSF] + noff[s / KSF][s % KSF], gh[s / KSF], fax[s / KSF], nq[s]);
+      constexpr int PFL = sizeof(R) == 4 ? 3 : SG_PFLF;  // facet k-steps of neighbour traces in flight
+      const R* np[4];
+      R wf[4];
+      int noff[4][KSF];
+      bool gh[4];
+      int fax[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
+        const NbrRef<R> NR = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
+        np[f] = NR.p;
+        gh[f] = GHOST && NR.ghost;
+        fax[f] = GHOST ? __builtin_amdgcn_readfirstlane(sMd.nb_axis[k][f]) : 0;
+        wf[f] = NR.physical ? R(-1) : R(1);
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks) {
-          const int s = f * KSF + ks;
-          R fl[3];
+          const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
+          const int on = sMd.fnode[f][bb];
+          const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
+          noff[f][ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
+        }
+      }
+      R nq[PFL][9];
+      {
+        constexpr int NS = 4 * KSF;
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
-            fl[i] = wf[f] * (cnf[f][0] * nq[s % PFL][i * 3 + 0] + cnf[f][1] * nq[s % PFL][i * 3 + 1] +
-                             cnf[f][2] * nq[s % PFL][i * 3 + 2]);
-          if (s + PFL < NS) {
-            const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
-            load_trace<SYM, GHOST>(np[f1] + noff[f1][k1], gh[f1], fax[f1], nq[s % PFL]);
-          }
+        for (int s = 0; s < PFL; ++s)
+          load_trace<SYM, GHOST>(np[s / KSF] + noff[s / KSF][s % KSF], gh[s / KSF], fax[s / KSF], nq[s]);
 #pragma unroll
-          for (int t = 0; t < MTT; ++t) {
-            const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+        for (int f = 0; f < 4; ++f) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              if (t < MTF)
-                acc[i][t < MTF ? t : 0] = MFMA64(a, fl[i], acc[i][t < MTF ? t : 0]);
-              else
-                accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, fl[i], accs[i][t < MTF ? 0 : t - MTF]);
+          for (int ks = 0; ks < KSF; ++ks) {
+            const int s = f * KSF + ks;
+            R fl[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              fl[i] = wf[f] * (cnf[f][0] * nq[s % PFL][i * 3 + 0] + cnf[f][1] * nq[s % PFL][i * 3 + 1] +
+                               cnf[f][2] * nq[s % PFL][i * 3 + 2]);
+            if (s + PFL < NS) {
+              const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
+              load_trace<SYM, GHOST>(np[f1] + noff[f1][k1], gh[f1], fax[f1], nq[s % PFL]);
+            }
+#pragma unroll
+            for (int t = 0; t < MTT; ++t) {
+              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                if (t < MTF)
+                  acc[i][t < MTF ? t : 0] = MFMA64(a, fl[i], acc[i][t < MTF ? t : 0]);
+                else
+                  accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, fl[i], accs[i][t < MTF ? 0 : t - MTF]);
+              }
             }
           }
         }
       }
+
+    };
+#ifdef SG_PHASE_PARITY
+    if (__builtin_amdgcn_readfirstlane((k == 0 || k == 3 || k == 4) ? 1 : 0)) {
+      do_volume();
+      STAMP(st2);
+      do_lifts();
+    } else {
+      do_lifts();
+      STAMP(st2);
+      do_volume();
     }
+#else
+    do_volume();
+    STAMP(st2);
+    do_lifts();
+#endif
 
     SG_PRIO(0);
     STAMP(st3);
