@@ -32,8 +32,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X datasheet FP64 matrix peak (256 CUs x 128 flop/clk x 2.4 GHz)
 FP64_MFMA_SUSTAINED_TFLOPS = 52.4   # v_mfma_f64_16x16x4_f64 (the shape the kernels use) back to back, measured
-                                    # (tools/ubench_fp64_mix.hip, profiles/r01); the 4x4x4_4b shape sustains 74
-                                    # (tools/ubench_mfma_sustained.hip, profiles/r02/mfma_small_tiles_experiment.txt)
+                                    # (tools/ubench_fp64_mix.hip, profiles/r01).  Not a ceiling: a loop shaped like the
+                                    # kernels' volume phase sustains 62 with VGPR accumulators, the 4x4x4_4b shape 74
+                                    # alone (tools/ubench_mfma_insitu.hip, profiles/r02/mfma_small_tiles_experiment.txt)
 
 
 def eigenmode3d_fields(X, t_u, t_s):
