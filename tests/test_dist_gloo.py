@@ -201,3 +201,17 @@ def test_halo_exchange_world2(dim, n, degree, grid):
 def test_halo_exchange_world4_2d_grid():
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(4, _free_port(), 2, (4, 4), 1, (2, 2)), nprocs=4, join=True)
+
+
+def test_halo_exchange_world8_bench_grid():
+    """The 8-rank layout of `bench.py --gpus 8` (the driver's scaling run): the process grid that
+    mesh._factor_grid picks for a cubic weak-scaling mesh - x is never split (1 x 2 x 4), interior ranks have three
+    face neighbours - driven through the real exchanger with gloo point-to-point calls on eight CPU processes."""
+    import torch.multiprocessing as mp
+    from seigen_amd.mesh import _factor_grid
+    n = 64
+    grid = _factor_grid(8, 3, (n, n, n))
+    gn = tuple(n * g for g in grid)
+    assert _factor_grid(8, 3, gn) == grid == (1, 2, 4)          # what bench.py builds: Partition(gn, rank, 8, grid)
+    assert _factor_grid(2, 3, (n, n, n)) == (1, 1, 2) and _factor_grid(4, 3, (n, n, n)) == (1, 2, 2)
+    mp.spawn(_worker, args=(8, _free_port(), 3, (2, 4, 8), 1, grid), nprocs=8, join=True)
