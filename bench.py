@@ -89,8 +89,10 @@ def self_launch(ngpus):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    # the launcher's own parser abbreviates options even after the script name: "--n" would be "ambiguous" there
+    argv = ["--cubes" if a == "--n" else ("--cubes=" + a[4:] if a.startswith("--n=") else a) for a in sys.argv[1:]]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     for ln in proc.stdout.splitlines():
