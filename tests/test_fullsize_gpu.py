@@ -101,10 +101,10 @@ def test_config3_eigenmode_and_time_reversal_full_size(gpu):
 
 
 @pytest.mark.parametrize("dim,degree,n,steps", [
-    (2, 2, (512, 512), 6),        # BASELINE config 2's mesh and order (lane kernels)
-    (2, 3, (383, 121), 6),        # BASELINE config 5's mesh and order (generic kernels)
+    (2, 2, (512, 512), 6),        # BASELINE config 2's mesh and order (2-D MFMA tile kernels)
+    (2, 3, (383, 121), 6),        # BASELINE config 5's mesh and order (2-D MFMA tile kernels)
     (3, 3, (48, 40, 36), 3),      # MFMA P3, ragged sizes (layout padding in x)
-    (3, 2, (48, 48, 48), 3),      # 3-D lane kernels
+    (3, 2, (48, 48, 48), 3),      # 3-D P2 (MFMA kernels on 4-row tiles)
 ])
 def test_time_reversal_and_linear_reproduction(gpu, dim, degree, n, steps):
     from seigen_amd import _lib
@@ -144,3 +144,44 @@ def test_time_reversal_and_linear_reproduction(gpu, dim, degree, n, steps):
         ds = np.abs(blk.get_field_range(_lib.FIELD_S, c0, nc) - s0[c0:c0 + nc]).max()
         assert du < 1e-11 and ds < 1e-11, (c0, du, ds)
     blk.close()
+
+
+@pytest.mark.parametrize("config", ["c2", "c5"])
+def test_full_size_2d_workloads_tile_vs_generic(gpu, monkeypatch, config):
+    """BASELINE configs 2 and 5 as workloads at full size - 512 x 512 squares, P2, DG4 sponge and box-Ricker source
+    (tests/explosive_source/explosive_source_lf4.py:17-45); Marmousi 383 x 121, P3, per-cell lambda / mu and a Ricker
+    source - 20 LF4 steps on the production path (2-D MFMA tile kernels) against the independently written generic
+    kernel family (itself checked against the oracle at small sizes): every field, everywhere, to 1e-10."""
+    import importlib.util
+    import os
+    from seigen_amd import _lib
+    import seigen_amd.elastic
+    import seigen_amd.harness.explosive_source as hx
+    monkeypatch.setattr(seigen_amd.elastic, "log", lambda s: None)
+    monkeypatch.setattr(hx, "log", lambda s: None)
+    spec = importlib.util.spec_from_file_location(
+        "bench_configs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    steps, out = 20, {}
+
+    def capture(elastic, nsteps, warmup):                   # the workload builders of tools/bench_configs.py hand over here
+        elastic.setup()
+        blk = elastic.block
+        times = [elastic.dt * (k + 1) for k in range(nsteps)]
+        nodes, values, static = elastic._source_table(times)
+        assert len(nodes) > 0
+        blk.set_source(nodes, values, static=static)
+        blk.step(nsteps)
+        res = tuple(blk.get_field(f) for f in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH))
+        blk.close()
+        return dict(value=0.0, res=res)
+
+    monkeypatch.setattr(bc, "timed", capture)
+    for path in ("generic", "tile"):
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        out[path] = (bc.config2 if config == "c2" else bc.config5)(steps, 0)["res"]
+    assert np.isfinite(out["generic"][1]).all() and np.abs(out["generic"][1]).max() > 0
+    for a, b in zip(out["tile"], out["generic"]):
+        scale = max(np.abs(b).max(), 1e-300)
+        assert np.abs(a - b).max() / scale < 1e-10
