@@ -185,3 +185,36 @@ def test_full_size_2d_workloads_tile_vs_generic(gpu, monkeypatch, config):
     for a, b in zip(out["tile"], out["generic"]):
         scale = max(np.abs(b).max(), 1e-300)
         assert np.abs(a - b).max() / scale < 1e-10
+
+
+def test_config3_full_size_mfma_vs_generic(gpu, monkeypatch):
+    """BASELINE config 3 at full size (64^3 cubes x 6 tets, P4): three LF4 steps of the eigenmode on the production
+    path (MFMA kernels, interleaved layout, symmetric-stress storage) against the independently written generic
+    kernel family (host layout, full tensor), sampled over the whole block.  The state (u, s) must agree to 1e-11;
+    the stage fields left behind are derivatives of it - sh1 = G(u1), utemp = F(G(u1)) - and carry the operators'
+    round-off amplification, eps (P^2/h)^k with P^2/h ~ 1e3..1e4 here: 1e-9 and 1e-7 of their scale."""
+    _quiet()
+    import bench
+    from seigen_amd import ElasticLF4, BoxMesh, _lib
+    n, P, steps = 64, 4, 3
+    samples = {}
+    for path in ("generic", "mfma"):
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        mesh = BoxMesh(n, n, n, 1.0, 1.0, 1.0)
+        el = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False)
+        el.density, el.mu, el.l = 1.0, 0.25, 0.5
+        el.dt = 0.5 * (1.0 / n) / 2 ** (P - 1)
+        bench.fill_initial_condition(el, el.dt)
+        el.setup()
+        blk = el.block
+        blk.set_source([], None)
+        blk.step(steps)
+        samples[path] = [(f, c0, blk.get_field_range(f, c0, nc)) for f in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH)
+                         for c0, nc in _sample_ranges(blk.ncells, per=192, count=9)]
+        blk.close()
+        del el
+    tol = {_lib.FIELD_U: 1e-11, _lib.FIELD_S: 1e-11, _lib.FIELD_SH: 1e-9, _lib.FIELD_UH: 1e-7}
+    scale = {f: max(np.abs(b).max() for g, _, b in samples["generic"] if g == f) for f in tol}   # per field, over all samples
+    assert all(v > 1e-3 for v in scale.values()), scale
+    for (f, c0, a), (_, _, b) in zip(samples["mfma"], samples["generic"]):
+        assert np.abs(a - b).max() / scale[f] < tol[f], (f, c0, np.abs(a - b).max() / scale[f])
