@@ -218,3 +218,55 @@ def test_config3_full_size_mfma_vs_generic(gpu, monkeypatch):
     assert all(v > 1e-3 for v in scale.values()), scale
     for (f, c0, a), (_, _, b) in zip(samples["mfma"], samples["generic"]):
         assert np.abs(a - b).max() / scale[f] < tol[f], (f, c0, np.abs(a - b).max() / scale[f])
+
+
+def test_config4_share_full_size_properties(gpu):
+    """One rank's share of BASELINE config 4 (3-D 256^3 on 8 GPUs): a 128^3-cube block, P4, 12.6 M cells, 5.3 G DoF,
+    85 GB resident.  g of a linear velocity field = the constant Hooke stress everywhere (sampled), and exact time
+    reversal: two LF4 steps forward from (u linear, s = 0), two back, the linear field returns to round-off."""
+    import ctypes as C
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    n, P = 128, 4
+    h = (1.0 / n,) * 3
+    blk = HipBlock(3, P, (n, n, n), h, (0.0, 0.0, 0.0))
+    assert blk.ncells == 6 * n ** 3
+    lam, mu = 0.5, 0.25
+    dt = 0.25 * h[0] / P ** 2
+    blk.set_params(1.0, dt, lam, mu)
+    A = np.arange(1, 10, dtype=np.float64).reshape(3, 3) / 7.0 - 0.4
+    layer = n * n * 6
+    lib = _lib.load()
+
+    def layer_coords(k):          # node coordinates of the k-th z-layer of cubes (the library's own numbering)
+        cfg = _lib.SgConfig()
+        cfg.dim, cfg.degree = 3, P
+        for a in range(3):
+            cfg.n[a], cfg.h[a], cfg.origin[a] = n, h[a], 0.0
+        cfg.n[2] = 1
+        cfg.origin[2] = k * h[2]
+        X = np.empty((layer, blk.nd, 3))
+        _lib.check(lib.sg_block_node_coords(C.byref(cfg), P, X.ctypes.data, X.nbytes))
+        return X
+
+    u_of = lambda X: np.einsum("ij,cnj->cni", A, X) + 0.3
+    for k in range(n):
+        blk.set_field_range(_lib.FIELD_U, k * layer, u_of(layer_coords(k)))
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    hooke = lam * np.trace(A) * np.eye(3) + mu * (A + A.T)
+    for c0, nc in _sample_ranges(blk.ncells, per=192, count=9):
+        got = blk.get_field_range(_lib.FIELD_SH, c0, nc)
+        assert np.abs(got - hooke).max() < 1e-10 * n, (c0, np.abs(got - hooke).max())
+    _advance(blk, FORWARD, 2)
+    k_mid = n // 2
+    moved = np.abs(blk.get_field_range(_lib.FIELD_U, k_mid * layer, 192) - u_of(layer_coords(k_mid))[:192]).max()
+    assert moved > 1e-9, "the forward steps must change the state"
+    blk.set_params(1.0, -dt, lam, mu)
+    _advance(blk, BACKWARD, 2)
+    for k in (0, 37, k_mid, n - 1):
+        ref = u_of(layer_coords(k))
+        for c0 in (0, layer // 2, layer - 192):
+            du = np.abs(blk.get_field_range(_lib.FIELD_U, k * layer + c0, 192) - ref[c0:c0 + 192]).max()
+            ds = np.abs(blk.get_field_range(_lib.FIELD_S, k * layer + c0, 192)).max()
+            assert du < 1e-11 and ds < 1e-11, (k, c0, du, ds)
+    blk.close()
