@@ -143,11 +143,70 @@ def ricker(t, a=159.42, t0=0.3):
     return (-1.0 + 2 * a * (t - t0) ** 2) * math.exp(-a * (t - t0) ** 2)
 
 
+def _clip_halfplane(poly, p0, nrm):
+    """part of the convex polygon poly [n, 2] on the side (x - p0).nrm >= 0"""
+    out = []
+    s = (poly - p0) @ nrm
+    for i in range(len(poly)):
+        j = (i + 1) % len(poly)
+        if s[i] >= 0:
+            out.append(poly[i])
+        if (s[i] >= 0) != (s[j] >= 0):
+            out.append(poly[i] + (s[i] / (s[i] - s[j])) * (poly[j] - poly[i]))
+    return np.array(out).reshape(-1, 2)
+
+
+def project_box_indicator(mesh, P, lo, hi):
+    """L2 projection of the indicator of the box [lo, hi] onto scalar DG_P (2-D) [nc, nd]:
+    M_K^-1 int_{K n box} phi_a.  The box polygon is clipped by the three edge half-planes of every
+    triangle it can touch, fan-triangulated and integrated with a rule exact for P_k.  (Build-defined
+    source of the REF-C convergence study, not in the reference - see ExplosiveSource.source_mode.)"""
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    nd = refelem.nnodes(2, P)
+    out = np.zeros((mesh.ncells, nd))
+    X = mesh.vertices[mesh.cells]                              # [nc, 3, 2]
+    touch = np.nonzero((X[..., 0].max(1) > lo[0]) & (X[..., 0].min(1) < hi[0]) &
+                       (X[..., 1].max(1) > lo[1]) & (X[..., 1].min(1) < hi[1]))[0]
+    xq, wq = refelem.simplex_quadrature(2, P)
+    xm, wm = refelem.simplex_quadrature(2, 2 * P)
+    pm, _ = refelem.tabulate(2, P, xm)
+    Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))
+    box = np.array([[lo[0], lo[1]], [hi[0], lo[1]], [hi[0], hi[1]], [lo[0], hi[1]]])
+    for c in touch:
+        V = X[c]
+        ctr = V.mean(axis=0)
+        poly = box
+        for e in range(3):
+            a, b = V[e], V[(e + 1) % 3]
+            nrm = np.array([-(b - a)[1], (b - a)[0]])
+            if (ctr - a) @ nrm < 0:
+                nrm = -nrm
+            poly = _clip_halfplane(poly, a, nrm)
+            if len(poly) < 3:
+                break
+        if len(poly) < 3:
+            continue
+        b_a = np.zeros(nd)
+        for t in range(1, len(poly) - 1):
+            T = np.array([poly[0], poly[t], poly[t + 1]])
+            Jt = (T[1:] - T[0]).T
+            xp = T[0] + xq @ Jt.T
+            xi = np.einsum('mi,qi->qm', mesh.Jinv[c], xp - mesh.v0[c])
+            phi, _ = refelem.tabulate(2, P, xi)
+            b_a += abs(np.linalg.det(Jt)) * (wq @ phi)
+        out[c] = Minv @ b_a / abs(mesh.detJ[c])
+    return out
+
+
 class ExplosiveSource(object):
-    """explosive_source_lf4.py:12-56 on RectangleMesh(int(Lx/h), int(Ly/h), Lx, Ly)."""
+    """explosive_source_lf4.py:12-56 on RectangleMesh(int(Lx/h), int(Ly/h), Lx, Ly).
+
+    source_mode: 'interpolate' = the reference's nodal interpolation of the box indicator (:36-40);
+    'unit_integral' = that interpolant scaled to the box's area; 'project' = its L2 projection (area exact on
+    every mesh).  The last two are build-defined, for the REF-C convergence study."""
 
     def __init__(self, Lx=300.0, Ly=150.0, h=2.5, degree=2, diagonal="left",
-                 src=(45.0, None), sponge=20.0, sigma_degree=4):
+                 src=(45.0, None), sponge=20.0, sigma_degree=4, source_mode="interpolate"):
         nx, ny = int(Lx / h), int(Ly / h)
         self.Lx, self.Ly, self.h = Lx, Ly, h
         self.mesh = omesh.RectangleMesh(nx, ny, Lx, Ly, diagonal)         # :9-10
@@ -165,9 +224,18 @@ class ExplosiveSource(object):
         self.src_mask = ((X[..., 0] >= sx - 0.5) & (X[..., 0] <= sx + 0.5) &
                          (X[..., 1] >= sy - 0.5) & (X[..., 1] <= sy + 0.5))
         d = 2
+        scalar = self.src_mask.astype(np.float64)
+        ops = el.E.ops
+        if source_mode == "project":
+            scalar = project_box_indicator(self.mesh, degree, (sx - 0.5, sy - 0.5), (sx + 0.5, sy + 0.5))
+        elif source_mode == "unit_integral":
+            scalar = scalar / float((ops.M @ scalar.reshape(-1)).sum())
+        elif source_mode != "interpolate":
+            raise ValueError("source_mode")
+        self.source_integral = float((ops.M @ scalar.reshape(-1)).sum())
         pattern = np.zeros(X.shape[:-1] + (d, d))
-        pattern[self.src_mask, 0, 0] = 1.0
-        pattern[self.src_mask, 1, 1] = 1.0
+        pattern[..., 0, 0] = scalar
+        pattern[..., 1, 1] = scalar
         self.pattern = pattern
         el.source = lambda t: ricker(t) * pattern                          # :36-40, elastic.py:285-288
         # DG4 sponge                                                       :43-45

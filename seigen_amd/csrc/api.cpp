@@ -226,6 +226,8 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
     if (cfg->nbr_mask == 0) h->grid_full = h->grid_blocks;
+    h->order_chunk = 0;
+    if (const char* oc = std::getenv("SEIGEN_HIP_ORDER_CHUNK")) h->order_chunk = std::max(0, std::atoi(oc));
     // 251 blocks per XCD label: with an odd (prime) stride of 4 * 251 items a wave's items do not keep falling on
     // the same column of the mesh, e.g. on the sponge strips at both ends of every row (config 2: 0.240 -> 0.232 ms)
     h->tile_grid = 2008;

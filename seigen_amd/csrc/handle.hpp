@@ -91,6 +91,7 @@ struct sg_handle {
   hipEvent_t ev_stage = nullptr, ev_second = nullptr;
   bool second_pending = false;
   int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
+  int order_chunk = 0;  // MFMA path: items per XCD chunk of whole-block launches (StageArgs::order_chunk)
   int grid_full = 0;    // ... and otherwise (every block slot of the device)
   T2Const t2c;          // 2-D tile kernels: kernarg copy of the mesh tables
   int tile_grid = 0;    // 2-D tile kernels: cap of the grid in blocks of four waves (SEIGEN_HIP_TILE_GRID)

@@ -54,6 +54,10 @@ struct StageArgs {
   int32_t sym;                  // MFMA path: stress fields are symmetric, touch only the i <= j lines
   int32_t grid_blocks;          // MFMA path: size of the persistent grid (a multiple of 8)
   int32_t f32;                  // MFMA path: fields, halo buffers and operator tables are float (sg_config.dtype = 1)
+  // MFMA path, whole-block launches: items are dealt to the XCDs in chunks of this many consecutive items, round-robin
+  // (0: one contiguous eighth of the items per XCD).  With a chunk of 1/8 of a z-layer all XCDs sweep the block layer by
+  // layer together, so the z-neighbour traces and the own rows of the next layer meet in the Infinity Cache.
+  int32_t order_chunk;
   // 2-D tile path, G stages: the sparse nodal source (elastic.py:217-218) added inside the stage kernel instead of
   // by a launch of its own.  src_slot[item] = slot of an item (16 cells of one class) that holds source nodes, or -1;
   // src_idx[slot][node][cell] = row of that node in this step's value table src_vals[row][dim*dim], or -1.

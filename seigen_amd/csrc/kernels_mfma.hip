@@ -85,6 +85,23 @@ struct MG {
 #define SG_PRIO_HI 3
 #endif
 #define SG_PRIO(p) do { if (SG_PRIO_HI) __builtin_amdgcn_s_setprio(p); } while (0)
+// Issue priorities per phase, one hex digit each: 0xVLE = volume, lifts, epilogue; per kernel (F / G, plain / fused).
+// Unequal priorities in the two matrix phases keep the two waves of a SIMD from settling into the same phase.
+#ifndef SG_PRIO_F0
+#define SG_PRIO_F0 0x330
+#endif
+#ifndef SG_PRIO_F1
+#define SG_PRIO_F1 0x330
+#endif
+#ifndef SG_PRIO_G0
+#define SG_PRIO_G0 0x330
+#endif
+#ifndef SG_PRIO_G1
+#define SG_PRIO_G1 0x330
+#endif
+#define SG_PRIO_VOL ((PRIO3 >> 8) & 3)
+#define SG_PRIO_LIFT ((PRIO3 >> 4) & 3)
+#define SG_PRIO_EPI (PRIO3 & 3)
 #define MFMA64(a, b, c) RT<R>::big((a), (b), (c))
 #define MFMA4(a, b, c) RT<R>::small((a), (b), (c))
 
@@ -272,10 +289,14 @@ __device__ __forceinline__ NbrRef<R_> nbr_ref(const MeshDev& md, const StageArgs
 // label gets one contiguous range of items; a different placement only changes speed.
 struct ItemRange {
   long lo, hi, step;
+  long chunk, xcd, nitems;  // chunk > 0: `it` counts the XCD's own items; item_of() maps to the global item
 };
-__device__ __forceinline__ ItemRange item_range(long nitems, int wave, int spread) {
+__device__ __forceinline__ ItemRange item_range(long nitems, int wave, int spread, long chunk) {
+  ItemRange r;
+  r.chunk = 0;
+  r.xcd = 0;
+  r.nitems = nitems;
   if (spread) {  // boundary shells: round-robin over every wave of the grid (over the item list if given)
-    ItemRange r;
     r.lo = (long)blockIdx.x * 4 + wave;
     r.hi = nitems;
     r.step = (long)gridDim.x * 4;
@@ -285,12 +306,28 @@ __device__ __forceinline__ ItemRange item_range(long nitems, int wave, int sprea
   const long xcd = blockIdx.x % 8;
   const long slot = blockIdx.x / 8;
   const long blocks_here = (nblk - xcd + 7) / 8;
+  r.step = blocks_here * 4;
+  if (chunk > 0) {
+    // chunks xcd, xcd + 8, ... of `chunk` consecutive items each
+    const long nchunks = (nitems + chunk - 1) / chunk;
+    const long mine = (nchunks - xcd + 7) / 8;
+    r.chunk = chunk;
+    r.xcd = xcd;
+    r.lo = slot * 4 + wave;
+    r.hi = mine > 0 ? mine * chunk : 0;
+    return r;
+  }
   const long ipx = (nitems + 7) / 8;
-  ItemRange r;
   r.lo = xcd * ipx + slot * 4 + wave;
   r.hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
-  r.step = blocks_here * 4;
   return r;
+}
+// global item of loop index `it`, or -1 (past the end of the last chunk)
+__device__ __forceinline__ long item_of(const ItemRange& r, long it) {
+  if (r.chunk == 0) return it;
+  const long c = it / r.chunk;
+  const long item = (c * 8 + r.xcd) * r.chunk + (it - c * r.chunk);
+  return item < r.nitems ? item : -1;
 }
 
 // Operator tiles and mesh tables into LDS, once per block.  All of a thread's loads are issued
@@ -343,6 +380,7 @@ template <typename R, int P, int MODE, int SYM>
 __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
+  constexpr int PRIO3 = MODE ? SG_PRIO_G1 : SG_PRIO_G0;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
 #ifndef SG_PF
 #define SG_PF 4
@@ -367,12 +405,14 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
   R* __restrict__ out = reinterpret_cast<R*>(A.out);
   const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
   const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread);
+  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
 
   STAMP_DECL;
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
-    const long item = A.item_list ? (long)A.item_list[it] : it;
+    const long iti = item_of(ir, it);
+    if (iti < 0) continue;
+    const long item = A.item_list ? (long)A.item_list[iti] : iti;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
@@ -421,7 +461,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
         for (int i = 0; i < 3; ++i) dst[ks][i] = NR.p[(nn * 3 + i) * NR.cstride];
       }
     };
-    SG_PRIO(SG_PRIO_HI);
+    SG_PRIO(SG_PRIO_VOL);
     STAMP(st1);
     // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead.
     //      One pass over the k-steps per reference direction r with all row tiles of D_r live:
@@ -516,6 +556,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
     //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
     {
       request(0, nx[0]);
+      SG_PRIO(SG_PRIO_LIFT);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         R(&flf)[KSF][3] = nx[f & 1];
@@ -583,7 +624,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
       }
     }
 
-    SG_PRIO(0);
+    SG_PRIO(SG_PRIO_EPI);
     STAMP(st3);
     // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
     //      vmcnt counts loads and stores together and the two kinds complete out of order with
@@ -697,6 +738,7 @@ template <typename R, int P, int MODE, int SYM, int GHOST>
 __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
+  constexpr int PRIO3 = MODE ? SG_PRIO_F1 : SG_PRIO_F0;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
   __shared__ R sAV[M::NFRAG_F * 64];
   __shared__ R sAL[M::NFRAG_L * 64];
@@ -713,12 +755,14 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   R* __restrict__ out = reinterpret_cast<R*>(A.out);
   const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
   const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread);
+  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
 
   STAMP_DECL;
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
-    const long item = A.item_list ? (long)A.item_list[it] : it;
+    const long iti = item_of(ir, it);
+    if (iti < 0) continue;
+    const long item = A.item_list ? (long)A.item_list[iti] : iti;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
     const LaneGeo L = lane_geo(sMd, A, g, w);
@@ -753,7 +797,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       for (int t = 0; t < NSM; ++t) accs[i][t] = R(0);
     }
 
-    SG_PRIO(SG_PRIO_HI);
+    SG_PRIO(SG_PRIO_VOL);
     STAMP(st1);
     // Phase order by class parity (-DSG_PHASE_PARITY): the six Kuhn classes of a cube form a ring of intra-cube face
     // neighbours 0-1-4-5-3-2-0, i.e. two sets {0, 3, 4} and {1, 2, 5} whose intra-cube neighbours all lie in the
@@ -879,10 +923,11 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #else
     do_volume();
     STAMP(st2);
+    SG_PRIO(SG_PRIO_LIFT);
     do_lifts();
 #endif
 
-    SG_PRIO(0);
+    SG_PRIO(SG_PRIO_EPI);
     STAMP(st3);
     // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
     // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the

@@ -128,6 +128,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     if (h->use_tile) a.grid_blocks = h->tile_grid;
     a.item_list = nullptr;
     a.nlist = 0;
+    a.order_chunk = (h->use_mfma && !a.spread) ? h->order_chunk : 0;
     if (region != SG_REGION_ALL) {
       // Both regions of a split stage are static: list the (cell group, class) items that have
       // an active cube once.  The interior launch then splits ACTIVE items evenly over the XCDs

@@ -106,6 +106,12 @@ class ElasticLF4(object):
             self.absorption_function = None
             self.source_function = None
             self.source_expression = None
+            # Separable source S(x, t) = w(t) * source_function(x): when set (a callable t -> float),
+            # `source_function` holds the spatial pattern and is NOT re-interpolated from
+            # `source_expression`.  Build-defined (the reference only knows re-interpolated Expressions,
+            # elastic.py:285-288): lets a harness use a pattern that is not a nodal interpolant, e.g.
+            # the L2 projection of the source box (harness/explosive_source.py, source_mode).
+            self.source_time_function = None
             self.density = None
             # False: the explicit reference's update u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (only rhs(form_u1)
             # is kept, elastic.py:341-345, :354-356); True: u1 = u0 + (...)/rho, what the implicit form
@@ -262,6 +268,12 @@ class ElasticLF4(object):
         expr = self.source_expression
         nsteps = len(times)
         d = self.dimension
+        if self.source_time_function is not None:
+            vals = self.source_function.dat.data_cells
+            nz = np.nonzero(np.abs(vals).reshape(vals.shape[0] * vals.shape[1], -1).max(axis=1) > 0)[0]
+            v = vals.reshape(-1, d, d)[nz]
+            w = np.array([float(self.source_time_function(t)) for t in times])
+            return nz, w[:, None, None, None] * v[None], False
         if expr is None or not hasattr(expr, "_params") or "t" not in expr._params:
             vals = self.source_function.dat.data_cells
             nz = np.nonzero(np.abs(vals).reshape(vals.shape[0] * vals.shape[1], -1).max(axis=1) > 0)[0]
@@ -341,6 +353,7 @@ class ElasticLF4(object):
                     self._advance(len(times))
             self._block.sync()
             if self.source and self.source_expression is not None and times and \
+                    self.source_time_function is None and \
                     "t" in getattr(self.source_expression, "_params", {}):
                 self.source_expression.t = times[-1]
                 self.source = self.source_expression

@@ -282,3 +282,87 @@ def evaluate_at(function, point, cell_xi=None):
     else:
         vals = function._get()[cell]
     return np.tensordot(phi, vals, axes=(0, 0))
+
+
+def _clip_polygon(poly, axis, bound, keep_below):
+    """Sutherland-Hodgman: the part of the convex polygon `poly` [n, 2] with x[axis] <= bound
+    (keep_below) or >= bound."""
+    out = []
+    n = len(poly)
+    for i in range(n):
+        a, b = poly[i], poly[(i + 1) % n]
+        ia = (a[axis] <= bound) if keep_below else (a[axis] >= bound)
+        ib = (b[axis] <= bound) if keep_below else (b[axis] >= bound)
+        if ia:
+            out.append(a)
+        if ia != ib:
+            t = (bound - a[axis]) / (b[axis] - a[axis])
+            out.append(a + t * (b - a))
+    return np.array(out).reshape(-1, 2)
+
+
+def project_box_indicator(space, lo, hi):
+    """L2 projection onto the scalar DG space of the indicator function of the box [lo, hi] (2-D):
+    per cell K, coefficients M_K^-1 int_{K n box} phi_a dx, the integral taken exactly (the clipped
+    triangle is a convex polygon, fan-triangulated, collapsed Gauss-Jacobi rule of the basis degree).
+
+    Not part of the reference, whose harness interpolates the indicator NODALLY
+    (tests/explosive_source/explosive_source_lf4.py:36-40) - on a mesh coarser than the box the
+    interpolant's integral then depends on which nodes happen to fall inside.  The projection's
+    integral is the box area on every mesh: the source of the REF-C convergence study.
+    Returns [cells, nd]; the local block of this rank."""
+    from .norms import simplex_rule, tabulate
+    if space.dim != 2:
+        raise NotImplementedError("project_box_indicator: 2-D spaces")
+    mesh, P, nd = space.mesh, space.degree, space.nd
+    part = mesh.partition
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    xq, wq = simplex_rule(2, P)
+    xm, wm = simplex_rule(2, 2 * P)
+    pm = tabulate(2, P, xm)
+    Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))      # reference mass, unit |det J|
+    out = np.zeros((space.ncells, nd))
+    X = space.node_coords()
+    corner = [0, P, nd - 1]
+    rng = []
+    for a in range(2):
+        i0 = int(np.floor((lo[a] - mesh.origin[a]) / mesh.h[a])) - part.start[a]
+        i1 = int(np.floor((hi[a] - mesh.origin[a]) / mesh.h[a])) - part.start[a]
+        rng.append(range(max(i0, 0), min(i1, part.n[a] - 1) + 1))
+    for j in rng[1]:
+        for i in rng[0]:
+            for k in range(mesh.cells_per_block):
+                cell = (j * part.n[0] + i) * mesh.cells_per_block + k
+                V = X[cell, corner]
+                poly = V.copy()
+                for a in range(2):
+                    if len(poly):
+                        poly = _clip_polygon(poly, a, hi[a], True)
+                    if len(poly):
+                        poly = _clip_polygon(poly, a, lo[a], False)
+                if len(poly) < 3:
+                    continue
+                J = (V[1:] - V[0]).T
+                Jinv = np.linalg.inv(J)
+                b = np.zeros(nd)
+                for t in range(1, len(poly) - 1):
+                    T = np.array([poly[0], poly[t], poly[t + 1]])
+                    Jt = (T[1:] - T[0]).T
+                    area2 = abs(np.linalg.det(Jt))
+                    if area2 < 1e-300:
+                        continue
+                    xp = T[0] + xq @ Jt.T                              # physical quadrature points
+                    xi = (xp - V[0]) @ Jinv.T
+                    b += area2 * (wq @ tabulate(2, P, xi))
+                out[cell] = Minv @ b / abs(np.linalg.det(J))
+    return out
+
+
+def integral(function):
+    """int f dx of a DG Function, per value component (local block of this rank)."""
+    from .norms import simplex_rule, tabulate, _cell_volume_factor
+    space = function.function_space()
+    xq, wq = simplex_rule(space.dim, space.degree)
+    w = wq @ tabulate(space.dim, space.degree, xq)
+    v = function.dat.data_cells
+    return _cell_volume_factor(space.mesh) * np.tensordot(w, v.sum(axis=0), axes=(0, 0))

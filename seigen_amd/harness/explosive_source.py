@@ -10,7 +10,11 @@ class ExplosiveSourceLF4():
         return RectangleMesh(int(Lx/h), int(Ly/h), Lx, Ly)
 
     def setup(self, Lx=300.0, Ly=150.0, h=2.5, degree=2, solver="explicit", output=False,
-              courant_number=0.5, dt=None, source_x=45.0):
+              courant_number=0.5, dt=None, source_x=45.0, source_mode="interpolate", source_y=None):
+        """source_mode: 'interpolate' - the reference's nodal interpolation of the box indicator
+        (explosive_source_lf4.py:36-40; its integral depends on the mesh: 2.08 m^2 at h = 2.5, P2);
+        'unit_integral' - the same interpolant scaled so that its integral is the box's 1 m^2;
+        'project' - the L2 projection of the indicator (integral 1 m^2 on every mesh)."""
         with timed_region('mesh generation'):
             mesh = self.generate_mesh(Lx, Ly, h)
             self.elastic = ElasticLF4.create(mesh, "DG", degree, dimension=2,
@@ -35,13 +39,33 @@ class ExplosiveSourceLF4():
 
         # Source (explosive_source_lf4.py:35-40): Ricker wavelet in a 1 m box, 1 m below the surface
         a = 159.42
+        source_y = Ly - 1.0 if source_y is None else source_y
         box = "x[0] >= %r && x[0] <= %r && x[1] >= %r && x[1] <= %r" % (
-            source_x - 0.5, source_x + 0.5, Ly - 1.5, Ly - 0.5)
+            source_x - 0.5, source_x + 0.5, source_y - 0.5, source_y + 0.5)
         ricker = "(-1.0 + 2*a*pow(t - 0.3, 2))*exp(-a*pow(t - 0.3, 2))"
         code = "%s ? %s : 0.0" % (box, ricker)
         self.elastic.source_expression = Expression(((code, "0.0"), ("0.0", code)), a=a, t=0)
         self.elastic.source_function = Function(self.elastic.S)
         self.elastic.source = self.elastic.source_expression
+        if source_mode != "interpolate":
+            import math
+            import numpy as np
+            from seigen_amd.functionspace import integral, project_box_indicator
+            el = self.elastic
+            lo, hi = (source_x - 0.5, source_y - 0.5), (source_x + 0.5, source_y + 0.5)
+            scalar = Function(FunctionSpace(mesh, "DG", degree))
+            if source_mode == "project":
+                scalar.assign(project_box_indicator(scalar.function_space(), lo, hi))
+            elif source_mode == "unit_integral":
+                scalar.interpolate(Expression("%s ? 1.0 : 0.0" % box))
+                scalar.assign(scalar.dat.data_cells * ((hi[0] - lo[0]) * (hi[1] - lo[1]) / float(integral(scalar))))
+            else:
+                raise ValueError("source_mode must be 'interpolate', 'unit_integral' or 'project'")
+            self.source_integral = float(integral(scalar))
+            pattern = np.zeros(scalar.dat.data_cells.shape + (2, 2))
+            pattern[..., 0, 0] = pattern[..., 1, 1] = scalar.dat.data_cells
+            el.source_function.assign(pattern)
+            el.source_time_function = lambda t: (-1.0 + 2 * a * (t - 0.3) ** 2) * math.exp(-a * (t - 0.3) ** 2)
 
         # Absorption (explosive_source_lf4.py:42-45): DG4 sponge, 20 m wide, not on the free surface
         F = FunctionSpace(mesh, "DG", 4)

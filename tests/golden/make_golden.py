@@ -7,6 +7,15 @@ build container: `python tests/golden/make_golden.py`).
                           (data files of the reference's own test; `t ux uy`, uy.py:7-17 reads them)
   explosive_oracle.npz    the oracle's receiver traces for the explosive_source_lf4.py set-up
                           with dt = 0.001 (uy.py:25), T = 2.5
+  explosive_oracle_project.npz   the same with the unit-moment source (L2 projection of the source box,
+                          oracle.harness.ExplosiveSource(source_mode="project")): the h = 2.5, P2 row of the REF-C
+                          convergence study (tools/refc_convergence.py)
+  fullspace_oracle.npz    oracle traces of the explosive source moved into the interior (160 m x 100 m, h = 1.25, P3,
+                          dt = 0.0005, projected source), compared with the exact 2-D full-space solution
+                          (oracle/analytic.py) in tests/test_oracle_pins.py
+  refc_convergence_hip.npz  NOT made here: receiver traces of the HIP path for the REF-C convergence study, written
+                          by tools/refc_convergence.py on a GPU box (gpurun_out/refc_convergence.npz, 'project' rows
+                          and the reference's own 'interpolate' h = 2.5 P2 row)
   stage_vectors.npz       F / G / full-step outputs of the oracle for seeded inputs on tiny meshes
                           (numpy.random.default_rng(seed), uniform [-1, 1))
   eigenmode_errors.json   oracle error functionals of the eigenmode sweeps
@@ -40,6 +49,26 @@ def explosive():
     ex.elastic.dt = 0.001
     times, tr = ex.run(2.5)
     np.savez_compressed(os.path.join(HERE, "explosive_oracle.npz"), times=times[4::5], traces=tr[4::5])
+
+
+def explosive_project():
+    ex = harness.ExplosiveSource(source_mode="project")
+    ex.elastic.dt = 0.001
+    times, tr = ex.run(2.5)
+    np.savez_compressed(os.path.join(HERE, "explosive_oracle_project.npz"), times=times[4::5], traces=tr[4::5])
+
+
+FULLSPACE = dict(Lx=160.0, Ly=100.0, h=1.25, degree=3, src=(80.0, 55.0), dt=0.0005, T=0.75,
+                 receivers=((105.0, 55.0), (80.0, 30.0), (98.0, 73.0)))
+
+
+def fullspace():
+    c = FULLSPACE
+    ex = harness.ExplosiveSource(Lx=c["Lx"], Ly=c["Ly"], h=c["h"], degree=c["degree"], src=c["src"], source_mode="project")
+    ex.elastic.dt = c["dt"]
+    times, tr = ex.run(c["T"], receivers=c["receivers"])
+    np.savez_compressed(os.path.join(HERE, "fullspace_oracle.npz"), times=times[9::10], traces=tr[9::10],
+                        receivers=np.array(c["receivers"]), src=np.array(c["src"]), Vp=ex.Vp)
 
 
 STAGE_CASES = [
@@ -128,3 +157,7 @@ if __name__ == "__main__":
         eigenmode_errors()
     if "explosive" in what:
         explosive()
+    if "explosive_project" in what:
+        explosive_project()
+    if "fullspace" in what:
+        fullspace()

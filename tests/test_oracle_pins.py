@@ -200,52 +200,141 @@ def _lsq_ratio(ours, ref, w):
     return float(np.dot(ours[w], ref[w]) / np.dot(ref[w], ref[w]))
 
 
-def test_ref_c_traces():
-    """tests/explosive_source/REF-C1..3 (external code, compared by eye in uy.py:45-80) against
-    the oracle's run of explosive_source_lf4.py with dt = 0.001 (uy.py:25).
-      C1 (45, 149), inside the source cell: the direct pulse matches to a few per cent in
-         amplitude and 5 ms in time.
-      C2 (90, 149), C3 (140, 149): arrival times and wave forms match (correlation >= 0.97); the
-         least-squares amplitude ratio to the reference is the SAME at both (2.24 and 2.18) - so it
-         is no propagation effect (a 2-D/3-D spreading mismatch would grow like sqrt(r): 1.45x
-         from C2 to C3) - and equals, to 4-7 %, the integral of the nodally interpolated source:
-         the indicator of the 1 m x 1 m box of explosive_source_lf4.py:36-38 hits two DG2 nodes of
-         the 2.5 m mesh, whose basis functions integrate to 2 |K| / 3 = 2.083 m^2, not 1 m^2.
-         [upstream] the reference's own run interpolates the same way on the same mesh.
-         tools/refc_moment.py (profiles/r02/refc_moment.txt) repeats the run on the HIP path at
-         h = 2.5 and h = 1.25, where the integral drops to 0.52 m^2 and the far field to 0.78 of
-         REF-C: it follows the discretised source, not the mesh resolution.
-      Late-time differences at C2 are reflections off the abrupt sponge of explosive_source_lf4.py:45."""
+UY_WINDOWS = ((0.0, 1.0), (0.5, 1.5), (1.0, 2.5))       # the plot ranges of uy.py:52,65,78
+
+
+def _refc_metrics(tr, refs, times, comp=1, sign=-1.0):
+    """(least-squares amplitude ratio, correlation) per receiver of sign*u_comp against REF-C's column comp + 1"""
+    out = []
+    for i in range(3):
+        w = (times > UY_WINDOWS[i][0]) & (times < UY_WINDOWS[i][1] - 1e-9)
+        o, r = sign * tr[w, i, comp], refs[i][w, 1 + comp]
+        if not np.any(r):                       # REF-C1 holds no x-motion
+            out.append((float("nan"), float("nan")))
+            continue
+        out.append((float(np.dot(o, r) / np.dot(r, r)), float(np.corrcoef(o, r)[0, 1])))
+    return out
+
+
+def test_ref_c_with_the_reference_set_up_is_characterised_not_matched():
+    """tests/explosive_source/REF-C1..3 (external code, compared by eye in uy.py:45-80) against the oracle's
+    run of explosive_source_lf4.py as the reference sets it up (nodal interpolation of the source box, h = 2.5,
+    P2; dt = 0.001 of uy.py:25).  These numbers CHARACTERISE that run; they are not a match:
+
+      * wave forms and arrival times agree (correlation 0.97-0.99),
+      * amplitudes are C1 1.05, C2 2.24, C3 2.18 times REF-C - and all three scale with the integral of the
+        nodally interpolated source (2.083 m^2 on this mesh instead of the box's 1 m^2; 0.52 m^2 and ratios
+        0.27 / 0.79 / 0.78 on the h = 1.25 mesh): the near-1 value at C1 is an accident of this mesh (round 2
+        asserted it as a pin; it is none).
+
+    The mesh-independent comparison is test_ref_c_unit_moment_convergence below."""
     times, tr, refs = _load_traces()
     for r in refs:
         np.testing.assert_allclose(r[:, 0], times, atol=1e-9)
-    uy = [-tr[:, i, 1] for i in range(3)]           # uy.py:37-43 plots -uy
-    ry = [r[:, 2] for r in refs]
-    # C1: peak of the direct pulse
-    k, kr = uy[0].argmin(), ry[0].argmin()
-    assert abs(times[k] - times[kr]) <= 0.0051
-    assert abs(uy[0][k] / ry[0][kr] - 1.0) < 0.08
-    w = times < 0.6
-    assert np.corrcoef(uy[0][w], ry[0][w])[0, 1] > 0.99
-    assert np.linalg.norm(uy[0][w] - ry[0][w]) / np.linalg.norm(ry[0][w]) < 0.15
-    # C1 records no x-motion in the reference (source x-position); ours is small
-    assert np.abs(tr[w, 0, 0]).max() < 0.02 * np.abs(uy[0]).max()
+    m = _refc_metrics(tr, refs, times)
+    for (ratio, corr), want in zip(m, (1.046, 2.235, 2.175)):
+        assert abs(ratio / want - 1.0) < 0.01 and corr > 0.97, m
     # integral of the interpolated source per unit amplitude, from the oracle's own mass matrix
     ex = harness.ExplosiveSource()
-    ops = ex.elastic.E.ops
-    area = float((ops.M @ ex.pattern[..., 0, 0].reshape(-1)).sum())
-    assert abs(area - 2.0 * 2.5 ** 2 / 2.0 / 3.0) < 1e-12 and int(ex.src_mask.sum()) == 2
-    # C2 / C3: P + Rayleigh arrival windows (the plot ranges of uy.py:65,78)
-    w2 = (times > 0.5) & (times < 1.45)
-    w3 = (times > 1.0) & (times < 2.45)
-    assert np.corrcoef(uy[1][w2], ry[1][w2])[0, 1] > 0.97
-    assert np.corrcoef(uy[2][w3], ry[2][w3])[0, 1] > 0.97
-    a2, a3 = _lsq_ratio(uy[1], ry[1], w2), _lsq_ratio(uy[2], ry[2], w3)
-    assert abs(a3 / a2 - 1.0) < 0.05, "the amplitude ratio must not depend on the distance"
-    assert abs(a2 / area - 1.0) < 0.12 and abs(a3 / area - 1.0) < 0.12, (a2, a3, area)
-    assert abs(times[w3][np.abs(uy[2][w3]).argmax()] - times[w3][np.abs(ry[2][w3]).argmax()]) < 0.05
+    assert abs(ex.source_integral - 2.0 * 2.5 ** 2 / 2.0 / 3.0) < 1e-12 and int(ex.src_mask.sum()) == 2
+    # the same run on the h = 1.25 mesh (HIP path, tools/refc_convergence.py): the source integral drops to
+    # 0.52 m^2 and every receiver follows it - refinement makes the "match" at C1 four times worse
+    h = np.load(os.path.join(GOLD, "refc_convergence_hip.npz"))
+    m2 = _refc_metrics(h["interpolate_h1.25_P2"], refs, times)
+    assert abs(m2[0][0] / 0.266 - 1) < 0.02 and abs(m2[1][0] / 0.786 - 1) < 0.02 and abs(m2[2][0] / 0.779 - 1) < 0.02
+    # C1 records no x-motion in the reference (source x-position); ours is small
+    w = times < 0.6
+    assert np.abs(tr[w, 0, 0]).max() < 0.02 * np.abs(tr[:, 0, 1]).max()
     # quiet before the first arrival, as in the reference
-    assert np.abs(uy[2][times < 0.9]).max() < 1e-3 * np.abs(uy[2]).max()
+    assert np.abs(tr[times < 0.9, 2, 1]).max() < 1e-3 * np.abs(tr[:, 2, 1]).max()
+
+
+def test_ref_c_unit_moment_convergence():
+    """REF-C against a source of UNIT MOMENT on every mesh (the L2 projection of the source box; build-defined
+    `source_mode='project'`), h in {2.5, 1.25, 0.625} x P in {2, 3, 4} (tools/refc_convergence.py on the HIP
+    path, profiles/r03/refc_convergence.txt; the h = 2.5 / P2 row is also run by the oracle and must agree).
+
+    Result: REF-C is NOT reproduced in amplitude.  The far field is mesh-converged to 0.1 % and sits at
+    1.271 x REF-C2 and 1.260 x REF-C3 in uy (correlation 0.993), 0.50 x / 0.56 x in ux (correlation 0.75 / 0.85);
+    C1, inside the source box, stays at 0.46-0.49.  The same code reproduces the exact full-space solution to
+    0.4 % (test_fullspace_analytic_pin), so the factor belongs to REF-C's generator, whose set-up the reference
+    does not record (REF-C's horizontal-to-vertical ratio is that of receivers AT the free
+    surface, not 1 m below it)."""
+    refs = [np.loadtxt(os.path.join(GOLD, "ref_c%d.txt" % i)) for i in (1, 2, 3)]
+    times = refs[0][:, 0]
+    h = np.load(os.path.join(GOLD, "refc_convergence_hip.npz"))
+    # the oracle's own run of the coarsest row = the HIP path's
+    o = np.load(os.path.join(GOLD, "explosive_oracle_project.npz"))
+    np.testing.assert_allclose(o["times"], times, atol=1e-9)
+    assert np.abs(o["traces"] - h["project_h2.5_P2"]).max() < 1e-9 * np.abs(o["traces"]).max()
+    rows = {}
+    for hh in (2.5, 1.25, 0.625):
+        for P in (2, 3, 4):
+            rows[(hh, P)] = _refc_metrics(h["project_h%g_P%d" % (hh, P)], refs, times)
+    fine = [rows[k] for k in ((1.25, 3), (1.25, 4), (0.625, 2), (0.625, 3), (0.625, 4))]
+    for i, want in ((1, 1.2707), (2, 1.2596)):
+        vals = np.array([m[i][0] for m in fine])
+        assert vals.max() / vals.min() - 1.0 < 2e-3, vals            # mesh-converged
+        assert abs(vals.mean() / want - 1.0) < 0.05, vals            # ... to this, not to 1
+        assert min(m[i][1] for m in fine) > 0.99
+    # even the coarsest mesh is within 6 % of the converged far field once the source has the right moment
+    assert abs(rows[(2.5, 2)][1][0] / 1.2707 - 1.0) < 0.06 and abs(rows[(2.5, 2)][2][0] / 1.2596 - 1.0) < 0.08
+    # C1 sits inside the 1 m source box: it sees the projected indicator itself, which converges slowly
+    c1 = np.array([m[0][0] for m in fine])
+    assert 0.40 < c1.min() and c1.max() < 0.52
+    # horizontal component: half of REF-C's, poorly correlated - REF-C's receivers are not where uy.py probes
+    ux = _refc_metrics(h["project_h0.625_P4"], refs, times, comp=0, sign=1.0)
+    assert abs(ux[1][0] - 0.50) < 0.03 and abs(ux[2][0] - 0.56) < 0.03 and ux[1][1] < 0.8
+
+
+def test_fullspace_analytic_pin():
+    """Source normalisation and P-wave propagation against theory: the explosive source moved into the interior
+    of a 160 m x 100 m domain (h = 1.25, P3, projected unit-moment source), oracle traces (fixture
+    fullspace_oracle.npz, make_golden.py) against the exact 2-D full-space solution of an explosive line source
+    (oracle/analytic.py) before any reflection arrives.  Amplitude within 0.5 %, misfit 0.5 % at the receiver
+    inside a cell; a receiver ON a mesh line (where DG fields are two-valued and least accurate) 3 % / 7 %."""
+    from oracle.analytic import explosive_line_source_2d
+    d = np.load(os.path.join(GOLD, "fullspace_oracle.npz"))
+    t, tr, src, Vp = d["times"], d["traces"], d["src"], float(d["Vp"])
+    res = []
+    for i in (0, 2):
+        x, y = d["receivers"][i]
+        dx, dy = x - src[0], y - src[1]
+        r = float(np.hypot(dx, dy))
+        vr = explosive_line_source_2d(r, t, Vp)
+        ours = tr[:, i, 0] * dx / r + tr[:, i, 1] * dy / r
+        res.append((np.dot(ours, vr) / np.dot(vr, vr), np.linalg.norm(ours - vr) / np.linalg.norm(vr)))
+    assert abs(res[1][0] - 1.0) < 0.005 and res[1][1] < 0.006, res
+    assert abs(res[0][0] - 1.0) < 0.035 and res[0][1] < 0.08, res
+    # the fixture is current: first 20 steps live
+    from tests.golden.make_golden import FULLSPACE as c
+    ex = harness.ExplosiveSource(Lx=c["Lx"], Ly=c["Ly"], h=c["h"], degree=c["degree"], src=c["src"], source_mode="project")
+    ex.elastic.dt = c["dt"]
+    tl, live = ex.run(20 * c["dt"], receivers=c["receivers"])
+    np.testing.assert_allclose(tl[9::10], t[:2], atol=1e-12)
+    assert np.abs(live[9::10] - tr[:2]).max() <= 1e-9 * np.abs(tr[:2]).max() + 1e-300
+
+
+def test_source_box_projection():
+    """The two independent implementations of the projected source (oracle: box clipped by the triangle's edges;
+    product host code: triangle clipped by the box's edges) agree, integrate to the box area on every mesh, and
+    reproduce the indicator where the box is a union of cells."""
+    from seigen_amd import FunctionSpace, RectangleMesh
+    from seigen_amd.functionspace import Function, integral, project_box_indicator
+    for hh, P in ((2.5, 2), (1.25, 3), (2.5, 4)):
+        nx, ny = int(300 / hh), int(150 / hh)
+        V = FunctionSpace(RectangleMesh(nx, ny, 300.0, 150.0), "DG", P)
+        a = project_box_indicator(V, (44.5, 148.5), (45.5, 149.5))
+        b = harness.project_box_indicator(omesh.RectangleMesh(nx, ny, 300.0, 150.0), P, (44.5, 148.5), (45.5, 149.5))
+        assert np.abs(a - b).max() < 1e-12
+        f = Function(V)
+        f.assign(a)
+        assert abs(float(integral(f)) - 1.0) < 1e-12
+    V = FunctionSpace(RectangleMesh(4, 4, 4.0, 4.0), "DG", 2)
+    v = project_box_indicator(V, (1.0, 1.0), (3.0, 2.0))
+    X = V.node_coords().mean(axis=1)
+    inside = (X[:, 0] > 1) & (X[:, 0] < 3) & (X[:, 1] > 1) & (X[:, 1] < 2)
+    assert np.abs(v - inside[:, None]).max() < 1e-12
 
 
 def test_explosive_oracle_rerun_matches_fixture():
