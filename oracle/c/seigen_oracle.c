@@ -28,11 +28,30 @@ typedef struct {
   const double* L;       /* [face][a][b'] */
 } so_mesh;
 
+/* What the eigenmode set-up does not need (all optional, NULL / 0 = absent):
+ *   sponge   Minv int sigma phi_a phi_b of the cells that carry sigma, as dense blocks computed by the numpy
+ *            oracle's quadrature (elastic.py:207-208; explosive_source_lf4.py:43-45)
+ *   source   nodal values of the stress source on its support, per step (elastic.py:217-218, :285-288)
+ *   lam, mu  one value per cell (build-defined heterogeneous extension)
+ *   rho      one value per cell; physical = 0: u1 = rho u0 + ..., 1: u1 = u0 + (...)/rho */
+typedef struct {
+  const double* lam;         /* [cell] or NULL */
+  const double* mu;          /* [cell] or NULL */
+  const double* rho;         /* [cell] or NULL */
+  int rho_physical;
+  const long* sponge_slot;   /* [cell] -> block or -1, or NULL */
+  const double* sponge_B;    /* [block][a][b] */
+  long src_nnz;              /* source nodes */
+  const long* src_node;      /* [nnz] flat scalar node = cell * nd + a */
+  const double* src_val;     /* [step][nnz][dim*dim] */
+  long src_nsteps;           /* steps covered by src_val (no source afterwards) */
+} so_extra;
+
 #define MAXD 3
 #define MAXND 35
 #define MAXNF 15
 
-void so_apply_F(const so_mesh* m, const double* T, double* out) {
+void so_apply_F_ex(const so_mesh* m, const double* T, const double* u_abs, const so_extra* ex, double* out) {
   const int d = m->dim, nd = m->nd, nf = m->nf, nfaces = m->nfaces, nc = d * d;
 #pragma omp parallel for schedule(static)
   for (long c = 0; c < m->ncells; ++c) {
@@ -78,12 +97,23 @@ void so_apply_F(const so_mesh* m, const double* T, double* out) {
           for (int i = 0; i < d; ++i) acc[a][i] += Lf[bp] * fl[bp][i];
       }
     }
+    if (ex && ex->sponge_slot && u_abs && ex->sponge_slot[c] >= 0) { /* - Minv int sigma phi u_abs */
+      const double* B = ex->sponge_B + ex->sponge_slot[c] * nd * nd;
+      const double* ua = u_abs + c * nd * d;
+      for (int a = 0; a < nd; ++a)
+        for (int b = 0; b < nd; ++b)
+          for (int i = 0; i < d; ++i) acc[a][i] -= B[a * nd + b] * ua[b * d + i];
+    }
     for (int a = 0; a < nd; ++a)
       for (int i = 0; i < d; ++i) out[(c * nd + a) * d + i] = acc[a][i];
   }
 }
 
-void so_apply_G(const so_mesh* m, const double* u, double lam, double mu, double* out) {
+void so_apply_F(const so_mesh* m, const double* T, double* out) { so_apply_F_ex(m, T, 0, 0, out); }
+
+/* srcv: this step's source values [nnz][dim*dim] or NULL */
+void so_apply_G_ex(const so_mesh* m, const double* u, double lam0, double mu0, const so_extra* ex, const double* srcv,
+                   double* out) {
   const int d = m->dim, nd = m->nd, nf = m->nf, nfaces = m->nfaces, nc = d * d;
 #pragma omp parallel for schedule(static)
   for (long c = 0; c < m->ncells; ++c) {
@@ -126,6 +156,7 @@ void so_apply_G(const so_mesh* m, const double* u, double lam, double mu, double
           for (int k = 0; k < d; ++k) W[a][i][k] += cnf[k] * lu[i];
       }
     }
+    const double lam = (ex && ex->lam) ? ex->lam[c] : lam0, mu = (ex && ex->mu) ? ex->mu[c] : mu0;
     for (int a = 0; a < nd; ++a) {
       double tr = 0;
       for (int k = 0; k < d; ++k) tr += W[a][k][k];
@@ -134,6 +165,13 @@ void so_apply_G(const so_mesh* m, const double* u, double lam, double mu, double
           out[(c * nd + a) * nc + i * d + j] = mu * (W[a][i][j] + W[a][j][i]) + (i == j ? lam * tr : 0.0);
     }
   }
+  if (ex && srcv) /* Minv int phi S = S nodally: the source lives in the same space (elastic.py:217-218) */
+    for (long z = 0; z < ex->src_nnz; ++z)
+      for (int ij = 0; ij < nc; ++ij) out[ex->src_node[z] * nc + ij] += srcv[z * nc + ij];
+}
+
+void so_apply_G(const so_mesh* m, const double* u, double lam, double mu, double* out) {
+  so_apply_G_ex(m, u, lam, mu, 0, 0, out);
 }
 
 static void axpy3(long n, double* y, double a, const double* x0, double b, const double* x1, double c, const double* x2) {
@@ -156,6 +194,37 @@ void so_step(const so_mesh* m, double* u, double* s, double* uh, double* sh, dou
     so_apply_F(m, sh, uh);                /* utemp :301 */
     so_apply_G(m, uh, lam, mu, s2);       /* sh2   :302 */
     axpy3(ns, s, 1.0, s, dt, sh, c3, s2); /* s1    :303-304, :348-352 */
+  }
+}
+
+/* The same with sponge, source and per-cell material / density.  step0 = index of the first step in
+ * ex->src_val.  u_abs of the two f applications of the velocity update is u0, of utemp it is u1
+ * (elastic.py:157-160, :169-172, :187-190). */
+void so_step_ex(const so_mesh* m, const so_extra* ex, double* u, double* s, double* uh, double* sh, double* u2, double* s2,
+                double rho0, double dt, double lam, double mu, long step0, int nsteps) {
+  const long nu = m->ncells * m->nd * m->dim, ns = nu * m->dim, per = (long)m->nd * m->dim;
+  const double c3 = dt * dt * dt / 24.0;
+  for (int k = 0; k < nsteps; ++k) {
+    const double* sv = (ex && ex->src_nnz > 0 && step0 + k < ex->src_nsteps)
+                           ? ex->src_val + (step0 + k) * ex->src_nnz * m->dim * m->dim : 0;
+    so_apply_F_ex(m, s, u, ex, uh);             /* uh1 */
+    so_apply_G_ex(m, uh, lam, mu, ex, sv, sh);  /* stemp */
+    so_apply_F_ex(m, sh, u, ex, u2);            /* uh2 */
+    if (ex && ex->rho) {
+#pragma omp parallel for schedule(static)
+      for (long i = 0; i < nu; ++i) {
+        const double r = ex->rho[i / per];
+        u[i] = ex->rho_physical ? u[i] + (dt * uh[i] + c3 * u2[i]) / r : r * u[i] + dt * uh[i] + c3 * u2[i];
+      }
+    } else if (ex && ex->rho_physical) {
+      axpy3(nu, u, 1.0, u, dt / rho0, uh, c3 / rho0, u2);
+    } else {
+      axpy3(nu, u, rho0, u, dt, uh, c3, u2);
+    }
+    so_apply_G_ex(m, u, lam, mu, ex, sv, sh);   /* sh1 */
+    so_apply_F_ex(m, sh, u, ex, uh);            /* utemp */
+    so_apply_G_ex(m, uh, lam, mu, ex, sv, s2);  /* sh2 */
+    axpy3(ns, s, 1.0, s, dt, sh, c3, s2);
   }
 }
 

@@ -51,6 +51,33 @@ def reference_operators(dim, P):
     return D, L, fnode
 
 
+def sponge_blocks(mesh, P, sigma_nodes, sigma_degree):
+    """(slot [nc] -> block or -1, B [nblocks, nd, nd]) with B = M_K^-1 int sigma phi_a phi_b dx for the cells
+    where the DG_q field sigma (nodal values [nc, nd_q]) is not identically zero: the blocks of
+    oracle.forms.ScalarOperators.absorption_matrix (elastic.py:207-208), built for those cells only so that
+    full-size meshes need no global sparse operators."""
+    d = mesh.dim
+    sig = np.asarray(sigma_nodes, dtype=np.float64).reshape(mesh.ncells, -1)
+    cells = np.nonzero(np.abs(sig).max(axis=1) > 0)[0]
+    slot = -np.ones(mesh.ncells, dtype=np.int64)
+    slot[cells] = np.arange(len(cells))
+    xq, wq = refelem.simplex_quadrature(d, 2 * P + sigma_degree)
+    phi, _ = refelem.tabulate(d, P, xq)
+    psi, _ = refelem.tabulate(d, sigma_degree, xq)
+    xm, wm = refelem.simplex_quadrature(d, 2 * P)
+    pm, _ = refelem.tabulate(d, P, xm)
+    Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))          # |det J| cancels against the integral's
+    sig_q = np.einsum('qc,nc->nq', psi, sig[cells])
+    loc = np.einsum('q,nq,qa,qb->nab', wq, sig_q, phi, phi)
+    return slot, np.einsum('ab,nbc->nac', Minv, loc)
+
+
+class SoExtra(C.Structure):
+    _fields_ = [("lam", C.c_void_p), ("mu", C.c_void_p), ("rho", C.c_void_p), ("rho_physical", C.c_int),
+                ("sponge_slot", C.c_void_p), ("sponge_B", C.c_void_p), ("src_nnz", C.c_long), ("src_node", C.c_void_p),
+                ("src_val", C.c_void_p), ("src_nsteps", C.c_long)]
+
+
 class CPort(object):
     def __init__(self, mesh, P):
         self.lib = C.CDLL(build())
@@ -63,15 +90,20 @@ class CPort(object):
         X = mesh.node_coords(P)
         nbr = -np.ones((nc, nfaces), dtype=np.int64)
         nbr_node = np.zeros((nc, nfaces, nf), dtype=np.int32)
-        for (c1, f1, c2, f2) in mesh.interior_facets:
-            for (ca, fa, cb, fb) in ((c1, f1, c2, f2), (c2, f2, c1, f1)):
-                nbr[ca, fa] = cb
-                Xa = X[ca, fnode[fa]]
-                Xb = X[cb, fnode[fb]]
-                dist = np.abs(Xa[:, None, :] - Xb[None, :, :]).max(axis=2)
-                j = dist.argmin(axis=1)
-                assert dist[np.arange(nf), j].max() < 1e-10
-                nbr_node[ca, fa] = fnode[fb][j]
+        IF = mesh.interior_facets
+        for (A, FA, B, FB) in ((0, 1, 2, 3), (2, 3, 0, 1)):          # both sides of every interior facet
+            nbr[IF[:, A], IF[:, FA]] = IF[:, B]
+            for fa in range(nfaces):
+                for fb in range(nfaces):
+                    sel = np.nonzero((IF[:, FA] == fa) & (IF[:, FB] == fb))[0]
+                    for lo in range(0, len(sel), 1 << 16):           # bounded temporaries
+                        k = sel[lo:lo + (1 << 16)]
+                        Xa = X[IF[k, A]][:, fnode[fa]]               # [n, nf, d]
+                        Xb = X[IF[k, B]][:, fnode[fb]]
+                        dist = np.abs(Xa[:, :, None, :] - Xb[:, None, :, :]).max(axis=3)
+                        j = dist.argmin(axis=2)
+                        assert np.take_along_axis(dist, j[:, :, None], axis=2).max() < 1e-10
+                        nbr_node[IF[k, A], fa] = fnode[fb][j]
         cn = np.zeros((nc, nfaces, d))
         cells = np.arange(nc)
         for f in range(nfaces):
@@ -82,6 +114,62 @@ class CPort(object):
         m.dim, m.nd, m.nf, m.nfaces, m.ncells = d, nd, nf, nfaces, nc
         (m.Jinv, m.cn, m.nbr, m.nbr_node, m.fnode, m.D, m.L) = [a.ctypes.data for a in self._keep]
         self.m = m
+
+        self.extra = None
+
+    def set_extra(self, lam=None, mu=None, rho=None, rho_physical=False, absorb=None, src_nodes=None, src_values=None,
+                  sponge=None):
+        """Optional ingredients of so_step_ex.  lam, mu, rho: one value per cell; absorb: the numpy oracle's
+        block-diagonal Minv int sigma phi phi (ElasticOperators.absorb, scipy sparse) - its non-zero cell blocks
+        are handed over densely (or sponge = (slot, B) from sponge_blocks); src_nodes [nnz] flat scalar nodes, src_values [nsteps, nnz, d, d]."""
+        ex = SoExtra()
+        keep = []
+
+        def arr(a, dt=np.float64):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        nc, nd = self.mesh.ncells, self.nd
+        if lam is not None:
+            ex.lam = arr(np.broadcast_to(np.asarray(lam, dtype=np.float64).ravel(), (nc,)))
+        if mu is not None:
+            ex.mu = arr(np.broadcast_to(np.asarray(mu, dtype=np.float64).ravel(), (nc,)))
+        if rho is not None:
+            ex.rho = arr(np.broadcast_to(np.asarray(rho, dtype=np.float64).ravel(), (nc,)))
+        ex.rho_physical = int(bool(rho_physical))
+        if absorb is not None:
+            A = absorb.tocsr()
+            rows = np.nonzero(np.diff(A.indptr))[0]
+            cells = np.unique(rows // nd)
+            slot = -np.ones(nc, dtype=np.int64)
+            slot[cells] = np.arange(len(cells))
+            B = np.zeros((len(cells), nd, nd))
+            coo = A.tocoo()
+            assert (coo.row // nd == coo.col // nd).all()
+            B[slot[coo.row // nd], coo.row % nd, coo.col % nd] = coo.data
+            ex.sponge_slot, ex.sponge_B = arr(slot, np.int64), arr(B)
+        if sponge is not None:
+            ex.sponge_slot, ex.sponge_B = arr(sponge[0], np.int64), arr(sponge[1])
+        if src_nodes is not None and len(src_nodes):
+            src_values = np.asarray(src_values, dtype=np.float64).reshape(-1, len(src_nodes), self.dim * self.dim)
+            ex.src_nnz, ex.src_nsteps = len(src_nodes), src_values.shape[0]
+            ex.src_node, ex.src_val = arr(src_nodes, np.int64), arr(src_values)
+        self._keep_extra = keep
+        self.extra = ex
+
+    def step_ex(self, u, s, rho, dt, lam, mu, nsteps, step0=0, inplace=False):
+        """nsteps LF4 steps with everything set by set_extra (scalars lam / mu / rho where no array was given)."""
+        if not inplace:
+            u = np.ascontiguousarray(u, dtype=np.float64).copy()
+            s = np.ascontiguousarray(s, dtype=np.float64).copy()
+        w = [np.empty_like(u), np.empty_like(s), np.empty_like(u), np.empty_like(s)]
+        self.work = w          # after the call: w[0] = utemp, w[1] = sh1 of the last step (the product's UH / SH buffers)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        ex = C.byref(self.extra) if self.extra is not None else None
+        self.lib.so_step_ex(C.byref(self.m), ex, p(u), p(s), p(w[0]), p(w[1]), p(w[2]), p(w[3]), C.c_double(rho),
+                            C.c_double(dt), C.c_double(lam), C.c_double(mu), C.c_long(step0), C.c_int(nsteps))
+        return u, s
 
     def threads(self):
         return int(self.lib.so_max_threads())

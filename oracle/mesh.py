@@ -70,23 +70,27 @@ class Mesh(object):
         self.Jinv = np.linalg.inv(self.J)          # [nc, m, i] = d xi_m / d x_i
 
     def _facets(self):
+        """Interior facets (c1, f1, c2, f2) and exterior facets (c, f), found by matching the sorted vertex
+        ids of every (cell, local face); listed in the order of the sorted vertex tuples, the two sides of an
+        interior facet in ascending (cell, face) order."""
         d = self.dim
-        table = {}
-        for c in range(self.ncells):
-            for f in range(d + 1):
-                key = tuple(sorted(int(self.cells[c, v]) for v in refelem.face_vertices(d, f)))
-                table.setdefault(key, []).append((c, f))
-        interior, exterior = [], []
-        for key in sorted(table):
-            ent = table[key]
-            if len(ent) == 2:
-                interior.append((ent[0][0], ent[0][1], ent[1][0], ent[1][1]))
-            elif len(ent) == 1:
-                exterior.append(ent[0])
-            else:
-                raise RuntimeError("non-manifold facet")
-        self.interior_facets = np.array(interior, dtype=np.int64).reshape(-1, 4)
-        self.exterior_facets = np.array(exterior, dtype=np.int64).reshape(-1, 2)
+        nc = self.ncells
+        fv = np.array([refelem.face_vertices(d, f) for f in range(d + 1)], dtype=np.int64).reshape(d + 1, -1)
+        keys = np.sort(self.cells[:, fv], axis=2).reshape(nc * (d + 1), -1)      # rows in (cell, face) order
+        order = np.lexsort(keys.T[::-1])                                          # stable: ties keep (cell, face) order
+        ks = keys[order]
+        same = np.zeros(len(order), dtype=bool)
+        same[:-1] = (ks[1:] == ks[:-1]).all(axis=1)                               # entry i and i + 1 share a facet
+        if (same[:-1] & same[1:]).any():
+            raise RuntimeError("non-manifold facet")
+        first = np.nonzero(same)[0]
+        paired = np.zeros(len(order), dtype=bool)
+        paired[first] = True
+        paired[first + 1] = True
+        a, b = order[first], order[first + 1]
+        self.interior_facets = np.stack([a // (d + 1), a % (d + 1), b // (d + 1), b % (d + 1)], axis=1).astype(np.int64).reshape(-1, 4)
+        e = order[~paired]
+        self.exterior_facets = np.stack([e // (d + 1), e % (d + 1)], axis=1).astype(np.int64).reshape(-1, 2)
 
     def facet_geometry(self, cell, f):
         """Outward unit normal and measure of local face f of the given cells
@@ -148,13 +152,12 @@ def structured(dim, n, L, diagonal="left", origin=None):
     for a in range(dim):
         # multiply before divide, as a plain "i*L/n" lattice
         vertices[ids, a] = origin[a] + grids[a].ravel() * (L[a] / n[a])
-    cells = []
-    # cube order: x fastest
-    ranges = [range(k) for k in reversed(n)]
-    for rev in itertools.product(*ranges):
-        idx = tuple(reversed(rev))
-        for cl in classes:
-            cells.append([sum((idx[a] + off[a]) * strides[a] for a in range(dim)) for off in cl])
+    # cube order: x fastest; cell = cube * ncls + class
+    cube = np.stack(np.meshgrid(*[np.arange(k) for k in n], indexing='ij'), axis=-1)        # [n0, .., dim]
+    cube = np.transpose(cube, tuple(reversed(range(dim))) + (dim,)).reshape(-1, dim)        # x fastest
+    off = np.array(classes, dtype=np.int64)                                                 # [ncls, dim+1, dim]
+    st = np.array(strides, dtype=np.int64)
+    cells = ((cube[:, None, None, :] + off[None]) * st).sum(axis=-1).reshape(-1, dim + 1)
     return Mesh(vertices, cells)
 
 

@@ -86,18 +86,22 @@ struct MG {
 #endif
 #define SG_PRIO(p) do { if (SG_PRIO_HI) __builtin_amdgcn_s_setprio(p); } while (0)
 // Issue priorities per phase, one hex digit each: 0xVLE = volume, lifts, epilogue; per kernel (F / G, plain / fused).
-// Unequal priorities in the two matrix phases keep the two waves of a SIMD from settling into the same phase.
+// The lift phase is the one that waits for memory (neighbour traces) and has little matrix work per load; the volume
+// phase has matrix work in abundance.  With the lifts ABOVE the volume a wave in its lifts gets its few matrix
+// instructions issued the moment their operands arrive and the SIMD's other wave fills the gaps from its volume
+// phase, instead of both waves queueing at equal priority: round 2's 0x330 -> 0x120 / 0x230 is 2-4 % on the step
+// (profiles/r03/priority_sweep.txt: plain stages 1.22-1.28 -> 1.17-1.20 ms; the fused G stage does not care).
 #ifndef SG_PRIO_F0
-#define SG_PRIO_F0 0x330
+#define SG_PRIO_F0 0x120
 #endif
 #ifndef SG_PRIO_F1
-#define SG_PRIO_F1 0x330
+#define SG_PRIO_F1 0x230
 #endif
 #ifndef SG_PRIO_G0
-#define SG_PRIO_G0 0x330
+#define SG_PRIO_G0 0x120
 #endif
 #ifndef SG_PRIO_G1
-#define SG_PRIO_G1 0x330
+#define SG_PRIO_G1 0x120
 #endif
 #define SG_PRIO_VOL ((PRIO3 >> 8) & 3)
 #define SG_PRIO_LIFT ((PRIO3 >> 4) & 3)

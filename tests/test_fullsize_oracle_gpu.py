@@ -1,0 +1,127 @@
+"""BASELINE configs 2, 3 and 5 at FULL size, production kernels against the ORACLE: the committed goldens of
+tests/golden/make_golden_fullsize.py (the oracle's plain-C restatement, oracle/c/seigen_oracle.c, run on the same
+inputs: tests/fullsize_cases.py).  Compared: ~400 cells sampled over the whole mesh (corners, source cells,
+sponge cells, random interior) in every field the product keeps - state u, s and the stage fields utemp, sh1 of
+the last step - plus the sums of every field over each slab of the mesh (covers every cell).  State to 1e-10 of
+its scale; the stage fields are derivatives of the state and carry the operators' round-off amplification
+(tests/test_fullsize_gpu.py): 1e-9 / 1e-7 in 3-D at P4.
+Follows seigen/elastic.py:204-219 (forms), :340-352 (combines), :285-288 (source), :207-208 (sponge)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import fullsize_cases as fc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _quiet():
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    helpers.log = lambda s: None
+    seigen_amd.elastic.log = lambda s: None
+
+
+def _compare(blk, gold, nlayers, tol):
+    from seigen_amd import _lib
+    fields = (("u", _lib.FIELD_U), ("s", _lib.FIELD_S), ("uh", _lib.FIELD_UH), ("sh", _lib.FIELD_SH))
+    cells = gold["cells"]
+    worst = {}
+    for name, f in fields:
+        full = blk.get_field(f)
+        want = gold[name]
+        scale = np.abs(want).max()
+        assert scale > 0 and np.isfinite(full).all()
+        err = np.abs(full[cells] - want).max() / scale
+        lay = fc.layer_sums(full, nlayers)
+        lscale = np.abs(gold[name + "_layers"]).max()
+        lerr = np.abs(lay - gold[name + "_layers"]).max() / max(lscale, scale)
+        worst[name] = (err, lerr)
+        # a slab sum adds up to (cells per slab) values: allow sqrt-like growth of round-off
+        assert err < tol[name] and lerr < 30 * tol[name], (name, err, lerr)
+        del full
+    return worst
+
+
+def test_config3_full_size_vs_oracle(gpu):
+    """3-D eigenmode, 64^3 cubes x 6 tets, P4 (BASELINE config 3, the bench workload): three LF4 steps on the MFMA
+    kernels from the product's own nodal interpolation of the eigenmode (bench.fill_initial_condition)."""
+    _quiet()
+    import bench
+    from seigen_amd import BoxMesh, ElasticLF4
+    c = fc.C3
+    gold = np.load(os.path.join(GOLD, "fullsize_c3.npz"))
+    mesh = BoxMesh(c["n"], c["n"], c["n"], 1.0, 1.0, 1.0)
+    el = ElasticLF4.create(mesh, "DG", c["P"], dimension=3, solver="explicit", output=False)
+    el.density, el.mu, el.l, el.dt = c["rho"], c["mu"], c["lam"], c["dt"]
+    bench.fill_initial_condition(el, el.dt)
+    el.setup()
+    blk = el.block
+    blk.set_source([], None)
+    blk.step(c["steps"])
+    _compare(blk, gold, c["n"], dict(u=1e-10, s=1e-10, sh=1e-9, uh=1e-7))
+    blk.close()
+
+
+def _box_source_expression(lo, hi, t0):
+    from seigen_amd import Expression
+    box = "x[0] >= %r && x[0] <= %r && x[1] >= %r && x[1] <= %r" % (lo[0], hi[0], lo[1], hi[1])
+    code = "%s ? (-1.0 + 2*a*pow(t - t0, 2))*exp(-a*pow(t - t0, 2)) : 0.0" % box
+    return Expression(((code, "0.0"), ("0.0", code)), a=fc.A_RICKER, t0=t0, t=0)
+
+
+def test_config2_full_size_vs_oracle(gpu):
+    """2-D explosive source, 512 x 512 squares, P2, DG4 sponge + box-Ricker source (BASELINE config 2) through the
+    solver class on the 2-D MFMA tile kernels, 20 steps from a smooth state."""
+    _quiet()
+    from seigen_amd import ElasticLF4, Expression, Function, FunctionSpace, RectangleMesh
+    c = fc.C2
+    gold = np.load(os.path.join(GOLD, "fullsize_c2.npz"))
+    n, h = c["n"], c["h"]
+    L = n * h
+    mesh = RectangleMesh(n, n, L, L)
+    el = ElasticLF4.create(mesh, "DG", c["P"], dimension=2, solver="explicit", output=False)
+    el.density, el.mu, el.l, el.dt = c["rho"], c["mu"], c["lam"], c["dt"]
+    sx, sy, hw = c["src"][0], c["src"][1], c["src_half"]
+    el.source_expression = _box_source_expression((sx - hw, sy - hw), (sx + hw, sy + hw), 10 * c["dt"])
+    el.source_function = Function(el.S)
+    el.source = el.source_expression
+    el.absorption_function = Function(FunctionSpace(mesh, "DG", c["sigma_degree"]))
+    el.absorption = Expression("x[0] <= %r || x[0] >= %r || x[1] <= %r ? %r : 0" % (c["sponge"], L - c["sponge"], c["sponge"], c["sigma"]))
+    u0, s0 = fc.smooth_state(el.U.node_coords(), c["k"], c["s_scale"])
+    el.u0.assign(Function(el.U).assign(u0))
+    el.s0.assign(Function(el.S).assign(s0))
+    el.run(c["steps"] * c["dt"] * (1 + 1e-9))
+    assert el.block.counters()["steps"] == c["steps"]
+    _compare(el.block, gold, n, dict(u=1e-10, s=1e-10, sh=1e-9, uh=1e-8))
+
+
+def test_config5_full_size_vs_oracle(gpu):
+    """Marmousi 382 x 120 squares, P3, per-cell lambda / mu and Gardner density (physical update), box-Ricker
+    source (BASELINE config 5) on the 2-D MFMA tile kernels, 20 steps from a smooth state."""
+    _quiet()
+    from seigen_amd import ElasticLF4, Function, RectangleMesh
+    from seigen_amd.marmousi import NX, NY, H, cell_material, gardner_density
+    c = fc.C5
+    gold = np.load(os.path.join(GOLD, "fullsize_c5.npz"))
+    nx, ny = NX - 1, NY - 1
+    mesh = RectangleMesh(nx, ny, nx * H, ny * H)
+    el = ElasticLF4.create(mesh, "DG", c["P"], dimension=2, solver="explicit", output=False)
+    lam, mu, vp = cell_material(el.U, density=gardner_density)
+    rho = gardner_density(vp)
+    assert fc.digest(lam, mu, rho) == str(gold["material_digest"]), "the material arrays are not the golden's"
+    dt = c["courant"] * H / float(vp.max())
+    assert dt == float(gold["dt"])
+    el.density, el.density_physical, el.l, el.mu, el.dt = rho, True, lam, mu, dt
+    sx, sy, hw = 0.5 * nx * H, ny * H - 24.0, c["src_half"]
+    el.source_expression = _box_source_expression((sx - hw, sy - hw), (sx + hw, sy + hw), 10 * dt)
+    el.source_function = Function(el.S)
+    el.source = el.source_expression
+    u0, s0 = fc.smooth_state(el.U.node_coords(), c["k"], c["s_scale"])
+    el.u0.assign(Function(el.U).assign(u0))
+    el.s0.assign(Function(el.S).assign(s0))
+    el.run(c["steps"] * dt * (1 + 1e-9))
+    assert el.block.counters()["steps"] == c["steps"]
+    _compare(el.block, gold, ny, dict(u=1e-10, s=1e-10, sh=1e-9, uh=1e-8))
