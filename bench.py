@@ -15,6 +15,15 @@ One "step" = one full LF4 timestep (six fused HIP launches = the reference's
 eight solves + two assigns, seigen/elastic.py:291-304) over the whole mesh.
 DoF-updates = (U dofs + S dofs) * steps  (SURVEY.md 8d).  Weak scaling: every
 GPU owns an n^3-cube block.  Prints ONE JSON line on rank 0.
+
+--workload c4 measures BASELINE config 4 instead (3-D explosive source, 256^3 cubes in total, P4, FP64, zero initial
+state, box-Ricker stress source, block-split over the ranks: fixed global size, the protocol of
+tests/eigenmode/README.md:7-13); it needs 4 or 8 GPUs (676 GB of fields; on one GPU it runs one rank's 128^3 share).
+With 8 ranks and no --workload the weak-scaling line carries an extra object "config4" measured in the same job.
+
+Watchdogs: every rank arms faulthandler.dump_traceback_later(--timeout): a rank that hangs in init or in an exchange
+dumps its stacks and exits non-zero; the self-launching parent (which never touches a GPU) additionally kills the
+child process group --timeout + 30 s after starting it.
 """
 import argparse
 import json
@@ -77,7 +86,7 @@ def fill_initial_condition(elastic, dt):
         blk.set_field_range(_lib.FIELD_S, k * cells_per_layer, T)
 
 
-def self_launch(ngpus):
+def self_launch(ngpus, timeout_s):
     """--gpus N > 1 without a torchrun environment: start the ranks as a child process group and
     relay what they print.  Nothing in this parent has initialised HIP (no exec of a GPU process)."""
     import socket
@@ -93,9 +102,27 @@ def self_launch(ngpus):
     argv = ["--cubes" if a == "--n" else ("--cubes=" + a[4:] if a.startswith("--n=") else a) for a in sys.argv[1:]]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
-    for ln in proc.stdout.splitlines():
+    import signal
+    # own session = own process group: the watchdog can take down the launcher and every rank with it
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s + 30.0)
+    except subprocess.TimeoutExpired:
+        print("bench.py: no result after %.0f s - killing the ranks (process group %d)" % (timeout_s + 30.0, proc.pid),
+              file=sys.stderr)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10.0)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        sys.exit(124)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
         print(ln)
     sys.stdout.flush()
     if proc.returncode != 0:
@@ -168,6 +195,167 @@ def cpu_baseline(degree, budget_s=15.0):
                       "%d threads" % (N, degree, m.ncells, n, el, cp.threads())}
 
 
+def csrc_digest():
+    """sha256 over the kernel / host sources the library is built from: identifies WHICH kernels a committed
+    traffic measurement belongs to (tools/make_traffic_json.py stores the same digest)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "seigen_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "seigen_amd", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(ROOT, "seigen_amd", "csrc", "*.hpp")) +
+                   [os.path.join(ROOT, "seigen_amd", "csrc", "Makefile")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+class Comm(object):
+    """The few collectives the bench needs (never on the data path)."""
+
+    def __init__(self, dist, backend, world):
+        self.dist, self.backend, self.world = dist, backend, world
+
+    def _t(self, x):
+        import torch
+        return torch.tensor([float(x)], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+
+    def barrier(self):
+        if self.dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def reduce_max(self, x):
+        if self.dist is None:
+            return x
+        t = self._t(x)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def gather(self, x):
+        """one float per rank -> list over ranks (on every rank)"""
+        if self.dist is None:
+            return [float(x)]
+        import torch
+        t = self._t(x)
+        outs = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [o.item() for o in outs]
+
+
+def build_config3(args, rank, world):
+    """Weak scaling of BASELINE config 3: the unit-cube eigenmode on an (n gx, n gy, n gz) mesh of cell size 1/n."""
+    from seigen_amd import ElasticLF4, BoxMesh
+    from seigen_amd.mesh import Partition, _factor_grid
+    n, P = args.n, args.degree
+    grid = _factor_grid(world, 3, (n, n, n))
+    gn = tuple(n * g for g in grid)
+    mesh = BoxMesh(gn[0], gn[1], gn[2], gn[0] / n, gn[1] / n, gn[2] / n)
+    mesh.set_partition(Partition(gn, rank, world, grid))
+    elastic = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False, dtype=args.dtype)
+    elastic.density, elastic.mu, elastic.l = 1.0, 0.25, 0.5
+    elastic.dt = 0.5 * (1.0 / n) / 2 ** (P - 1)
+    fill_initial_condition(elastic, elastic.dt)
+    elastic.setup()
+    elastic.block.set_source([], None)
+    name = "3D eigenmode, %dx%dx%d cubes x 6 tets (%d^3 per GPU), DG P%d, %s, LF4" % (
+        gn[0], gn[1], gn[2], n, P, "FP32" if args.dtype == "f32" else "FP64")
+    return elastic, grid, gn, name, "weak"
+
+
+def build_config4(args, rank, world, nsteps_source):
+    """BASELINE config 4: 3-D explosive source, 256^3 cubes x 6 tets in total (fixed global size), P4, zero initial
+    state, the explosive test's material (explosive_source_lf4.py:21-23) and Ricker wavelet (:37-38) in a
+    4-cube box at the centre, blocks from Partition.  One rank: its 128^3 share alone (85 GB)."""
+    from seigen_amd import ElasticLF4, BoxMesh, Expression, Function, Vp, cfl_dt
+    from seigen_amd.mesh import Partition, _factor_grid
+    P, h = args.degree, 2.5
+    N = args.c4_cubes if world > 1 else args.c4_cubes // 2
+    grid = _factor_grid(world, 3, (N, N, N))
+    mesh = BoxMesh(N, N, N, N * h, N * h, N * h)
+    mesh.set_partition(Partition((N, N, N), rank, world, grid))
+    el = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False, dtype=args.dtype)
+    el.density, el.mu, el.l = 1.0, 3600.0, 3599.3664
+    el.dt = cfl_dt(h, Vp(el.mu, el.l, el.density), 0.05) / 2 ** (P - 1)
+    c = 0.5 * N * h
+    box = " && ".join("x[%d] >= %r && x[%d] <= %r" % (a, c - 2 * h, a, c + 2 * h) for a in range(3))
+    # the wavelet of explosive_source_lf4.py:37-38, centred 40 steps into the run so that the timed steps carry it
+    code = "%s ? (-1.0 + 2*a*pow(t - t0, 2))*exp(-a*pow(t - t0, 2)) : 0.0" % box
+    z = "0.0"
+    el.source_expression = Expression(((code, z, z), (z, code, z), (z, z, code)), a=159.42, t0=40 * el.dt, t=0)
+    el.source_expression.support_box = ((c - 2 * h,) * 3, (c + 2 * h,) * 3)
+    el.source_function = Function(el.S)          # zero; the per-step table below is what the kernels see
+    el.setup()
+    times = [el.dt * (k + 1) for k in range(nsteps_source)]
+    nodes, values, static = el._source_table(times)
+    el.block.set_source(nodes, values, static=static)
+    el._agree_on_stress_storage()
+    name = "3D explosive source (config 4), %d^3 cubes x 6 tets in total, blocks %s, DG P%d, %s, LF4" % (
+        N, "x".join(str(v) for v in mesh.partition.n), P, "FP32" if args.dtype == "f32" else "FP64")
+    if world == 1:
+        name += " - ONE rank's share of the 256^3 mesh (no neighbours)"
+    return el, grid, (N, N, N), name, "strong"
+
+
+def measure(elastic, args, comm, steps, warmup):
+    """W untimed + K timed steps between barriers; returns per-stage device times, counters, timings."""
+    import seigen_amd
+    blk = elastic.block
+
+    def sync():
+        blk.sync()
+        comm.barrier()
+
+    sync()
+    t0 = time.perf_counter()
+    elastic._advance(warmup)
+    sync()
+    warm_s = comm.reduce_max(time.perf_counter() - t0)
+    if steps is None:
+        # long enough for clocks and power to settle (the package reaches its power cap within about
+        # a second): at least 2 s of timed stepping, from the warm-up's own rate
+        per_step = warm_s / max(warmup, 1)
+        steps = int(min(max(math.ceil(2.2 / max(per_step, 1e-6)), 20), 20000))
+        if args.n == 64 and args.degree == 4 and comm.world == 1:
+            steps = max(steps, 250)
+    ex = elastic._exchanger
+    if ex is not None:
+        ex.reset_stats(timing=True)
+    blk.enable_timing(True)
+    c0 = blk.counters()
+    sync()
+    t0 = time.perf_counter()
+    elastic._advance(steps)
+    blk.sync()
+    t_own = time.perf_counter() - t0          # this rank alone (before the closing barrier)
+    comm.barrier()
+    t1 = time.perf_counter()
+    c1 = blk.counters()
+    blk.enable_timing(False)
+    elapsed = comm.reduce_max(t1 - t0)
+    probe = blk.get_field_range(seigen_amd._lib.FIELD_U, 0, 6)
+    assert np.isfinite(probe).all(), "non-finite solution"
+    return dict(steps=steps, elapsed=elapsed, own_ms_per_step=comm.gather(t_own / steps * 1e3), c0=c0, c1=c1,
+                ranks=int(round(sum(comm.gather(1.0)))))
+
+
+def halo_block(elastic, m, comm, backend):
+    ex, c0, c1, nst = elastic._exchanger, m["c0"], m["c1"], m["steps"]
+    st = ex.stats()
+    ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
+    return {"transport": "host-staged/%s" % backend if ex.staged else backend,
+            "pack_ms_per_step": comm.gather((c1["halo_pack_ms"] - c0["halo_pack_ms"]) / nst),
+            "bytes_sent_per_step": comm.gather((c1["halo_bytes_packed"] - c0["halo_bytes_packed"]) / nst),
+            "exposed_wait_ms_per_step": comm.gather(st["exposed_wait_ms"] / nst),
+            "host_blocked_ms_per_step": comm.gather(st.get("host_blocked_ms", 0.0) / nst),
+            "exchanges_per_step": st["exchanges"] / nst,
+            # split stages count once, with the longer of their two concurrent launches (sg_get_counters)
+            "kernel_ms_per_step": comm.gather(sum(ms) / nst),
+            "grid_blocks": os.environ.get("SEIGEN_HIP_GRID_BLOCKS", "default (15/16 of the block slots while exchanging)")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,10 +368,24 @@ def main():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="f64: the reference's precision (headline); f32: the separately reported FP32 second mode "
                          "(SURVEY 8d, 32 B per DoF-update)")
+    ap.add_argument("--workload", choices=("c3", "c4"), default=None,
+                    help="c3: weak scaling of config 3 (default); c4: BASELINE config 4 (256^3 in total, 4 or 8 GPUs; "
+                         "one GPU: one rank's 128^3 share).  8 ranks without this flag: c3 plus a \"config4\" object")
+    ap.add_argument("--c4-cubes", type=int, default=256, help="global cubes per axis of config 4 (tests use less)")
+    ap.add_argument("--c4-steps", type=int, default=20, help="timed steps of the appended config-4 measurement")
+    ap.add_argument("--timeout", type=float, default=900.0,
+                    help="seconds after which a rank that has not finished dumps its stacks and exits non-zero")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus)      # never returns
+        self_launch(args.gpus, args.timeout)      # never returns
+
+    # a rank stuck in init, in an exchange or in a kernel: stacks of all threads to stderr, then exit(1) -
+    # from a watchdog thread of the interpreter's own, independent of the GIL
+    import faulthandler
+    faulthandler.dump_traceback_later(args.timeout, exit=True)
+    if os.environ.get("SEIGEN_BENCH_TEST_HANG"):      # tests/test_host_logic.py: a rank that never comes back
+        time.sleep(1e6)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,101 +395,50 @@ def main():
     # multi-process path with host-staged halos, e.g. two ranks on one GPU (tests/test_dist_gpu.py).
     backend = os.environ.get("SEIGEN_DIST_BACKEND", "nccl")
     if "WORLD_SIZE" in os.environ:      # launched by torch.distributed.run: a process group even for one rank
+        import datetime
         import torch
         import torch.distributed as dist
         dev_index = int(os.environ.get("SEIGEN_HIP_DEVICE", local_rank))
         torch.cuda.set_device(dev_index)
+        tmo = datetime.timedelta(seconds=max(60.0, args.timeout))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if args.workload == "c4" and world not in (1, 4, 8) and args.c4_cubes == 256:
+        if rank == 0:
+            print("bench.py: config 4 (256^3 cubes, 676 GB of fields) needs 4 or 8 GPUs (or 1 for one rank's share)", file=sys.stderr)
+        sys.exit(2)
 
     import seigen_amd
-    from seigen_amd import ElasticLF4, BoxMesh
-    from seigen_amd.mesh import Partition, _factor_grid
     import seigen_amd.helpers as helpers
     helpers.log = lambda s: None
     seigen_amd.elastic.log = lambda s: None
-
-    n, P = args.n, args.degree
-    grid = _factor_grid(world, 3, (n, n, n))
-    gn = tuple(n * g for g in grid)
-    # weak scaling: the unit cube eigenmode on an (n*gx, n*gy, n*gz) mesh of cell size 1/n
-    mesh = BoxMesh(gn[0], gn[1], gn[2], gn[0] / n, gn[1] / n, gn[2] / n)
-    mesh.set_partition(Partition(gn, rank, world, grid))
-    elastic = ElasticLF4.create(mesh, "DG", P, dimension=3, solver="explicit", output=False, dtype=args.dtype)
+    comm = Comm(dist, backend, world)
+    P = args.degree
     esz = 4 if args.dtype == "f32" else 8        # bytes per stored value
-    elastic.density, elastic.mu, elastic.l = 1.0, 0.25, 0.5
-    elastic.dt = 0.5 * (1.0 / n) / 2 ** (P - 1)
-    fill_initial_condition(elastic, elastic.dt)
-    elastic.setup()
+
+    workload = args.workload or "c3"
+    if workload == "c4":
+        steps = args.steps if args.steps is not None else 30
+        elastic, grid, gn, wname, scaling = build_config4(args, rank, world, steps + args.warmup + 1)
+        args.steps = steps
+    else:
+        elastic, grid, gn, wname, scaling = build_config3(args, rank, world)
     blk = elastic.block
-    blk.set_source([], None)
-
-    def sync():
-        blk.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    def reduce_max(x):
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.item()
-
-    def gather(x):
-        """one float per rank -> list over ranks (on every rank)"""
-        if dist is None:
-            return [float(x)]
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        outs = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        return [o.item() for o in outs]
-
-    sync()
-    t0 = time.perf_counter()
-    elastic._advance(args.warmup)
-    sync()
-    warm_s = reduce_max(time.perf_counter() - t0)
-    if args.steps is None:
-        # long enough for clocks and power to settle (the package reaches its power cap within about
-        # a second): at least 2 s of timed stepping, from the warm-up's own rate
-        per_step = warm_s / max(args.warmup, 1)
-        args.steps = int(min(max(math.ceil(2.2 / max(per_step, 1e-6)), 20), 20000))
-        if n == 64 and P == 4 and world == 1:
-            args.steps = max(args.steps, 250)
-    ex = elastic._exchanger
-    if ex is not None:
-        ex.reset_stats(timing=True)
-    blk.enable_timing(True)
-    c0 = blk.counters()
-    sync()
-    t0 = time.perf_counter()
-    elastic._advance(args.steps)
-    sync()
-    t1 = time.perf_counter()
-    c1 = blk.counters()
-    blk.enable_timing(False)
-    elapsed = reduce_max(t1 - t0)
-    ranks_reporting = int(round(sum(gather(1.0))))
-
-    # sanity: the field must still be finite
-    probe = blk.get_field_range(seigen_amd._lib.FIELD_U, 0, 6)
-    assert np.isfinite(probe).all(), "non-finite solution"
+    n = args.n
+    m = measure(elastic, args, comm, args.steps, args.warmup)
+    args.steps = m["steps"]
+    elapsed, c0, c1, ranks_reporting = m["elapsed"], m["c0"], m["c1"], m["ranks"]
 
     d = 3
     nodes = blk.ncells * blk.nd
     dofs_per_gpu = blk.u_dofs + blk.s_dofs
-    total_dofs = int(round(sum(gather(dofs_per_gpu))))
+    total_dofs = int(round(sum(comm.gather(dofs_per_gpu))))
     value = total_dofs * args.steps / elapsed / 1e6
 
     # kernels as rocprofv3 names them: <P, 0> plain store (stages uh1/utemp, stemp/sh1),
@@ -320,23 +471,31 @@ def main():
     for name, stages in names:
         tot_ms = sum(ms[i] for i in stages)
         launches = sum(nl[i] for i in stages)
-        # bytes per STEP, not per launch: a split stage (multi-GPU: FIRST + SECOND) covers the block once
+        # bytes per STEP, not per launch: a split stage (multi-GPU: FIRST + SECOND) covers the block once, and its
+        # device time is counted once (the longer of the two concurrent launches)
         byts = sum(words[i] for i in stages) * nst * nodes * float(esz)
         byts_phys = sum(words_phys[i] for i in stages) * nst * nodes * float(esz)
-        kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(launches, 1),
+        per = len(stages) * nst           # stage executions of this kernel in the timed region
+        kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(per, 1),
                           gbs=byts / max(tot_ms, 1e-12) / 1e6, gbs_phys=byts_phys / max(tot_ms, 1e-12) / 1e6,
-                          bytes_per_launch=byts / max(launches, 1), bytes_phys_per_launch=byts_phys / max(launches, 1))
+                          bytes_per_launch=byts / max(per, 1), bytes_phys_per_launch=byts_phys / max(per, 1))
     dom = max(kern, key=lambda k: kern[k]["ms"])
-    # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE,
-    # calibrated with tools/calib_fetch.hip) - measured separately, see profiles/<round>/*_traffic.json
+    # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated with
+    # tools/calib_fetch.hip) - measured separately (tools/profile_config3.sh -> profiles/<round>/config3_traffic.json)
+    # and quoted ONLY if that file was made with the kernels that are running now (digest of seigen_amd/csrc)
     traffic = None
     traffic_src = None
-    if world == 1 and n == 64 and P == 4 and args.dtype == "f64":
+    if world == 1 and workload == "c3" and n == 64 and P == 4 and args.dtype == "f64":
+        digest = csrc_digest()
         for tj in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "config3_traffic.json"))):
             try:
-                t = json.load(open(tj))["kernels"].get(dom, {}).get("bytes")
-                if t:
+                tdoc = json.load(open(tj))
+                t = tdoc["kernels"].get(dom, {}).get("bytes")
+                if t and tdoc.get("csrc_sha256") == digest:
                     traffic, traffic_src = t, os.path.relpath(tj, ROOT)
+                elif t:
+                    traffic_src = "stale: %s was measured with other kernel sources (csrc digest %s..., running %s...)" % (
+                        os.path.relpath(tj, ROOT), str(tdoc.get("csrc_sha256"))[:12], digest[:12])
             except (OSError, ValueError, KeyError):
                 pass
     k = kern[dom]
@@ -347,6 +506,7 @@ def main():
             "achieved_physical": k["gbs_phys"], "frac_physical": k["gbs_phys"] / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_ratio": (traffic / k["bytes_phys_per_launch"]) if traffic else None,
+            "traffic_ratio_algorithmic": (traffic / k["bytes_per_launch"]) if traffic else None,
             "algorithmic_bytes_per_launch": k["bytes_per_launch"],
             "physical_bytes_per_launch": k["bytes_phys_per_launch"],
             "avg_launch_ms": k["avg_ms"],
@@ -358,8 +518,7 @@ def main():
         # second view of the same kernel: the dense element-local products on the FP64 matrix pipe.
         # Algorithmic flop per cell and launch: 2 * (9 nd^2 + 12 nd nf), F and G alike.
         nf = (P + 1) * (P + 2) // 2
-        stages_dom = dict(names)[dom]
-        flop = 2.0 * (9 * blk.nd ** 2 + 12 * blk.nd * nf) * blk.ncells * len(stages_dom) * nst / max(k["launches"], 1)
+        flop = 2.0 * (9 * blk.nd ** 2 + 12 * blk.nd * nf) * blk.ncells
         tf = flop / (k["avg_ms"] * 1e-3) / 1e12
         if args.dtype == "f64":
             roof["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
@@ -370,34 +529,43 @@ def main():
 
     # halo layer, per rank (lists over ranks): device time of the trace packs, bytes handed to the
     # transport, and the time the launch stream (RCCL) or the host (host-staged) waited for traces
-    halo = None
-    if world > 1:
-        st = ex.stats()
-        halo = {"transport": "host-staged/%s" % backend if ex.staged else backend,
-                "pack_ms_per_step": gather((c1["halo_pack_ms"] - c0["halo_pack_ms"]) / nst),
-                "bytes_sent_per_step": gather((c1["halo_bytes_packed"] - c0["halo_bytes_packed"]) / nst),
-                "exposed_wait_ms_per_step": gather(st["exposed_wait_ms"] / nst),
-                "exchanges_per_step": st["exchanges"] / nst,
-                "kernel_ms_per_step": gather(sum(ms) / nst)}
+    halo = halo_block(elastic, m, comm, backend) if world > 1 else None
+    own = m["own_ms_per_step"]
+    out = {
+        "metric": "M DoF-updates/sec, 3D elastic P=%d" % P + (" (FP32 second mode)" if args.dtype == "f32" else ""),
+        "value": value, "unit": "M DoF-updates/s",
+        "n_gpus": ranks_reporting, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": wname, "cells": int(blk.ncells * world) if workload == "c3" else int(6 * gn[0] * gn[1] * gn[2]),
+                   "dofs": int(total_dofs), "block_grid": list(grid), "dt": elastic.dt},
+        "roofline": roof,
+        "timed_region_s": elapsed,
+        "rank_ms_per_step": {"min": min(own), "max": max(own), "per_rank": own},
+    }
+    if halo is not None:
+        out["halo"] = halo
+
+    # 8 ranks, no explicit workload: BASELINE config 4 in the same job (its own mesh, its own barriers)
+    if args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4"):
+        elastic._exchanger = None
+        blk.close()
+        del elastic, blk
+        el4, grid4, gn4, wname4, _ = build_config4(args, rank, world, args.c4_steps + 3 + 1)
+        m4 = measure(el4, args, comm, args.c4_steps, 3)
+        dofs4 = int(round(sum(comm.gather(el4.block.u_dofs + el4.block.s_dofs))))
+        own4 = m4["own_ms_per_step"]
+        out["config4"] = {"workload": wname4, "value": dofs4 * m4["steps"] / m4["elapsed"] / 1e6, "unit": "M DoF-updates/s",
+                          "ms_per_step": m4["elapsed"] / m4["steps"] * 1e3, "steps": m4["steps"], "warmup": 3,
+                          "scaling": "strong (fixed global size)", "block_grid": list(grid4), "dofs": dofs4,
+                          "block_cubes": list(el4.mesh.partition.n), "dt": el4.dt,
+                          "rank_ms_per_step": {"min": min(own4), "max": max(own4), "per_rank": own4},
+                          "halo": halo_block(el4, m4, comm, backend)}
     if rank == 0:
-        out = {
-            "metric": "M DoF-updates/sec, 3D elastic P=%d" % P + (" (FP32 second mode)" if args.dtype == "f32" else ""),
-            "value": value, "unit": "M DoF-updates/s",
-            "n_gpus": ranks_reporting, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "3D eigenmode, %dx%dx%d cubes x 6 tets (%d^3 per GPU), DG P%d, %s, LF4"
-                                   % (gn[0], gn[1], gn[2], n, P, "FP32" if args.dtype == "f32" else "FP64"),
-                       "cells": int(blk.ncells * world), "dofs": int(total_dofs),
-                       "block_grid": list(grid), "dt": elastic.dt},
-            "roofline": roof,
-            "timed_region_s": elapsed,
-        }
-        if halo is not None:
-            out["halo"] = halo
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(out))
+    faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -125,6 +125,9 @@ int sg_get_stream(const sg_handle* h, void** stream);
 /* Blocks with neighbours launch SG_REGION_SECOND of a split stage on a second, lower-priority stream beside
  * SG_REGION_FIRST of the same stage (it depends on the stage before, not on FIRST; SEIGEN_HIP_OVERLAP=0 switches
  * this off); everything queued later on the main stream waits for it.  NULL if the handle has no such stream.
+ * Call order: sg_run_stage(stage, SG_REGION_SECOND) must directly follow sg_run_stage(stage, SG_REGION_FIRST) of
+ * the SAME stage (FIRST records the event SECOND's stream waits for); anything else returns SG_ERR_STATE.
+ * Timing counters (sg_get_counters kernel_ms) count such a stage once, with the longer of its two launches.
  * For instrumentation: the host layer records an event on it to tell how long the next stage really waited
  * for traces (what ParLoopHaloEnd times in the reference, tests/tiling/utils.py:144). */
 int sg_get_second_stream(const sg_handle* h, void** stream);

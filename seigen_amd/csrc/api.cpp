@@ -5,6 +5,39 @@
 
 std::string g_create_err;
 
+// Which kernel family runs a block (and with it the layout's group width gw: 16 cubes per 128-byte line for the
+// MFMA and tile kernels, 64 for the lane kernels, 1 = host layout for the generic kernel).
+KernelPath choose_kernel_path(const sg_config& cfg) {
+  KernelPath kp;
+  const int ncls = cfg.dim == 1 ? 1 : (cfg.dim == 2 ? 2 : 6);
+  // kernel path: MFMA kernels (interleaved layout) where they exist, unless SEIGEN_HIP_PATH=generic
+  const char* path_env = std::getenv("SEIGEN_HIP_PATH");
+  const bool force_generic = path_env && std::strcmp(path_env, "generic") == 0;
+  // 3-D: the MFMA kernels at every degree (degrees 1 and 2 use 4x4x4 tiles only); measured with
+  // tools/path_sweep.py they beat the lane and generic kernels everywhere except degree 1 on blocks
+  // under 65536 cells (SEIGEN_HIP_PATH=mfma forces them)
+  const bool force_mfma = path_env && std::strcmp(path_env, "mfma") == 0;
+  const int64_t ncube_all = (int64_t)cfg.n[0] * (cfg.dim > 1 ? cfg.n[1] : 1) * (cfg.dim > 2 ? cfg.n[2] : 1);
+  const int64_t ncells_all = ncube_all * ncls;
+  kp.mfma = mfma_supported(cfg.dim, cfg.degree) && !force_generic &&
+            !(path_env && std::strcmp(path_env, "lane") == 0) &&
+            (cfg.degree >= 2 || ncells_all >= 65536 || force_mfma);
+  // lane-per-cell kernels need enough 64-cell groups to fill the chip; below that the
+  // thread-per-node generic kernel has more parallelism (SEIGEN_HIP_PATH=lane forces them)
+  const bool force_lane = path_env && std::strcmp(path_env, "lane") == 0;
+  kp.lane = !kp.mfma && lane_supported(cfg.dim, cfg.degree) && !force_generic &&
+            (force_lane || ncells_all >= (cfg.degree == 1 ? 196608 : 120000));  // crossovers measured
+                                                                 // (tools/path_sweep.py, profiles/r02/small_2d_configs_negative_results.txt)
+  // 2-D: the MFMA tile kernels (16 cells per wave, operators in registers) from SG_TILE2D_MIN_CELLS cells up
+  // (measured crossover against the generic kernel, tools/path_sweep.py); SEIGEN_HIP_PATH=tile forces them
+  const bool force_tile = path_env && std::strcmp(path_env, "tile") == 0;
+  kp.tile = tile2d_supported(cfg.dim, cfg.degree) && !force_generic && !force_lane &&
+            (force_tile || ncells_all >= SG_TILE2D_MIN_CELLS);
+  if (kp.tile) kp.lane = false;
+  kp.gw = (kp.mfma || kp.tile) ? 16 : (kp.lane ? 64 : 1);
+  return kp;
+}
+
 extern "C" {
 
 const char* sg_last_error(const sg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -96,35 +129,15 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   for (int s = 0; s < 6; ++s) h->md.has_nbr[s] = (s < 2 * cfg->dim) ? ((cfg->nbr_mask >> s) & 1) : 0;
   h->ncls = h->md.ncls;
   h->ncells = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2] * h->ncls;
-  // kernel path: MFMA kernels (interleaved layout) where they exist, unless SEIGEN_HIP_PATH=generic
-  const char* path_env = std::getenv("SEIGEN_HIP_PATH");
-  const bool force_generic = path_env && std::strcmp(path_env, "generic") == 0;
-  // 3-D: the MFMA kernels at every degree (degrees 1 and 2 use 4x4x4 tiles only); measured with
-  // tools/path_sweep.py they beat the lane and generic kernels everywhere except degree 1 on blocks
-  // under 65536 cells (SEIGEN_HIP_PATH=mfma forces them)
-  const bool force_mfma = path_env && std::strcmp(path_env, "mfma") == 0;
-  const int64_t ncells_all = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2] * h->ncls;
-  h->use_mfma = mfma_supported(cfg->dim, cfg->degree) && !force_generic &&
-                !(path_env && std::strcmp(path_env, "lane") == 0) &&
-                (cfg->degree >= 2 || ncells_all >= 65536 || force_mfma);
-  // lane-per-cell kernels need enough 64-cell groups to fill the chip; below that the
-  // thread-per-node generic kernel has more parallelism (SEIGEN_HIP_PATH=lane forces them)
-  const bool force_lane = path_env && std::strcmp(path_env, "lane") == 0;
-  const int64_t ncube_all = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
-  h->use_lane = !h->use_mfma && lane_supported(cfg->dim, cfg->degree) && !force_generic &&
-                (force_lane || ncube_all * h->ncls >= (cfg->degree == 1 ? 196608 : 120000));  // crossovers measured
-                                                                     // (tools/path_sweep.py, profiles/r02/small_2d_configs_negative_results.txt)
-  // 2-D: the MFMA tile kernels (16 cells per wave, operators in registers) from SG_TILE2D_MIN_CELLS cells up
-  // (measured crossover against the generic kernel, tools/path_sweep.py); SEIGEN_HIP_PATH=tile forces them
-  const bool force_tile = path_env && std::strcmp(path_env, "tile") == 0;
-  h->use_tile = tile2d_supported(cfg->dim, cfg->degree) && !force_generic && !force_lane &&
-                (force_tile || ncells_all >= SG_TILE2D_MIN_CELLS);
-  if (h->use_tile) h->use_lane = false;
+  const KernelPath kp = choose_kernel_path(*cfg);
+  h->use_mfma = kp.mfma;
+  h->use_lane = kp.lane;
+  h->use_tile = kp.tile;
   if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
   h->f32 = cfg->dtype;
   if (h->f32 && !h->use_mfma)
     return fail(h, SG_ERR_ARG, "dtype f32 is implemented on the MFMA path (3-D blocks; degree 1 from 65536 cells)");
-  h->md.gw = (h->use_mfma || h->use_tile) ? 16 : (h->use_lane ? 64 : 1);
+  h->md.gw = kp.gw;
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
   if (h->use_tile) h->t2c = tile2d_const(h->md);
@@ -226,7 +239,15 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);
     if (cfg->nbr_mask == 0) h->grid_full = h->grid_blocks;
+    // F stages of a whole 3-D block: items dealt to the XCDs in chunks of 1/8 of a z-layer of cubes, so that all XCDs
+    // sweep the block layer by layer together (the z-neighbour traces then meet the own rows of the next layer in the
+    // Infinity Cache: F stages -3 %, profiles/r03/order_chunk_sweep.txt; the G stages do not gain and keep one
+    // contiguous range per XCD).  SEIGEN_HIP_ORDER_CHUNK overrides (0 = off).
     h->order_chunk = 0;
+    if (h->use_mfma && cfg->dim == 3) {
+      const int64_t per_layer = ((int64_t)cfg->n[0] * cfg->n[1] + 15) / 16 * 6;
+      if (cfg->n[2] >= 16) h->order_chunk = (int)std::max<int64_t>(6, (per_layer + 7) / 8);
+    }
     if (const char* oc = std::getenv("SEIGEN_HIP_ORDER_CHUNK")) h->order_chunk = std::max(0, std::atoi(oc));
     // 251 blocks per XCD label: with an odd (prime) stride of 4 * 251 items a wave's items do not keep falling on
     // the same column of the mesh, e.g. on the sponge strips at both ends of every row (config 2: 0.240 -> 0.232 ms)

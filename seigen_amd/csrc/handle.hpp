@@ -104,7 +104,11 @@ struct sg_handle {
   double last_ms = 0.0;
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;   // per-launch event pairs, resolved lazily (no sync in the hot loop)
-  std::vector<int> ev_stage_ids;         // stage of pair k = events 2k, 2k+1
+  // stage of pair k = events 2k, 2k+1 (6 = halo pack); + 16 for the FIRST, + 32 for the SECOND launch of a stage
+  // that runs its two regions side by side on two streams (their pairs overlap in time: the stage counts the longer)
+  std::vector<int> ev_stage_ids;
+  double first_ms_pending[6] = {-1, -1, -1, -1, -1, -1};
+  int first_recorded_stage = -1;         // stage whose FIRST launch recorded ev_stage last (SECOND must follow it)
   sg_counters_t counters;
   std::string err;
 };
@@ -158,8 +162,17 @@ int leave_sym_mode(sg_handle* h);
 struct Box {
   int o[3], n[3];
 };
-void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out);
+struct KernelPath {
+  bool mfma = false, lane = false, tile = false;
+  int gw = 1;
+};
+KernelPath choose_kernel_path(const sg_config& cfg);
+// shell thickness along x: the interleaved layouts put gw consecutive cubes of an x-row on the lanes of one item, so a
+// one-cube shell next to an x side would use one lane in gw of every item it touches AND make the launch that owns the
+// other gw - 1 lanes run the same item again.  With whole groups in the shell no item is cut (2 x 2 x 2).
+inline int shell_width_x(int gw) { return gw > 1 ? gw : 1; }
+void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out, int xw);
 inline void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
-  region_boxes(h->cfg.dim, h->cfg.n, h->md.has_nbr, region, out);
+  region_boxes(h->cfg.dim, h->cfg.n, h->md.has_nbr, region, out, shell_width_x(h->md.gw));
 }
 int resolve_timing(sg_handle* h);

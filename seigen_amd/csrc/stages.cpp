@@ -4,7 +4,7 @@
 
 // ---- stage launches --------------------------------------------------------------------
 
-void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out) {
+void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out, int xw) {
   out.clear();
   int lo[3] = {0, 0, 0}, hi[3];
   for (int a = 0; a < 3; ++a) hi[a] = n[a];
@@ -12,11 +12,13 @@ void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int regio
     out.push_back(Box{{0, 0, 0}, {hi[0], hi[1], hi[2]}});
     return;
   }
-  // interior: peel one cube off every side that has a neighbour block
+  // interior: peel one cube (along x: one layout group of xw cubes, handle.hpp shell_width_x) off every side
+  // that has a neighbour block
   int ilo[3] = {0, 0, 0}, ihi[3] = {hi[0], hi[1], hi[2]};
   for (int a = 0; a < d; ++a) {
-    if (has_nbr[2 * a]) ilo[a] = 1;
-    if (has_nbr[2 * a + 1]) ihi[a] = hi[a] - 1;
+    const int w = (a == 0 && xw > 1) ? xw : 1;
+    if (has_nbr[2 * a]) ilo[a] = w < hi[a] ? w : hi[a];
+    if (has_nbr[2 * a + 1]) ihi[a] = hi[a] - w > 0 ? hi[a] - w : 0;
     if (ihi[a] < ilo[a]) ihi[a] = ilo[a];
   }
   if (region == SG_REGION_INTERIOR) {
@@ -128,7 +130,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     if (h->use_tile) a.grid_blocks = h->tile_grid;
     a.item_list = nullptr;
     a.nlist = 0;
-    a.order_chunk = (h->use_mfma && !a.spread) ? h->order_chunk : 0;
+    a.order_chunk = (h->use_mfma && !a.spread && kind == 0) ? h->order_chunk : 0;
     if (region != SG_REGION_ALL) {
       // Both regions of a split stage are static: list the (cell group, class) items that have
       // an active cube once.  The interior launch then splits ACTIVE items evenly over the XCDs
@@ -236,10 +238,21 @@ int resolve_timing(sg_handle* h) {
   for (size_t k = 0; k < h->ev_stage_ids.size(); ++k) {
     float ms = 0;
     HIPCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]));
-    if (h->ev_stage_ids[k] == 6)
+    const int id = h->ev_stage_ids[k], st = id & 15;
+    if (st == 6) {
       h->counters.halo_pack_ms += ms;
-    else
-      h->counters.kernel_ms[h->ev_stage_ids[k]] += ms;
+    } else if (id & 16) {
+      // FIRST of a stage whose SECOND runs beside it on the other stream: both pairs start at (about) the same
+      // point and overlap, so the stage's device time is the LONGER of the two, not their sum
+      if (h->first_ms_pending[st] >= 0) h->counters.kernel_ms[st] += h->first_ms_pending[st];  // a FIRST without SECOND
+      h->first_ms_pending[st] = ms;
+    } else if (id & 32) {
+      const double f = h->first_ms_pending[st];
+      h->counters.kernel_ms[st] += (f > ms ? f : (double)ms);
+      h->first_ms_pending[st] = -1;
+    } else {
+      h->counters.kernel_ms[st] += ms;
+    }
   }
   h->ev_stage_ids.clear();
   return SG_OK;
@@ -256,12 +269,19 @@ int sg_run_stage(sg_handle* h, int stage, int region) {
   const bool second = h->overlap && region == SG_REGION_SECOND;
   hipStream_t const main_stream = h->stream;
   if (second) {
-    // depends on everything before this stage's FIRST (ev_stage), not on FIRST itself
+    // depends on everything before this stage's FIRST (ev_stage), not on FIRST itself - so FIRST of the SAME stage
+    // must have been issued (it records ev_stage); anything else would wait on a stale event and race
+    if (h->first_recorded_stage != stage)
+      return fail(h, SG_ERR_STATE, "sg_run_stage(stage, SG_REGION_SECOND) must follow sg_run_stage(stage, SG_REGION_FIRST) of the same stage");
+    h->first_recorded_stage = -1;
     HIPCHECK(h, hipStreamWaitEvent(h->stream2, h->ev_stage, 0));
     h->stream = h->stream2;
   } else {
     if (int rc = join_second(h)) return rc;
-    if (h->overlap && region == SG_REGION_FIRST) HIPCHECK(h, hipEventRecord(h->ev_stage, h->stream));
+    if (h->overlap && region == SG_REGION_FIRST) {
+      HIPCHECK(h, hipEventRecord(h->ev_stage, h->stream));
+      h->first_recorded_stage = stage;
+    }
   }
   size_t k = h->ev_stage_ids.size();
   int rc = SG_OK;
@@ -283,7 +303,7 @@ int sg_run_stage(sg_handle* h, int stage, int region) {
   if (rc == SG_OK) rc = run_stage_impl(h, stage, region);
   if (rc == SG_OK && h->timing) {
     if (hipEventRecord(h->ev_pool[2 * k + 1], h->stream) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
-    else h->ev_stage_ids.push_back(stage);
+    else h->ev_stage_ids.push_back(stage + ((h->overlap && region == SG_REGION_FIRST) ? 16 : (second ? 32 : 0)));
   }
   if (second) {
     if (rc == SG_OK && hipEventRecord(h->ev_second, h->stream2) != hipSuccess) rc = fail(h, SG_ERR_DEVICE, "hipEventRecord failed");
@@ -503,6 +523,11 @@ int sg_get_counters(sg_handle* h, sg_counters_t* out) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   int rc = resolve_timing(h);
   if (rc != SG_OK) return rc;
+  for (int st = 0; st < 6; ++st)      // a FIRST launch whose SECOND was never issued
+    if (h->first_ms_pending[st] >= 0 && !h->second_pending) {
+      h->counters.kernel_ms[st] += h->first_ms_pending[st];
+      h->first_ms_pending[st] = -1;
+    }
   *out = h->counters;
   return SG_OK;
 }
@@ -513,7 +538,7 @@ int sg_region_boxes(const sg_config* cfg, int region, int32_t* boxes, int max_bo
   for (int a = 0; a < cfg->dim; ++a) n[a] = cfg->n[a];
   for (int s2 = 0; s2 < 2 * cfg->dim; ++s2) has_nbr[s2] = (cfg->nbr_mask >> s2) & 1;
   std::vector<Box> out;
-  region_boxes(cfg->dim, n, has_nbr, region, out);
+  region_boxes(cfg->dim, n, has_nbr, region, out, shell_width_x(choose_kernel_path(*cfg).gw));
   int cnt = 0;
   for (const Box& b : out) {
     if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;

@@ -37,10 +37,10 @@ static constexpr size_t XFER_CHUNK_BYTES = (size_t)64 << 20;
 
 // Large transfers (sg_set_field / sg_get_field of hundreds of MB): chunks of 64 MB go through pinned
 // host slots.  Download: layout kernel -> device slot -> async DMA -> pinned slot, while the host
-// copies the previous pinned slot into the caller's (pageable) array on several threads.  Upload: the
-// mirror image.  A plain hipMemcpy to pageable memory runs at 11 GB/s (one staging thread inside the
+// copies the previous pinned slot into the caller's (pageable) array on several threads.  Downloads only:
+// uploads from pageable memory already run at 47 GB/s inside the runtime.  A plain hipMemcpy to pageable memory runs at 11 GB/s (one staging thread inside the
 // runtime); this pipeline is bound by the link.
-static int transfer_pipelined(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host, bool to_device) {
+static int download_pipelined(sg_handle* h, int field, int64_t cell0, int64_t ncells, double* host) {
   const size_t per_cell = h->field_len[field] / (size_t)h->ncells;
   const int comps = (int)(per_cell / h->re.nd);
   const size_t chunk_cells = std::max<size_t>(1, XFER_CHUNK_BYTES / (per_cell * sizeof(double)));
@@ -55,44 +55,26 @@ static int transfer_pipelined(sg_handle* h, int field, int64_t cell0, int64_t nc
     c0 = c * (int64_t)chunk_cells;
     n = std::min<int64_t>((int64_t)chunk_cells, ncells - c0);
   };
-  int* flag = (to_device && h->sym && field_is_stress(field)) ? h->sym_flag : nullptr;
-  const int symdl = (!to_device && h->sym && field_is_stress(field)) ? 1 : 0;
+  const int symdl = (h->sym && field_is_stress(field)) ? 1 : 0;
   for (int64_t c = 0; c <= nchunks; ++c) {
     const int sl = (int)(c & 1);
     int64_t c0, n;
-    if (to_device) {
-      if (c < nchunks) {
-        range(c, c0, n);
-        const size_t nb = (size_t)n * per_cell * sizeof(double);
-        HIPCHECK(h, hipEventSynchronize(h->xfer_ev[sl]));  // the slot's previous DMA has left the pinned buffer
-        parallel_memcpy(h->pin[sl], host + (size_t)c0 * per_cell, nb);
-        if (h->md.gw == 1) {
-          HIPCHECK(h, hipMemcpyAsync(h->field[field] + (size_t)(cell0 + c0) * per_cell, h->pin[sl], nb, hipMemcpyHostToDevice, h->stream));
-        } else {
-          HIPCHECK(h, hipMemcpyAsync(h->dstage[sl], h->pin[sl], nb, hipMemcpyHostToDevice, h->stream));
-          if (launch_layout(h->md, comps, 0, h->field[field], h->dstage[sl], cell0 + c0, n, 0, flag, h->f32, h->stream) != 0)
-            return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
-        }
-        HIPCHECK(h, hipEventRecord(h->xfer_ev[sl], h->stream));
+    if (c < nchunks) {
+      range(c, c0, n);
+      const size_t nb = (size_t)n * per_cell * sizeof(double);
+      if (h->md.gw == 1) {
+        HIPCHECK(h, hipMemcpyAsync(h->pin[sl], h->field[field] + (size_t)(cell0 + c0) * per_cell, nb, hipMemcpyDeviceToHost, h->stream));
+      } else {
+        if (launch_layout(h->md, comps, 1, h->field[field], h->dstage[sl], cell0 + c0, n, symdl, nullptr, h->f32, h->stream) != 0)
+          return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
+        HIPCHECK(h, hipMemcpyAsync(h->pin[sl], h->dstage[sl], nb, hipMemcpyDeviceToHost, h->stream));
       }
-    } else {
-      if (c < nchunks) {
-        range(c, c0, n);
-        const size_t nb = (size_t)n * per_cell * sizeof(double);
-        if (h->md.gw == 1) {
-          HIPCHECK(h, hipMemcpyAsync(h->pin[sl], h->field[field] + (size_t)(cell0 + c0) * per_cell, nb, hipMemcpyDeviceToHost, h->stream));
-        } else {
-          if (launch_layout(h->md, comps, 1, h->field[field], h->dstage[sl], cell0 + c0, n, symdl, nullptr, h->f32, h->stream) != 0)
-            return fail(h, SG_ERR_DEVICE, "layout kernel launch failed");
-          HIPCHECK(h, hipMemcpyAsync(h->pin[sl], h->dstage[sl], nb, hipMemcpyDeviceToHost, h->stream));
-        }
-        HIPCHECK(h, hipEventRecord(h->xfer_ev[sl], h->stream));
-      }
-      if (c > 0) {  // the previous chunk has arrived (or is arriving) in the other slot: hand it to the caller
-        range(c - 1, c0, n);
-        HIPCHECK(h, hipEventSynchronize(h->xfer_ev[sl ^ 1]));
-        parallel_memcpy(host + (size_t)c0 * per_cell, h->pin[sl ^ 1], (size_t)n * per_cell * sizeof(double));
-      }
+      HIPCHECK(h, hipEventRecord(h->xfer_ev[sl], h->stream));
+    }
+    if (c > 0) {  // the previous chunk has arrived (or is arriving) in the other slot: hand it to the caller
+      range(c - 1, c0, n);
+      HIPCHECK(h, hipEventSynchronize(h->xfer_ev[sl ^ 1]));
+      parallel_memcpy(host + (size_t)c0 * per_cell, h->pin[sl ^ 1], (size_t)n * per_cell * sizeof(double));
     }
   }
   HIPCHECK(h, sync_all(h));
@@ -109,18 +91,7 @@ static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, doub
   // downloads only: uploads from pageable memory already run at 47 GB/s inside the runtime (measured,
   // tools/transfer_rate.py: 35 GB/s through this pipeline)
   if (!to_device && (size_t)ncells * per_cell * sizeof(double) >= ((size_t)16 << 20) && !std::getenv("SEIGEN_HIP_PLAIN_COPY")) {
-    int rc = transfer_pipelined(h, field, cell0, ncells, host, to_device);
-    if (rc != SG_OK) return rc;
-    if (to_device && h->sym && field_is_stress(field)) {
-      int flag = 0;
-      HIPCHECK(h, hipMemcpy(&flag, h->sym_flag, sizeof(int), hipMemcpyDeviceToHost));
-      if (flag) {
-        rc = leave_sym_mode(h);
-        if (rc != SG_OK) return rc;
-        return transfer_pipelined(h, field, cell0, ncells, host, true);
-      }
-    }
-    return SG_OK;
+    return download_pipelined(h, field, cell0, ncells, host);
   }
   if (h->md.gw == 1) {
     double* dev = h->field[field] + (size_t)cell0 * per_cell;

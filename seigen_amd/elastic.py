@@ -281,9 +281,12 @@ class ElasticLF4(object):
             return nz, v[None], True
         t_keep = expr.t
         nz, Xs = [], []
-        for cell0, X in self.S.node_coords_chunks():      # slab by slab: bounded host memory
+        for cell0, X, cells in self._support_scan_chunks(expr):
             idx = np.nonzero(expr.support_mask(X).reshape(-1))[0]
-            nz.append(idx + cell0 * X.shape[1])
+            if cells is None:
+                nz.append(idx + cell0 * X.shape[1])
+            else:                                         # a sub-box of the block: rows of X are the cells `cells`
+                nz.append(cells[idx // X.shape[1]] * X.shape[1] + idx % X.shape[1])
             Xs.append(X.reshape(-1, X.shape[-1])[idx])
         nz, Xs = np.concatenate(nz), np.concatenate(Xs)
         if nsteps * len(nz) * d * d * 8 > self.SOURCE_TABLE_MAX_BYTES:
@@ -296,6 +299,47 @@ class ElasticLF4(object):
             values[k] = expr.evaluate(Xs)
         expr.t = t_keep
         return nz, values, False
+
+    def _support_scan_chunks(self, expr):
+        """Node coordinates to search for the support of a source: the whole block slab by slab (bounded host
+        memory), or - when the expression carries a hint `support_box = (lo, hi)`, the caller's promise that it
+        vanishes outside that box - only the cubes of this rank's block that touch the box (a 128^3-cube P4
+        block has 440 M nodes; a localised source touches a few thousand).  Yields (cell0, X, cells): X
+        [n, nd, dim]; cells = None for n consecutive cells from cell0, else the block-local cell of every row."""
+        box = getattr(expr, "support_box", None)
+        if box is None:
+            for cell0, X in self.S.node_coords_chunks():
+                yield cell0, X, None
+            return
+        import ctypes as C
+        from .functionspace import block_config
+        mesh, part, d = self.mesh, self.mesh.partition, self.dimension
+        ncls = mesh.cells_per_block
+        lo, hi = np.asarray(box[0], dtype=np.float64), np.asarray(box[1], dtype=np.float64)
+        rng = []
+        for a in range(d):
+            o = mesh.origin[a] + part.start[a] * mesh.h[a]
+            i0 = max(int(np.floor((lo[a] - o) / mesh.h[a] - 1e-9)), 0)
+            i1 = min(int(np.floor((hi[a] - o) / mesh.h[a] + 1e-9)), part.n[a] - 1)
+            if i1 < i0:
+                return
+            rng.append((i0, i1 - i0 + 1))
+        cfg = block_config(mesh, self.degree)
+        for a in range(d):
+            cfg.n[a] = rng[a][1]
+            cfg.origin[a] = mesh.origin[a] + (part.start[a] + rng[a][0]) * mesh.h[a]
+        nsub = int(np.prod([r[1] for r in rng])) * ncls
+        X = np.empty((nsub, self.S.nd, d))
+        _lib.check(_lib.load().sg_block_node_coords(C.byref(cfg), self.degree, X.ctypes.data, X.nbytes))
+        # sub-box cube (x fastest) -> block cube -> cell = cube * ncls + class
+        idx = np.indices([r[1] for r in reversed(rng)]).reshape(d, -1)[::-1]        # [axis][sub cube], x fastest
+        cube = np.zeros(idx.shape[1], dtype=np.int64)
+        mul = 1
+        for a in range(d):
+            cube += (idx[a] + rng[a][0]) * mul
+            mul *= part.n[a]
+        cells = (cube[:, None] * ncls + np.arange(ncls)[None, :]).reshape(-1)
+        yield 0, X, cells
 
     # ---- time loop (elastic.py:267-315) ----------------------------------------------------------
     def step_times(self, T):

@@ -122,6 +122,7 @@ class HaloExchanger(object):
         self.timing = bool(timing)
         self.exchanges = 0
         self._wait_host_s = 0.0
+        self._host_blocked_s = 0.0
         self._wait_events = []
         self._wait_dev_ms = 0.0
 
@@ -135,7 +136,7 @@ class HaloExchanger(object):
     def stats(self):
         self._resolve_wait_events()
         return {"exposed_wait_ms": self._wait_dev_ms + 1e3 * self._wait_host_s, "exchanges": self.exchanges,
-                "bytes_sent": self.bytes_sent}
+                "bytes_sent": self.bytes_sent, "host_blocked_ms": 1e3 * self._host_blocked_s}
 
     def start(self, field):
         """Pack the block-side traces of `field` and post the sends / receives."""
@@ -183,11 +184,19 @@ class HaloExchanger(object):
         self.exchanges += 1
         if self.timing and (self.staged or self.stream is None):
             import time
+            # host-staged transport: only the send/receive wait counts as "waited for traces"; the
+            # synchronisation on the copy-out event before it sits behind the FIRST launch, the pack and the
+            # device-to-host copies and is this rank's own work (it is reported separately, host_blocked_ms)
             t0 = time.perf_counter()
+            if self.staged and reqs is not None:
+                reqs.synchronize()
+                reqs = None
+            t1 = time.perf_counter()
             try:
                 return self._finish(kind, reqs)
             finally:
-                self._wait_host_s += time.perf_counter() - t0
+                self._wait_host_s += time.perf_counter() - t1
+                self._host_blocked_s += time.perf_counter() - t0
         if self.timing:
             a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             # the wait only costs what it lasts beyond the SECOND launch that was queued just before it

@@ -145,3 +145,23 @@ def test_bench_one_rank_under_torchrun_with_rccl(gpu):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["value"] > 0
 
+
+
+def test_bench_config4_workload_on_ranks_sharing_one_gpu(gpu):
+    """`bench.py --workload c4` (BASELINE config 4: explosive source, fixed global size, block-split) with a small
+    global mesh on 4 ranks that share the test box's GPU (gloo, host-staged): the line names the workload, reports
+    strong scaling, per-rank step times and the halo block; the source is found through the support-box scan."""
+    r = _launch(4, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c4", "--c4-cubes", "32", "--steps", "3",
+                    "--warmup", "1"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong" and out["value"] > 0
+    assert "config 4" in out["config"]["workload"] and "32^3 cubes" in out["config"]["workload"]
+    assert out["config"]["cells"] == 6 * 32 ** 3 and int(np.prod(out["config"]["block_grid"])) == 4
+    assert len(out["rank_ms_per_step"]["per_rank"]) == 4
+    assert 0 < out["rank_ms_per_step"]["min"] <= out["rank_ms_per_step"]["max"]
+    assert len(out["halo"]["kernel_ms_per_step"]) == 4 and "host_blocked_ms_per_step" in out["halo"]
+    # every stage counted once per step although split stages are two concurrent launches
+    assert sum(out["roofline"]["stage_avg_ms"]) <= out["ms_per_step"] * 1.5

@@ -304,6 +304,9 @@ def test_region_boxes_partition_the_block_for_every_neighbour_mask(dim, n):
     hdr = open(os.path.join(ROOT, "include", "seigen_hip.h")).read()
     max_boxes = int(re.search(r"#define SG_MAX_REGION_BOXES (\d+)", hdr).group(1))
     full = tuple(n) + (1,) * (3 - dim)
+    # group width of the layout such a block gets (degree 1): 2-D blocks run the tile kernels (16), small 3-D and
+    # 1-D blocks the generic kernel (1)
+    gw = 16 if dim == 2 else 1
     for mask in range(1 << (2 * dim)):
         cover = {}
         for region in range(5):
@@ -327,7 +330,21 @@ def test_region_boxes_partition_the_block_for_every_neighbour_mask(dim, n):
             if mask >> (2 * a + 1) & 1:
                 idx[a] = full[a] - 1
                 shell[tuple(idx)] = 1
-        if all(full[a] >= 2 for a in range(dim)):
+        assert (cover[2] >= shell).all(), "BOUNDARY contains every cube with a neighbour block across a face"
+        # Along x the shell is a whole layout group thick where the block's kernels interleave gw cubes of an
+        # x-row per item (handle.hpp shell_width_x): extra cubes lie within gw - 1 of an x side with a neighbour
+        extra = cover[2] - shell
+        if extra.any():
+            assert gw > 1
+            ok = np.zeros(full, dtype=int)
+            if mask & 1:
+                ok[:min(gw, full[0])] = 1
+            if mask & 2:
+                ok[max(full[0] - gw, 0):] = 1
+            assert (extra <= ok).all()
+        elif gw > 1 and (mask & 3) and full[0] > 2:
+            assert False, "an x side with a neighbour block must make a group-thick shell"
+        if all(full[a] >= 2 for a in range(dim)) and gw == 1:
             np.testing.assert_array_equal(cover[2], shell)
         assert (cover[3] >= cover[2]).all(), "FIRST contains the shell"
     if dim == 3 and min(n) >= 3:
@@ -458,3 +475,29 @@ def test_interop_permutation_recovers_a_foreign_numbering(mesh, P):
     with pytest.raises(ValueError):
         dg_permutation(ours.reshape(-1, dim), (theirs + 0.01).reshape(-1, dim), nd)
 
+
+
+def test_bench_watchdog_ends_hung_ranks():
+    """A rank that never comes back (hung init / exchange) must make `bench.py --gpus N` exit non-zero within the
+    stated time: every rank arms faulthandler.dump_traceback_later(--timeout, exit=True); the self-launching parent
+    would kill the process group 30 s later.  No GPU needed: the ranks hang before touching one."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SEIGEN_BENCH_TEST_HANG="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--timeout", "4"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 90
+    assert "Timeout (0:00:04)" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_traffic_digest_follows_the_kernel_sources(tmp_path):
+    """bench.py quotes profiles/*/config3_traffic.json only while seigen_amd/csrc is what was profiled."""
+    import bench
+    d = bench.csrc_digest()
+    assert len(d) == 64 and d == bench.csrc_digest()

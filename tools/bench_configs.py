@@ -36,7 +36,8 @@ def timed(elastic, steps, warmup):
     elastic.setup()
     blk = elastic.block
     if elastic.source:
-        times = [elastic.dt * (k + 1) for k in range(steps + warmup)]
+        # the --stages pass steps another `steps` times: its source must still be active
+        times = [elastic.dt * (k + 1) for k in range(warmup + steps * (2 if STAGES else 1))]
         nodes, values, static = elastic._source_table(times)
         blk.set_source(nodes, values, static=static)
     else:

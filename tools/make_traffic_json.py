@@ -10,6 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmc_summary import summarise  # noqa: E402
 import glob
 
@@ -49,6 +50,8 @@ def main():
         "_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 3 "
                 "--warmup 1` (config 3, 1 GPU, tools/profile_config3.sh); counters are in KB; " + how +
                 ": FETCH_SIZE reads %.4f of the true bytes, WRITE_SIZE %.4f; mean per launch." % (f, w),
+        # which kernels these numbers belong to: bench.py quotes them only while the sources are unchanged
+        "csrc_sha256": __import__("bench").csrc_digest(),
         "fetch_factor": f, "write_factor": w, "kernels": kern}, indent=1))
 
 
