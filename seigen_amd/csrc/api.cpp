@@ -49,6 +49,7 @@ void sg_destroy(sg_handle* h) {
   for (int f = 0; f < 4; ++f)
     if (h->field[f]) (void)hipFree(h->field[f]);
   if (h->md_dev) (void)hipFree(h->md_dev);
+  if (h->mk_dev) (void)hipFree(h->mk_dev);
   if (h->Dt) (void)hipFree(h->Dt);
   if (h->Lt) (void)hipFree(h->Lt);
   if (h->fragF) (void)hipFree(h->fragF);
@@ -178,6 +179,11 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   HIPCHECK(h, hipMemcpy(h->Dt, Dt.data(), Dt.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHECK(h, hipMemcpy(h->Lt, Lt.data(), Lt.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHECK(h, hipMemcpy(h->md_dev, &h->md, sizeof(MeshDev), hipMemcpyHostToDevice));
+  if (h->use_mfma) {
+    const MfmaConst mk = mfma_const(h->md);
+    HIPCHECK(h, hipMalloc((void**)&h->mk_dev, sizeof(MfmaConst)));
+    HIPCHECK(h, hipMemcpy(h->mk_dev, &mk, sizeof(MfmaConst), hipMemcpyHostToDevice));
+  }
 
   for (int f = 0; f < 4; ++f) {
     size_t comps = field_is_stress(f) ? (size_t)d * d : (size_t)d;

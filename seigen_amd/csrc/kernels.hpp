@@ -19,6 +19,30 @@ struct ElemDims {
   static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
 };
 
+// What the MFMA stage kernels need to know about the mesh, laid out for SCALAR loads: everything is uniform over
+// a wave (an item is 16 cells of one class), the per-class part is contiguous (one batch of s_load's at an offset
+// that depends only on the class), and the per-lane node tables are packed four byte entries to a word - lane
+// group q = lane >> 4 extracts row 4 ks + q with one v_bfe.  The first MFMA kernels read these from a copy of
+// MeshDev in LDS: about 45 DEPENDENT ds_read / s_waitcnt round trips per item in front of the first trace load
+// (tools/wave_sim.py, profiles/r03/kernel_experiments.txt) - the lesson of the 2-D tile kernels' T2Const.
+constexpr int MK_KSF = 4;     // facet k-steps at degree 4 (15 facet nodes)
+struct MfmaClassConst {
+  int32_t nb_axis[4], nb_dir[4], nb_cls[4];
+  int32_t slot_ord[4];        // ordinal of the matching facet among the neighbour cube's facets on that side
+  uint32_t nbw[4][MK_KSF];    // [f][ks] byte q: neighbour ELEMENT node matching my facet node 4 ks + q (MeshDev::nb_node)
+  uint32_t nfw[4][MK_KSF];    // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
+};
+struct MfmaConst {
+  int32_t n[3];
+  int32_t halo_per_cube;
+  int32_t has_nbr[6];
+  int32_t pad_[2];
+  int64_t ncube, ncube_pad;
+  uint32_t fw[4][MK_KSF];     // [f][ks] byte q: my element node of facet node 4 ks + q (MeshDev::fnode)
+  MfmaClassConst cls[6];
+};
+MfmaConst mfma_const(const MeshDev& md_host);
+
 struct StageArgs {
   const double* in;    // stress for F, velocity for G           [cell][node][comp]
   double* out;         // result, or in-place target of a fused combine
@@ -28,6 +52,7 @@ struct StageArgs {
   const double* Dt;        // [dim][nd(b)][nd(a)]  transposed Mhat^-1 Shat_r
   const double* Lt;        // [nfaces][nf(b')][nd(a)] transposed facet lifts
   const MeshDev* md;       // device copy
+  const MfmaConst* mk;     // MFMA path: device copy of mfma_const(md)
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null

@@ -217,6 +217,32 @@ struct LaneGeo {
   bool active; // valid and inside the launch's region
 };
 
+typedef __attribute__((address_space(4))) const MfmaConst cMfmaConst;
+typedef __attribute__((address_space(4))) const MfmaClassConst cMfmaClassConst;
+
+__device__ __forceinline__ LaneGeo lane_geo(const cMfmaConst& md, const StageArgs& A, long g, int w) {
+  LaneGeo L;
+  L.c = g * 16 + w;
+  L.valid = L.c < md.ncube;
+  // 32-bit arithmetic: a block has far fewer than 2^31 cubes (288 GB hold about 2^24 of them at
+  // degree 1), and the 64-bit divisions this replaces are some hundred instructions each
+  const unsigned cl = L.valid ? (unsigned)L.c : 0u;
+  const unsigned n0 = (unsigned)md.n[0], n1 = (unsigned)md.n[1];
+  const unsigned t = cl / n0, z = t / n1;
+  L.cc[0] = (int)(cl - t * n0);
+  L.cc[1] = (int)(t - z * n1);
+  L.cc[2] = (int)z;
+  bool in = false;
+  for (int bx = 0; bx < A.nbox; ++bx) {
+    bool ib = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ib = ib && (L.cc[a] >= A.boxes_o[bx][a]) && (L.cc[a] < A.boxes_o[bx][a] + A.boxes_n[bx][a]);
+    in = in || ib;
+  }
+  L.active = L.valid && in;
+  return L;
+}
+
 __device__ __forceinline__ LaneGeo lane_geo(const MeshDev& md, const StageArgs& A, long g, int w) {
   LaneGeo L;
   L.c = g * 16 + w;
@@ -249,6 +275,52 @@ struct NbrRef {
   bool physical;    // domain boundary: no neighbour (p then points at the own cell)
 };
 
+// byte q of a packed node word (MfmaConst): sh = 8 * (lane >> 4)
+__device__ __forceinline__ int word_byte(unsigned w, int sh) { return (int)((w >> sh) & 255u); }
+
+template <int ND, int NF, int NC, typename R_>
+__device__ __forceinline__ NbrRef<R_> nbr_ref(const cMfmaConst& md, const cMfmaClassConst& kc, const StageArgs& A,
+                                              const LaneGeo& L, long g, int k, int f, int w, const R_* own_base) {
+  NbrRef<R_> R;
+  const R_* const fin = reinterpret_cast<const R_*>(A.in);
+  R.p = own_base;
+  R.cstride = 16;
+  R.ghost = false;
+  R.physical = false;
+#ifdef SG_EXP_NOTRACE  // timing experiment only (wrong results): every trace read hits the own cell
+  R.physical = true;
+  return R;
+#endif
+  const int axis = kc.nb_axis[f];      // scalar loads: wave-uniform
+  const int kn = kc.nb_cls[f];
+  if (axis < 0) {
+    R.p = fin + ((g * 6 + kn) * (long)ND) * NC * 16 + w;
+    return R;
+  }
+  const int dir = kc.nb_dir[f];
+  const int cax = axis == 0 ? L.cc[0] : (axis == 1 ? L.cc[1] : L.cc[2]);
+  const int nax = axis == 0 ? md.n[0] : (axis == 1 ? md.n[1] : md.n[2]);
+  const int cn = cax + dir;
+  const bool inside = L.valid && cn >= 0 && cn < nax;
+  const long stride = (axis == 0) ? 1 : (axis == 1) ? md.n[0] : (long)md.n[0] * md.n[1];
+  const long nc = inside ? L.c + dir * stride : L.c;
+  const R_* pin = fin + (((nc >> 4) * 6 + (inside ? kn : k)) * (long)ND) * NC * 16 + (nc & 15);
+  const int side = 2 * axis + (dir > 0 ? 1 : 0);
+  if (!inside && L.valid && md.has_nbr[side]) {
+    long c2 = (axis == 0) ? (L.cc[1] + (long)md.n[1] * L.cc[2])
+                          : (axis == 1) ? (L.cc[0] + (long)md.n[0] * L.cc[2]) : (L.cc[0] + (long)md.n[0] * L.cc[1]);
+    long slot = c2 * md.halo_per_cube + kc.slot_ord[f];
+    R.p = reinterpret_cast<const R_*>(A.ghost[side]) + slot * NF * 3;  // packed trace: 3 comps per facet node (velocity, or T_i,axis)
+    R.cstride = 1;
+    R.ghost = true;
+    return R;
+  }
+  R.p = pin;
+  R.physical = !inside;
+  return R;
+}
+
+// the same from the LDS copy of MeshDev (G kernels: their register budget has no room for the scalar path's selects)
 template <int ND, int NF, int NC, typename R_>
 __device__ __forceinline__ NbrRef<R_> nbr_ref(const MeshDev& md, const StageArgs& A, const LaneGeo& L, long g, int k, int f,
                                               int w, const R_* own_base) {
@@ -354,6 +426,13 @@ __device__ __forceinline__ void copy_to_lds(R* dst, const R* __restrict__ src) {
 }
 
 template <int NV, int NL, typename R>
+__device__ __forceinline__ void load_tables(R* sAV, R* sAL, const StageArgs& A) {
+  copy_to_lds<NV * 64>(sAV, reinterpret_cast<const R*>(A.fragV));
+  copy_to_lds<NL * 64>(sAL, reinterpret_cast<const R*>(A.fragL));
+  __syncthreads();
+}
+
+template <int NV, int NL, typename R>
 __device__ __forceinline__ void load_tables(R* sAV, R* sAL, MeshDev* sMd, const StageArgs& A) {
   const int* src = reinterpret_cast<const int*>(A.md);
   int* dst = reinterpret_cast<int*>(sMd);
@@ -453,7 +532,11 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
 #pragma unroll
       for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = R(0);
 
-    R nx[2][KSF][3];  // neighbour traces: facet f in nx[f & 1], facet f + 1 on its way into the other
+#ifndef SG_GNBUF
+#define SG_GNBUF 2
+#endif
+    constexpr int NB = SG_GNBUF;   // trace buffers: facet f in nx[f % NB], the next NB - 1 facets on their way
+    R nx[NB][KSF][3];
     auto request = [&](int f, R (&dst)[KSF][3]) {
       const NbrRef<R> NR = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
 #pragma unroll
@@ -559,15 +642,16 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
     //      requested before the last tile pass.  Row tile t covers the row-quads m = 4t .. 4t+3
     //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
     {
-      request(0, nx[0]);
+#pragma unroll
+      for (int f0 = 0; f0 < NB - 1; ++f0) request(f0, nx[f0]);
       SG_PRIO(SG_PRIO_LIFT);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        R(&flf)[KSF][3] = nx[f & 1];
+        R(&flf)[KSF][3] = nx[f % NB];
 #pragma unroll
         for (int t = 0; t < MTT; ++t) {
           // next facet's traces: asked for a whole facet ahead
-          if (t == 0 && f + 1 < 4) request(f + 1, nx[(f + 1) & 1]);
+          if (t == 0 && f + NB - 1 < 4) request(f + NB - 1, nx[(f + NB - 1) % NB]);
           // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
           auto fold = [&](int m0, int nm, const R (&v)[3][4]) {
 #pragma unroll
@@ -746,8 +830,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
   __shared__ R sAV[M::NFRAG_F * 64];
   __shared__ R sAL[M::NFRAG_L * 64];
-  __shared__ MeshDev sMd;
-  load_tables<M::NFRAG_F, M::NFRAG_L>(sAV, sAL, &sMd, A);
+  load_tables<M::NFRAG_F, M::NFRAG_L>(sAV, sAL, A);
+  const cMfmaConst& mk = *(const cMfmaConst*)(unsigned long long)A.mk;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -758,10 +842,21 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
   R* __restrict__ out = reinterpret_cast<R*>(A.out);
   const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
-  const long ngroups = sMd.ncube_pad >> 4;
+  const long ngroups = mk.ncube_pad >> 4;
   const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
 
   STAMP_DECL;
+#ifndef SG_XPF
+#define SG_XPF 0
+#endif
+  // Cross-item prefetch (SG_XPF): the own rows of the NEXT item's first k-step are requested when this item's lift
+  // phase begins - half an item before they are needed - so that an item does not open with a full memory latency
+  // in front of its first matrix instruction.  Measured: no gain (8.17-8.20 against 8.17-8.19 ms/step,
+  // profiles/r03/kernel_experiments.txt) - the SIMD's other wave already covers that latency; off by default.
+  R Tnext[9];
+  long pf_item = -1;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Tnext[c] = R(0);
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
     const long iti = item_of(ir, it);
@@ -769,7 +864,9 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     const long item = A.item_list ? (long)A.item_list[iti] : iti;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
-    const LaneGeo L = lane_geo(sMd, A, g, w);
+    const LaneGeo L = lane_geo(mk, A, g, w);
+    const cMfmaClassConst& kc = mk.cls[k];
+    const int qsh = q * 8;
     if (!__any(L.active)) continue;
     const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
     int qo = q * 9 * 16;  // B rows: see mfma_stage_G
@@ -817,8 +914,14 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #endif
         constexpr int PFV = sizeof(R) == 4 ? 2 : SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
         R Tq[PFV][9];
+        if (SG_XPF && __builtin_amdgcn_readfirstlane(pf_item == item ? 1 : 0)) {
 #pragma unroll
-        for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
+          for (int c = 0; c < 9; ++c) Tq[0][c] = Tnext[c];
+        } else {
+          load_tensor<SYM>(brow(0), 16, Tq[0]);
+        }
+#pragma unroll
+        for (int s0 = 1; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           R T[9];
@@ -865,16 +968,15 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       int fax[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const NbrRef<R> NR = nbr_ref<ND, NF, 9>(sMd, A, L, g, k, f, w, own);
+        const NbrRef<R> NR = nbr_ref<ND, NF, 9>(mk, kc, A, L, g, k, f, w, own);
         np[f] = NR.p;
         gh[f] = GHOST && NR.ghost;
-        fax[f] = GHOST ? __builtin_amdgcn_readfirstlane(sMd.nb_axis[k][f]) : 0;
+        fax[f] = GHOST ? kc.nb_axis[f] : 0;
         wf[f] = NR.physical ? R(-1) : R(1);
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks) {
-          const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;
-          const int on = sMd.fnode[f][bb];
-          const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
+          const int on = word_byte(mk.fw[f][ks], qsh);
+          const int nn = NR.ghost ? word_byte(kc.nfw[f][ks], qsh) : (NR.physical ? on : word_byte(kc.nbw[f][ks], qsh));
           noff[f][ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
         }
       }
@@ -927,6 +1029,17 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #else
     do_volume();
     STAMP(st2);
+    if (SG_XPF && KS > 1) {
+      // the next item of this wave (same mapping as the loop header); inactive or missing items are simply not used
+      const long itn = it + ir.step;
+      long nitem = -1;
+      if (itn < ir.hi) {
+        const long in2 = item_of(ir, itn);
+        if (in2 >= 0) nitem = A.item_list ? (long)A.item_list[in2] : in2;
+      }
+      pf_item = nitem;
+      if (nitem >= 0) load_tensor<SYM>(in + (nitem * (long)ND) * 9 * 16 + w + qo, 16, Tnext);
+    }
     SG_PRIO(SG_PRIO_LIFT);
     do_lifts();
 #endif

@@ -1,5 +1,9 @@
 #include "mfma_tables.hpp"
 
+#include <cstring>
+
+#include "kernels.hpp"
+
 #include <cstddef>
 using std::size_t;
 
@@ -155,6 +159,43 @@ std::vector<double> tile2d_frags_L(const RefElem& re) {
         }
       }
   return out;
+}
+
+
+MfmaConst mfma_const(const MeshDev& md) {
+  MfmaConst c;
+  std::memset(&c, 0, sizeof(c));
+  for (int a = 0; a < 3; ++a) c.n[a] = md.n[a];
+  c.halo_per_cube = md.halo_per_cube;
+  for (int s = 0; s < 6; ++s) c.has_nbr[s] = md.has_nbr[s];
+  c.ncube = md.ncube;
+  c.ncube_pad = md.ncube_pad;
+  const int nf = md.nf;
+  auto pack = [&](const uint8_t* row, int ks) {
+    uint32_t w = 0;
+    for (int q = 0; q < 4; ++q) {
+      const int bb = (4 * ks + q < nf) ? 4 * ks + q : 0;   // padded rows repeat facet node 0 (they meet zero lift columns)
+      w |= (uint32_t)row[bb] << (8 * q);
+    }
+    return w;
+  };
+  for (int f = 0; f < 4; ++f)
+    for (int ks = 0; ks < MK_KSF; ++ks) c.fw[f][ks] = pack(md.fnode[f], ks);
+  for (int k = 0; k < 6; ++k) {
+    MfmaClassConst& kc = c.cls[k];
+    for (int f = 0; f < 4; ++f) {
+      kc.nb_axis[f] = md.nb_axis[k][f];
+      kc.nb_dir[f] = md.nb_dir[k][f];
+      kc.nb_cls[f] = md.nb_cls[k][f];
+      const int kn = md.nb_cls[k][f], fn = md.nb_face[k][f];
+      kc.slot_ord[f] = (kn >= 0 && kn < MAX_CLS && fn >= 0 && fn < MAX_FACES) ? md.face_ord[kn][fn] : 0;
+      for (int ks = 0; ks < MK_KSF; ++ks) {
+        kc.nbw[f][ks] = pack(md.nb_node[k][f], ks);
+        kc.nfw[f][ks] = pack(md.nb_fnode[k][f], ks);
+      }
+    }
+  }
+  return c;
 }
 
 }  // namespace sg

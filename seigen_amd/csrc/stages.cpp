@@ -87,6 +87,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.Dt = h->Dt;
   a.Lt = h->Lt;
   a.md = h->md_dev;
+  a.mk = h->mk_dev;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
   a.sym = h->sym ? 1 : 0;

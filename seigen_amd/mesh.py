@@ -15,23 +15,39 @@ import numpy as np
 
 
 def _factor_grid(world, dim, n):
-    """Process grid for `world` ranks: split the longest axes first."""
-    grid = [1] * dim
-    w = world
-    p = 2
-    factors = []
-    while w > 1:
-        while w % p == 0:
-            factors.append(p)
-            w //= p
-        p += 1
-    for f in sorted(factors, reverse=True):
-        # axis with the most cells per block left; on ties the slowest-varying one.  In 3-D the
-        # x axis is split last (weight 1/4): the MFMA layout interleaves 16 consecutive cubes along
-        # x, so a block side normal to x makes boundary groups that use 1 lane in 16.
-        ax = max(range(dim), key=lambda a: (n[a] / grid[a] * (0.25 if (dim == 3 and a == 0) else 1.0), a))
-        grid[ax] *= f
-    return tuple(grid)
+    """Process grid for `world` ranks: the factorisation whose blocks have the smallest halo (facet-trace)
+    surface per rank - 2 x 2 x 2 for eight ranks on a cube.  A block side normal to x costs no more
+    than the others since the shell next to it is made of whole layout groups (csrc/handle.hpp shell_width_x;
+    profiles/r03/launch_structure_one_device.txt); ties go to the grid with fewer cuts along x, then y (the x
+    shell is 16 cubes thick, which leaves less of the block to the launch that overlaps the exchange)."""
+    def grids(w, d):
+        if d == 1:
+            yield (w,)
+            return
+        for g in range(1, w + 1):
+            if w % g == 0:
+                for rest in grids(w // g, d - 1):
+                    yield (g,) + rest
+
+    best = None
+    for grid in grids(world, dim):
+        if any(grid[a] > n[a] for a in range(dim)):
+            continue
+        blk = [-(-n[a] // grid[a]) for a in range(dim)]                 # the largest block
+        area = 0
+        for a in range(dim):
+            if grid[a] > 1:
+                face = 1
+                for b in range(dim):
+                    if b != a:
+                        face *= blk[b]
+                area += face * (2 if grid[a] > 2 else 1)                 # an inner block has both sides
+        key = (area,) + tuple(grid)
+        if best is None or key < best[0]:
+            best = (key, grid)
+    if best is None:
+        raise ValueError("more ranks than cells")
+    return tuple(best[1])
 
 
 class Partition(object):

@@ -205,13 +205,17 @@ def test_halo_exchange_world4_2d_grid():
 
 def test_halo_exchange_world8_bench_grid():
     """The 8-rank layout of `bench.py --gpus 8` (the driver's scaling run): the process grid that
-    mesh._factor_grid picks for a cubic weak-scaling mesh - x is never split (1 x 2 x 4), interior ranks have three
-    face neighbours - driven through the real exchanger with gloo point-to-point calls on eight CPU processes."""
+    mesh._factor_grid picks for a cubic weak-scaling mesh and for config 4's 256^3 cubes - 2 x 2 x 2, the smallest
+    halo surface, every rank has three face neighbours - driven through the real exchanger with gloo
+    point-to-point calls on eight CPU processes; and the 1 x 2 x 4 grid of rounds 1-2 next to it."""
     import torch.multiprocessing as mp
     from seigen_amd.mesh import _factor_grid
     n = 64
     grid = _factor_grid(8, 3, (n, n, n))
     gn = tuple(n * g for g in grid)
-    assert _factor_grid(8, 3, gn) == grid == (1, 2, 4)          # what bench.py builds: Partition(gn, rank, 8, grid)
+    assert _factor_grid(8, 3, gn) == grid == (2, 2, 2)          # what bench.py builds: Partition(gn, rank, 8, grid)
+    assert _factor_grid(8, 3, (256, 256, 256)) == (2, 2, 2)     # config 4: 128^3 blocks
     assert _factor_grid(2, 3, (n, n, n)) == (1, 1, 2) and _factor_grid(4, 3, (n, n, n)) == (1, 2, 2)
-    mp.spawn(_worker, args=(8, _free_port(), 3, (2, 4, 8), 1, grid), nprocs=8, join=True)
+    assert _factor_grid(8, 3, (16, 64, 64)) == (1, 2, 4) and _factor_grid(6, 2, (4, 100)) == (1, 6)
+    mp.spawn(_worker, args=(8, _free_port(), 3, (4, 4, 4), 1, grid), nprocs=8, join=True)
+    mp.spawn(_worker, args=(8, _free_port(), 3, (2, 4, 8), 1, (1, 2, 4)), nprocs=8, join=True)
