@@ -263,7 +263,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   {
     const char* ge = std::getenv("SEIGEN_HIP_GRAPH");  // 0/1 overrides (measurements)
     const int64_t dofs = h->ncells * (int64_t)h->re.nd * (cfg->dim + cfg->dim * cfg->dim);
-    h->graph_ok = ge ? (std::strcmp(ge, "0") != 0) : (!h->use_mfma && dofs <= (int64_t)1 << 23);
+    h->graph_ok = ge ? (std::strcmp(ge, "0") != 0) : (dofs <= (int64_t)1 << 23);
   }
   {
     const char* ov = std::getenv("SEIGEN_HIP_OVERLAP");

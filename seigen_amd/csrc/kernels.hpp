@@ -83,6 +83,7 @@ struct StageArgs {
   // (0: one contiguous eighth of the items per XCD).  With a chunk of 1/8 of a z-layer all XCDs sweep the block layer by
   // layer together, so the z-neighbour traces and the own rows of the next layer meet in the Infinity Cache.
   int32_t order_chunk;
+  int32_t nitems;               // MFMA path: items of this launch (the item list's length, or cell groups x classes)
   // 2-D tile path, G stages: the sparse nodal source (elastic.py:217-218) added inside the stage kernel instead of
   // by a launch of its own.  src_slot[item] = slot of an item (16 cells of one class) that holds source nodes, or -1;
   // src_idx[slot][node][cell] = row of that node in this step's value table src_vals[row][dim*dim], or -1.

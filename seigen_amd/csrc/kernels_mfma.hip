@@ -1173,7 +1173,14 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 template <typename R, int P, int SYM>
 static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
   // persistent grid, at most 2 blocks per CU; a multiple of 8 (one item range per XCD label)
-  const dim3 grid((unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512)), block(256);
+  // ... and no more blocks than there are items for their four waves (small blocks - the reference's own 3-D sweeps run
+  // N <= 8 - are launch-bound: every block copies the operator tiles into LDS before its first item)
+  unsigned nblk = (unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512);
+  if (a.nitems > 0 && !a.spread) {
+    const unsigned need = (((unsigned)a.nitems + 3u) / 4u + 7u) / 8u * 8u;
+    nblk = need < nblk ? need : nblk;
+  }
+  const dim3 grid(nblk), block(256);
   if (kind == 0) {
     // blocks without neighbour blocks never meet a packed remote trace: GHOST = 0 instantiation
     bool ghosts = false;

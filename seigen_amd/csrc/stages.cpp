@@ -163,6 +163,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       a.item_list = list;
       a.nlist = nlist;
     }
+    a.nitems = a.item_list ? a.nlist : (int32_t)std::min<int64_t>((h->md.ncube_pad / h->md.gw) * h->ncls, INT32_MAX);
     int rc = h->use_mfma   ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
              : h->use_tile ? launch_stage_tile2d(kind, h->cfg.degree, a, h->t2c, (long)(h->md.ncube_pad / 16) * h->ncls, h->stream)
                            : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
