@@ -50,6 +50,7 @@ void sg_destroy(sg_handle* h) {
     if (h->field[f]) (void)hipFree(h->field[f]);
   if (h->md_dev) (void)hipFree(h->md_dev);
   if (h->mk_dev) (void)hipFree(h->mk_dev);
+  if (h->nbr_tab) (void)hipFree(h->nbr_tab);
   if (h->Dt) (void)hipFree(h->Dt);
   if (h->Lt) (void)hipFree(h->Lt);
   if (h->fragF) (void)hipFree(h->fragF);
@@ -70,10 +71,12 @@ void sg_destroy(sg_handle* h) {
     unsigned long long v[32];
     if (hipMemcpy(v, h->dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
       for (int k = 0; k < 4; ++k)
-        std::fprintf(stderr, "[seigen_hip stamps] %s mode %d: items %llu  cycles/item: setup %.0f volume %.0f lifts %.0f epilogue %.0f\n",
+        std::fprintf(stderr, "[seigen_hip stamps] %s mode %d: items %llu  cycles/item: setup %.0f volume %.0f lifts %.0f epilogue %.0f"
+                             "   (lifts: neighbour set-up %.0f, facet 0 %.0f, facets 1-3 %.0f)\n",
                      k < 2 ? "F" : "G", k & 1, v[8 * k + 4], v[8 * k + 4] ? (double)v[8 * k + 0] / v[8 * k + 4] : 0.0,
                      v[8 * k + 4] ? (double)v[8 * k + 1] / v[8 * k + 4] : 0.0, v[8 * k + 4] ? (double)v[8 * k + 2] / v[8 * k + 4] : 0.0,
-                     v[8 * k + 4] ? (double)v[8 * k + 3] / v[8 * k + 4] : 0.0);
+                     v[8 * k + 4] ? (double)v[8 * k + 3] / v[8 * k + 4] : 0.0, v[8 * k + 4] ? (double)v[8 * k + 5] / v[8 * k + 4] : 0.0,
+                     v[8 * k + 4] ? (double)v[8 * k + 6] / v[8 * k + 4] : 0.0, v[8 * k + 4] ? (double)v[8 * k + 7] / v[8 * k + 4] : 0.0);
     (void)hipFree(h->dbg);
   }
   if (h->lam_d) (void)hipFree(h->lam_d);
@@ -183,6 +186,14 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     const MfmaConst mk = mfma_const(h->md);
     HIPCHECK(h, hipMalloc((void**)&h->mk_dev, sizeof(MfmaConst)));
     HIPCHECK(h, hipMemcpy(h->mk_dev, &mk, sizeof(MfmaConst), hipMemcpyHostToDevice));
+    if ((h->md.ncube_pad / 16) * 6 * 16 >= ((int64_t)1 << 31))     // cell slots are int32 (288 GB hold far fewer cells)
+      return fail(h, SG_ERR_ARG, "block too large for the MFMA path's neighbour table");
+    {
+      std::vector<int32_t> tab;
+      build_nbr_table(h->md, tab);
+      HIPCHECK(h, hipMalloc((void**)&h->nbr_tab, tab.size() * sizeof(int32_t)));
+      HIPCHECK(h, hipMemcpy(h->nbr_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
   }
 
   for (int f = 0; f < 4; ++f) {

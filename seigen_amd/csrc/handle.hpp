@@ -90,6 +90,7 @@ struct sg_handle {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_stage = nullptr, ev_second = nullptr;
   bool second_pending = false;
+  int32_t* nbr_tab = nullptr;   // MFMA path: per-item neighbour table (StageArgs::nbr_tab)
   MfmaConst* mk_dev = nullptr;  // MFMA path: scalar-load copy of the mesh constants (kernels.hpp MfmaConst)
   int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
   int order_chunk = 0;  // MFMA path: items per XCD chunk of whole-block launches (StageArgs::order_chunk)

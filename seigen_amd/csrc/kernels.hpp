@@ -1,6 +1,7 @@
 // Launch interface between the C-ABI host code (api.cpp, transfer.cpp, stages.cpp) and the HIP kernels.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "mesh_tables.hpp"
 
@@ -42,6 +43,8 @@ struct MfmaConst {
   MfmaClassConst cls[6];
 };
 MfmaConst mfma_const(const MeshDev& md_host);
+// [item = cell group * 6 + class][lane 0..15][facet 0..3] (see StageArgs::nbr_tab); (ncube_pad / 16) * 6 * 64 entries
+void build_nbr_table(const MeshDev& md_host, std::vector<int32_t>& tab);
 
 struct StageArgs {
   const double* in;    // stress for F, velocity for G           [cell][node][comp]
@@ -53,6 +56,13 @@ struct StageArgs {
   const double* Lt;        // [nfaces][nf(b')][nd(a)] transposed facet lifts
   const MeshDev* md;       // device copy
   const MfmaConst* mk;     // MFMA path: device copy of mfma_const(md)
+  // MFMA path: where every cell finds its four facet neighbours, tabulated once per block (mfma_tables.cpp
+  // build_nbr_table): nbr_tab[(item * 16 + lane) * 4 + f] = the neighbour's cell slot (cell group * 16 * 6 ... see
+  // there), -1 on the domain boundary, -2 - s for slot s of the packed remote trace of that block side.  Replaces
+  // the per-item recomputation (cube coordinates by division, neighbour class / axis / direction look-ups, bounds
+  // tests): 256 B per item read with one 16-byte load per lane, against 76 KB of cell data.
+  const int32_t* nbr_tab;
+  int32_t all_active;      // the launch covers the whole block (no region boxes to test)
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null

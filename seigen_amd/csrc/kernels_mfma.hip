@@ -89,13 +89,14 @@ struct MG {
 // The lift phase is the one that waits for memory (neighbour traces) and has little matrix work per load; the volume
 // phase has matrix work in abundance.  With the lifts ABOVE the volume a wave in its lifts gets its few matrix
 // instructions issued the moment their operands arrive and the SIMD's other wave fills the gaps from its volume
-// phase, instead of both waves queueing at equal priority: round 2's 0x330 -> 0x120 / 0x230 is 2-4 % on the step
-// (profiles/r03/priority_sweep.txt: plain stages 1.22-1.28 -> 1.17-1.20 ms; the fused G stage does not care).
+// phase, instead of both waves queueing at equal priority: round 2's 0x330 -> 0x120 is 2-4 % on the step
+// (profiles/r03/priority_sweep.txt: plain stages 1.22-1.28 -> 1.17-1.20 ms; the fused G stage does not care; the
+// fused F stage, bandwidth-bound, wants the opposite order once the neighbours come from the table: 0x320).
 #ifndef SG_PRIO_F0
 #define SG_PRIO_F0 0x120
 #endif
 #ifndef SG_PRIO_F1
-#define SG_PRIO_F1 0x230
+#define SG_PRIO_F1 0x320
 #endif
 #ifndef SG_PRIO_G0
 #define SG_PRIO_G0 0x120
@@ -118,13 +119,14 @@ struct MG {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");       \
     __builtin_amdgcn_sched_barrier(0);                                             \
   } while (0)
-#define STAMP_DECL unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sacc[4] = {0, 0, 0, 0}, sitems = 0
+#define STAMP_DECL unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sta = 0, stb = 0, sacc[4] = {0, 0, 0, 0}, ssub[3] = {0, 0, 0}, sitems = 0
 #define STAMP_ACC                                                                  \
   do {                                                                             \
     sacc[0] += st1 - st0;                                                          \
     sacc[1] += st2 - st1;                                                          \
     sacc[2] += st3 - st2;                                                          \
     sacc[3] += st4 - st3;                                                          \
+    if (sta) { ssub[0] += sta - st2; ssub[1] += stb - sta; ssub[2] += st3 - stb; } \
     sitems += 1;                                                                   \
   } while (0)
 #define STAMP_FLUSH                                                                \
@@ -132,6 +134,7 @@ struct MG {
     if (A.dbg && lane == 0) {                                                      \
       for (int z = 0; z < 4; ++z) atomicAdd(&A.dbg[z], sacc[z]);                   \
       atomicAdd(&A.dbg[4], sitems);                                                \
+      for (int z = 0; z < 3; ++z) atomicAdd(&A.dbg[5 + z], ssub[z]);               \
     }                                                                              \
   } while (0)
 #else
@@ -278,86 +281,44 @@ struct NbrRef {
 // byte q of a packed node word (MfmaConst): sh = 8 * (lane >> 4)
 __device__ __forceinline__ int word_byte(unsigned w, int sh) { return (int)((w >> sh) & 255u); }
 
-template <int ND, int NF, int NC, typename R_>
-__device__ __forceinline__ NbrRef<R_> nbr_ref(const cMfmaConst& md, const cMfmaClassConst& kc, const StageArgs& A,
-                                              const LaneGeo& L, long g, int k, int f, int w, const R_* own_base) {
-  NbrRef<R_> R;
-  const R_* const fin = reinterpret_cast<const R_*>(A.in);
-  R.p = own_base;
-  R.cstride = 16;
-  R.ghost = false;
-  R.physical = false;
-#ifdef SG_EXP_NOTRACE  // timing experiment only (wrong results): every trace read hits the own cell
-  R.physical = true;
-  return R;
-#endif
-  const int axis = kc.nb_axis[f];      // scalar loads: wave-uniform
-  const int kn = kc.nb_cls[f];
-  if (axis < 0) {
-    R.p = fin + ((g * 6 + kn) * (long)ND) * NC * 16 + w;
-    return R;
-  }
-  const int dir = kc.nb_dir[f];
-  const int cax = axis == 0 ? L.cc[0] : (axis == 1 ? L.cc[1] : L.cc[2]);
-  const int nax = axis == 0 ? md.n[0] : (axis == 1 ? md.n[1] : md.n[2]);
-  const int cn = cax + dir;
-  const bool inside = L.valid && cn >= 0 && cn < nax;
-  const long stride = (axis == 0) ? 1 : (axis == 1) ? md.n[0] : (long)md.n[0] * md.n[1];
-  const long nc = inside ? L.c + dir * stride : L.c;
-  const R_* pin = fin + (((nc >> 4) * 6 + (inside ? kn : k)) * (long)ND) * NC * 16 + (nc & 15);
-  const int side = 2 * axis + (dir > 0 ? 1 : 0);
-  if (!inside && L.valid && md.has_nbr[side]) {
-    long c2 = (axis == 0) ? (L.cc[1] + (long)md.n[1] * L.cc[2])
-                          : (axis == 1) ? (L.cc[0] + (long)md.n[0] * L.cc[2]) : (L.cc[0] + (long)md.n[0] * L.cc[1]);
-    long slot = c2 * md.halo_per_cube + kc.slot_ord[f];
-    R.p = reinterpret_cast<const R_*>(A.ghost[side]) + slot * NF * 3;  // packed trace: 3 comps per facet node (velocity, or T_i,axis)
-    R.cstride = 1;
-    R.ghost = true;
-    return R;
-  }
-  R.p = pin;
-  R.physical = !inside;
-  return R;
+// Whole-block launches test no region boxes: the cube coordinates (two integer divisions per lane) are not needed
+__device__ __forceinline__ LaneGeo lane_geo_all(long ncube, long g, int w) {
+  LaneGeo L;
+  L.c = g * 16 + w;
+  L.valid = L.c < ncube;
+  L.cc[0] = L.cc[1] = L.cc[2] = 0;
+  L.active = L.valid;
+  return L;
 }
 
-// the same from the LDS copy of MeshDev (G kernels: their register budget has no room for the scalar path's selects)
+// The four neighbours of this lane's cell from the block's table (StageArgs::nbr_tab): one 16-byte load per lane
+typedef int nbr4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ nbr4 load_nbr4(const StageArgs& A, long item, int w) {
+  return *reinterpret_cast<const nbr4*>(A.nbr_tab + (item * 16 + w) * 4);
+}
+// e: table entry of facet f; side: block side the facet crosses (wave-uniform; only used for a remote trace)
 template <int ND, int NF, int NC, typename R_>
-__device__ __forceinline__ NbrRef<R_> nbr_ref(const MeshDev& md, const StageArgs& A, const LaneGeo& L, long g, int k, int f,
-                                              int w, const R_* own_base) {
+__device__ __forceinline__ NbrRef<R_> nbr_from_entry(const StageArgs& A, int e, int side, const R_* own_base) {
   NbrRef<R_> R;
   const R_* const fin = reinterpret_cast<const R_*>(A.in);
-  R.p = own_base;
   R.cstride = 16;
-  R.ghost = false;
-  R.physical = false;
+  R.ghost = e < -1;
+  R.physical = e == -1;
 #ifdef SG_EXP_NOTRACE  // timing experiment only (wrong results): every trace read hits the own cell
+  R.p = own_base;
+  R.ghost = false;
   R.physical = true;
   return R;
 #endif
-  const int axis = md.nb_axis[k][f];
-  const int kn = md.nb_cls[k][f];
-  if (axis < 0) {
-    R.p = fin + ((g * 6 + kn) * (long)ND) * NC * 16 + w;
-    return R;
+  const long slot = e < 0 ? 0 : e;
+  const R_* pin = fin + ((slot >> 4) * (long)ND) * NC * 16 + (slot & 15);
+  R.p = e < 0 ? own_base : pin;
+  if (__any(R.ghost)) {        // blocks with neighbour blocks only, and there only the shell items
+    if (R.ghost) {
+      R.p = reinterpret_cast<const R_*>(A.ghost[side]) + (long)(-2 - e) * NF * 3;
+      R.cstride = 1;
+    }
   }
-  const int dir = md.nb_dir[k][f];
-  const int cn = L.cc[axis] + dir;
-  const bool inside = L.valid && cn >= 0 && cn < md.n[axis];
-  const long stride = (axis == 0) ? 1 : (axis == 1) ? md.n[0] : (long)md.n[0] * md.n[1];
-  const long nc = inside ? L.c + dir * stride : L.c;
-  const R_* pin = fin + (((nc >> 4) * 6 + (inside ? kn : k)) * (long)ND) * NC * 16 + (nc & 15);
-  const int side = 2 * axis + (dir > 0 ? 1 : 0);
-  if (!inside && L.valid && md.has_nbr[side]) {
-    long c2 = (axis == 0) ? (L.cc[1] + (long)md.n[1] * L.cc[2])
-                          : (axis == 1) ? (L.cc[0] + (long)md.n[0] * L.cc[2]) : (L.cc[0] + (long)md.n[0] * L.cc[1]);
-    long slot = c2 * md.halo_per_cube + md.face_ord[kn][md.nb_face[k][f]];
-    R.p = reinterpret_cast<const R_*>(A.ghost[side]) + slot * NF * 3;  // packed trace: 3 comps per facet node (velocity, or T_i,axis)
-    R.cstride = 1;
-    R.ghost = true;
-    return R;
-  }
-  R.p = pin;
-  R.physical = !inside;
   return R;
 }
 
@@ -498,7 +459,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
     const long item = A.item_list ? (long)A.item_list[iti] : iti;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
-    const LaneGeo L = lane_geo(sMd, A, g, w);
+    const LaneGeo L = A.all_active ? lane_geo_all(sMd.ncube, g, w) : lane_geo(sMd, A, g, w);
+    const nbr4 nbe = load_nbr4(A, item, w);
     if (!__any(L.active)) continue;
     const R* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
     // B row of this lane at k-step ks = node 4 ks + q: one pointer per item plus compile-time
@@ -538,7 +500,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
     constexpr int NB = SG_GNBUF;   // trace buffers: facet f in nx[f % NB], the next NB - 1 facets on their way
     R nx[NB][KSF][3];
     auto request = [&](int f, R (&dst)[KSF][3]) {
-      const NbrRef<R> NR = nbr_ref<ND, NF, 3>(sMd, A, L, g, k, f, w, own);
+      const NbrRef<R> NR = nbr_from_entry<ND, NF, 3>(A, nbe[f], 2 * sMd.nb_axis[k][f] + (sMd.nb_dir[k][f] > 0 ? 1 : 0), own);
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
         const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
@@ -864,9 +826,14 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     const long item = A.item_list ? (long)A.item_list[iti] : iti;
     const long g = item / 6;
     const int k = (int)(item - g * 6);
-    const LaneGeo L = lane_geo(mk, A, g, w);
+    const LaneGeo L = A.all_active ? lane_geo_all(mk.ncube, g, w) : lane_geo(mk, A, g, w);
     const cMfmaClassConst& kc = mk.cls[k];
     const int qsh = q * 8;
+#ifndef SG_NBE_LATE
+#define SG_NBE_LATE 0
+#endif
+    nbr4 nbe = {0, 0, 0, 0};
+    if (!((SG_NBE_LATE >> MODE) & 1)) nbe = load_nbr4(A, item, w);
     if (!__any(L.active)) continue;
     const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
     int qo = q * 9 * 16;  // B rows: see mfma_stage_G
@@ -966,9 +933,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       int noff[4][KSF];
       bool gh[4];
       int fax[4];
+      if ((SG_NBE_LATE >> MODE) & 1) nbe = load_nbr4(A, item, w);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const NbrRef<R> NR = nbr_ref<ND, NF, 9>(mk, kc, A, L, g, k, f, w, own);
+        const NbrRef<R> NR = nbr_from_entry<ND, NF, 9>(A, nbe[f], 2 * kc.nb_axis[f] + (kc.nb_dir[f] > 0 ? 1 : 0), own);
         np[f] = NR.p;
         gh[f] = GHOST && NR.ghost;
         fax[f] = GHOST ? kc.nb_axis[f] : 0;
@@ -981,6 +949,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
         }
       }
       R nq[PFL][9];
+      STAMP(sta);   // diagnostic builds: end of the neighbour set-up
       {
         constexpr int NS = 4 * KSF;
 #pragma unroll
@@ -988,6 +957,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
           load_trace<SYM, GHOST>(np[s / KSF] + noff[s / KSF][s % KSF], gh[s / KSF], fax[s / KSF], nq[s]);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
+          if (f == 1) STAMP(stb);   // diagnostic builds: end of facet 0
 #pragma unroll
           for (int ks = 0; ks < KSF; ++ks) {
             const int s = f * KSF + ks;

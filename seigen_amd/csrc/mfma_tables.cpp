@@ -198,4 +198,43 @@ MfmaConst mfma_const(const MeshDev& md) {
   return c;
 }
 
+
+// The neighbour of (cube c, class k) across facet f, exactly as the stage kernels used to derive it per item
+// (kernels_mfma.hip nbr_ref): same cube (axis < 0), the cube one step along `axis`, the domain boundary, or a
+// neighbour block's packed trace.  A cell slot is ((c / 16) * 6 + class) * 16 + c % 16: the position of the cell's
+// 16-lane column in the interleaved layout, independent of node and component counts.
+void build_nbr_table(const MeshDev& md, std::vector<int32_t>& tab) {
+  const int64_t ngroups = md.ncube_pad / 16;
+  tab.assign((size_t)ngroups * 6 * 64, -1);
+  const int64_t n0 = md.n[0], n1 = md.n[1], n2 = md.n[2];
+  for (int64_t g = 0; g < ngroups; ++g)
+    for (int k = 0; k < 6; ++k)
+      for (int w = 0; w < 16; ++w) {
+        const int64_t c = g * 16 + w;
+        int32_t* e = &tab[(size_t)(((g * 6 + k) * 16 + w) * 4)];
+        if (c >= md.ncube) continue;                      // layout padding: treated as domain boundary (reads its own slot)
+        const int64_t cc[3] = {c % n0, (c / n0) % n1, c / (n0 * n1)};
+        for (int f = 0; f < 4; ++f) {
+          const int axis = md.nb_axis[k][f], kn = md.nb_cls[k][f];
+          if (axis < 0) {
+            e[f] = (int32_t)((g * 6 + kn) * 16 + w);
+            continue;
+          }
+          const int dir = md.nb_dir[k][f];
+          const int64_t cn = cc[axis] + dir, nax = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+          if (cn >= 0 && cn < nax) {
+            const int64_t nc = c + dir * (axis == 0 ? 1 : (axis == 1 ? n0 : n0 * n1));
+            e[f] = (int32_t)(((nc >> 4) * 6 + kn) * 16 + (nc & 15));
+            continue;
+          }
+          const int side = 2 * axis + (dir > 0 ? 1 : 0);
+          if (md.has_nbr[side]) {
+            const int64_t c2 = axis == 0 ? cc[1] + n1 * cc[2] : (axis == 1 ? cc[0] + n0 * cc[2] : cc[0] + n0 * cc[1]);
+            const int64_t slot = c2 * md.halo_per_cube + md.face_ord[kn][md.nb_face[k][f]];
+            e[f] = (int32_t)(-2 - slot);
+          }                                               // else: -1, the domain boundary
+        }
+      }
+}
+
 }  // namespace sg
