@@ -289,8 +289,7 @@ def build_config4(args, rank, world, nsteps_source):
     el.source_function = Function(el.S)          # zero; the per-step table below is what the kernels see
     el.setup()
     times = [el.dt * (k + 1) for k in range(nsteps_source)]
-    nodes, values, static = el._source_table(times)
-    el.block.set_source(nodes, values, static=static)
+    el.upload_source(times)
     el._agree_on_stress_storage()
     name = "3D explosive source (config 4), %d^3 cubes x 6 tets in total, blocks %s, DG P%d, %s, LF4" % (
         N, "x".join(str(v) for v in mesh.partition.n), P, "FP32" if args.dtype == "f32" else "FP64")

@@ -151,6 +151,17 @@ class HipBlock(object):
         check(self.lib.sg_set_source(self.h, nodes.size, nodes.ctypes.data, -1 if static else values.shape[0],
                                      values.ctypes.data), self.h)
 
+    def set_source_separable(self, nodes, pattern, weights):
+        """S(node, step k) = weights[k] * pattern[node]: nodes [nnz], pattern [nnz, d, d], weights [nsteps]."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64).ravel()
+        weights = _f64(weights).ravel()
+        if nodes.size == 0 or weights.size == 0:
+            check(self.lib.sg_set_source(self.h, 0, None, 0, None), self.h)
+            return
+        pattern = _f64(pattern).reshape(nodes.size, self.dim, self.dim)
+        check(self.lib.sg_set_source_separable(self.h, nodes.size, nodes.ctypes.data, pattern.ctypes.data, weights.size,
+                                               weights.ctypes.data), self.h)
+
     # ---- hot path ---------------------------------------------------------------------
     def step(self, nsteps=1):
         check(self.lib.sg_step(self.h, int(nsteps)), self.h)

@@ -531,6 +531,7 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   h->src_nsteps = 0;
   h->src_step = 0;
   h->src_static = false;
+  h->src_weights.clear();
   if (nnz == 0 || nsteps == 0) return SG_OK;
   if (!nodes || !values || nsteps < -1) return SG_ERR_ARG;
   const bool is_static = nsteps == -1;
@@ -619,6 +620,18 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   h->src_nnz = nnz;
   h->src_nsteps = nsteps;
   h->src_static = is_static;
+  return SG_OK;
+}
+
+int sg_set_source_separable(sg_handle* h, int64_t nnz, const int64_t* nodes, const double* pattern, int64_t nsteps,
+                            const double* weights) {
+  if (!h || nnz < 0 || nsteps < 0) return SG_ERR_ARG;
+  if (nnz == 0 || nsteps == 0) return sg_set_source(h, 0, nullptr, 0, nullptr);
+  if (!weights) return SG_ERR_ARG;
+  int rc = sg_set_source(h, nnz, nodes, 1, pattern);      // one slice: order, offsets, symmetry check, fused tables
+  if (rc != SG_OK) return rc;
+  h->src_weights.assign(weights, weights + nsteps);
+  h->src_nsteps = nsteps;
   return SG_OK;
 }
 

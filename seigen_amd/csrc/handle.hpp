@@ -73,6 +73,7 @@ struct sg_handle {
   int64_t src_nsteps = 0;
   int64_t src_step = 0;
   bool src_static = false;  // one time slice that holds at every step
+  std::vector<double> src_weights;  // separable source: src_values is one slice, scaled by src_weights[src_step]
   // 2-D tile path: the source is added inside the G stage kernels (StageArgs::src_slot / src_idx)
   bool src_fused = false;
   int32_t* src_slot_d = nullptr;

@@ -422,25 +422,25 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const void* field, int
 // ---- sparse source ----------------------------------------------------------------------
 template <typename T>
 __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64_t* offs, const double* values,
-                              double coef) {
+                              double coef, double scale) {
   long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= nnz * ncomp) return;
   long k = idx / ncomp;
   int c = (int)(idx - k * ncomp);
   // a node may be listed more than once (its entries add up): atomic, the table is tiny
-  atomicAdd(&field[offs[k] + (long)c * gw], (T)(coef * values[idx]));
+  atomicAdd(&field[offs[k] + (long)c * gw], (T)(coef * __dmul_rn(scale, values[idx])));
 }
 
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
-                  int f32, void* stream) {
+                  double scale, int f32, void* stream) {
   if (nnz <= 0) return 0;
   long total = nnz * ncomp;
   if (f32)
     hipLaunchKernelGGL(source_kernel<float>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       (float*)field, ncomp, gw, (long)nnz, offs, values, coef);
+                       (float*)field, ncomp, gw, (long)nnz, offs, values, coef, scale);
   else
     hipLaunchKernelGGL(source_kernel<double>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       (double*)field, ncomp, gw, (long)nnz, offs, values, coef);
+                       (double*)field, ncomp, gw, (long)nnz, offs, values, coef, scale);
   return (int)hipGetLastError();
 }
 

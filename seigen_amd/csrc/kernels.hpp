@@ -100,6 +100,7 @@ struct StageArgs {
   const int32_t* src_slot;
   const int32_t* src_idx;
   const double* src_vals;
+  double src_scale;          // factor on src_vals (a separable source's weight of this step, else 1)
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)
@@ -155,7 +156,8 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& md_host, const void* field
                 const int* sides, void* const* outs, int sym, int f32, void* stream);
 
 // field[off[k] + c*gw] += coef * values[k][c] at the sparse source nodes (off = device offset of comp 0)
+// (values are scaled by `scale` and rounded first: a separable source's weight of this step)
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
-                  int f32, void* stream);
+                  double scale, int f32, void* stream);
 
 }  // namespace sg

@@ -406,10 +406,10 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           const int ix = (a < ND) ? A.src_idx[(sslot_src * ND + a) * 16 + w] : -1;
           if (ix >= 0) {
             const double* sv = A.src_vals + (long)ix * 4;
-            v00 += sv[0];
-            v01 += sv[1];
-            v10 += sv[2];
-            v11 += sv[3];
+            v00 += __dmul_rn(A.src_scale, sv[0]);   // rounded product first: bitwise = a table of the products
+            v01 += __dmul_rn(A.src_scale, sv[1]);
+            v10 += __dmul_rn(A.src_scale, sv[2]);
+            v11 += __dmul_rn(A.src_scale, sv[3]);
           }
         }
         if (MODE == 1) {

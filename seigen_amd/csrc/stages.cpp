@@ -69,6 +69,11 @@ void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int regio
 static bool source_active(const sg_handle* h) {
   return h->src_nnz != 0 && (h->src_static || h->src_step < h->src_nsteps);
 }
+// separable source: the one stored slice, scaled by this step's weight
+static bool source_one_slice(const sg_handle* h) { return h->src_static || !h->src_weights.empty(); }
+static double source_scale(const sg_handle* h) {
+  return h->src_weights.empty() ? 1.0 : h->src_weights[(size_t)h->src_step];
+}
 
 static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mode, double c_self, double c_aux,
                   double c_new, int region, int uabs_f = SG_FIELD_U, bool with_source = false) {
@@ -110,7 +115,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   if (with_source && h->src_fused && source_active(h)) {  // tile path: the G kernel adds this step's source values
     a.src_slot = h->src_slot_d;
     a.src_idx = h->src_idx_d;
-    a.src_vals = h->src_values + (size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz * h->cfg.dim * h->cfg.dim;
+    a.src_vals = h->src_values + (size_t)(source_one_slice(h) ? 0 : h->src_step) * h->src_nnz * h->cfg.dim * h->cfg.dim;
+    a.src_scale = source_scale(h);
   }
   std::vector<Box> boxes;
   region_boxes(h, region, boxes);
@@ -199,8 +205,8 @@ static int add_source(sg_handle* h, int field, double coef, int region = SG_REGI
     cnt = h->src_nnz - h->src_nfirst;
   }
   if (cnt == 0) return SG_OK;
-  const double* vals = h->src_values + ((size_t)(h->src_static ? 0 : h->src_step) * h->src_nnz + off) * d * d;
-  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, h->f32, h->stream);
+  const double* vals = h->src_values + ((size_t)(source_one_slice(h) ? 0 : h->src_step) * h->src_nnz + off) * d * d;
+  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, source_scale(h), h->f32, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
   return SG_OK;
 }

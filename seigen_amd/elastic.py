@@ -291,7 +291,7 @@ class ElasticLF4(object):
         nz, Xs = np.concatenate(nz), np.concatenate(Xs)
         if nsteps * len(nz) * d * d * 8 > self.SOURCE_TABLE_MAX_BYTES:
             raise MemoryError("the source can be non-zero at %d nodes over %d steps: its table would take %.1f GB; "
-                              "the sparse per-step source of libseigen_hip is meant for localised sources"
+                              "too much for a per-step table, and the source does not factorise into w(t) * pattern(x)"
                               % (len(nz), nsteps, nsteps * len(nz) * d * d * 8 / 1e9))
         values = np.zeros((nsteps, len(nz), d, d))
         for k in range(nsteps):
@@ -341,6 +341,76 @@ class ElasticLF4(object):
         cells = (cube[:, None] * ncls + np.arange(ncls)[None, :]).reshape(-1)
         yield 0, X, cells
 
+    def _source_separable(self, times):
+        """(nodes, pattern [nnz, d, d], weights [nsteps]) if the source is S(x, t) = w(t) * pattern(x) on its
+        support - what `cond(x) ? f(t) : 0` sources (explosive_source_lf4.py:36-40) and `source_time_function` are -
+        else None.  An Expression is TESTED, not assumed: the factorisation found at one pivot entry must
+        reproduce the full evaluation at six other steps to round-off."""
+        d = self.dimension
+        if self.source_time_function is not None:
+            vals = self.source_function.dat.data_cells
+            nz = np.nonzero(np.abs(vals).reshape(vals.shape[0] * vals.shape[1], -1).max(axis=1) > 0)[0]
+            return nz, vals.reshape(-1, d, d)[nz], np.array([float(self.source_time_function(t)) for t in times])
+        expr = self.source_expression
+        if expr is None or not hasattr(expr, "_params") or "t" not in expr._params or len(times) < 2:
+            return None
+        t_keep = expr.t
+        try:
+            nz, Xs = [], []
+            for cell0, X, cells in self._support_scan_chunks(expr):
+                idx = np.nonzero(expr.support_mask(X).reshape(-1))[0]
+                nz.append(idx + cell0 * X.shape[1] if cells is None else cells[idx // X.shape[1]] * X.shape[1] + idx % X.shape[1])
+                Xs.append(X.reshape(-1, X.shape[-1])[idx])
+            nz, Xs = np.concatenate(nz), np.concatenate(Xs)
+            if len(nz) == 0:
+                return nz, np.zeros((0, d, d)), np.zeros(len(times))
+            n = len(times)
+            best = None
+            for k in sorted({0, n // 4, n // 2, 3 * n // 4, n - 1}):          # a step where the source is strong
+                expr.t = times[k]
+                V = expr.evaluate(Xs).reshape(len(nz), d, d)
+                if best is None or np.abs(V).max() > np.abs(best[1]).max():
+                    best = (k, V)
+            k0, pattern = best
+            if not np.abs(pattern).max() > 0:
+                return None
+            piv = np.unravel_index(np.abs(pattern).argmax(), pattern.shape)
+            xp = Xs[piv[0]:piv[0] + 1]
+            w = np.empty(n)
+            for k in range(n):
+                expr.t = times[k]
+                w[k] = expr.evaluate(xp).reshape(d, d)[piv[1], piv[2]] / pattern[piv]
+            rng = np.random.default_rng(0)
+            for k in sorted(set(int(v) for v in rng.integers(0, n, size=6)) | {0, n - 1}):
+                expr.t = times[k]
+                V = expr.evaluate(Xs).reshape(len(nz), d, d)
+                if np.abs(V - w[k] * pattern).max() > 1e-13 * max(np.abs(V).max(), np.abs(w[k] * pattern).max(), 1e-300):
+                    return None
+            return nz, pattern, w
+        finally:
+            expr.t = t_keep
+
+    def upload_source(self, times):
+        """Hand the source of the next len(times) steps to the device: as a table of nodal values per step
+        (the reference's re-interpolation, elastic.py:285-288, restricted to the support) or, when that table would
+        exceed SOURCE_TABLE_MAX_BYTES or `source_time_function` is set, as one slice and a weight per step
+        (sg_set_source_separable) if the source factorises."""
+        if not self.source:
+            self._block.set_source([], None)
+            return
+        if self.source_time_function is not None:
+            self._block.set_source_separable(*self._source_separable(times))
+            return
+        try:
+            nodes, values, static = self._source_table(times)
+        except MemoryError:
+            sep = self._source_separable(times)
+            if sep is None:
+                raise
+            self._block.set_source_separable(*sep)
+            return
+        self._block.set_source(nodes, values, static=static)
+
     # ---- time loop (elastic.py:267-315) ----------------------------------------------------------
     def step_times(self, T):
         """The values of `t` visited by the reference loop ``t = dt; while t <= T + 1e-12``."""
@@ -379,12 +449,8 @@ class ElasticLF4(object):
 
         with timed_region('timestepping'):
             times = self.step_times(T)
-            if self.source:
-                with timed_region('source term update'):
-                    nodes, values, static = self._source_table(times)
-                    self._block.set_source(nodes, values, static=static)
-            else:
-                self._block.set_source([], None)
+            with timed_region('source term update'):
+                self.upload_source(times)
             self._agree_on_stress_storage()
             with self.loop_context():
                 if self.output:

@@ -95,9 +95,7 @@ class ExplosiveSourceLF4():
         el = self.elastic
         el.setup()
         times = el.step_times(T)
-        if el.source:
-            nodes, values, static = el._source_table(times)
-            el.block.set_source(nodes, values, static=static)
+        el.upload_source(times)
         locs = [locate(el.U, r) for r in receivers]
         out_t, out_v = [], []
         done = 0

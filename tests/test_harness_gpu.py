@@ -484,3 +484,61 @@ def test_eigenmode_bench_record(gpu, tmp_path):
     for task in ("timestepping", "solver setup", "compute_error"):
         assert rec["timings"][task] > 0
     assert json.loads(path.read_text())["meta"]["dofs"] == rec["meta"]["dofs"]
+
+
+def test_separable_source(gpu):
+    """sg_set_source_separable (one slice + a weight per step) against sg_set_source with the table of the products:
+    bitwise equal, on the fused-source 2-D tile path and on the launch path (3-D); through the solver class an
+    Expression source whose table would not fit is factorised after testing it, a source that does not factorise
+    still raises."""
+    from seigen_amd import ElasticLF4, Expression, Function, RectangleMesh, _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(4)
+    for dim, degree, n in ((2, 3, (20, 9)), (3, 4, (3, 2, 2)), (3, 2, (2, 2, 3))):
+        res = []
+        for mode in ("table", "separable"):
+            blk = HipBlock(dim, degree, n, [1.0 / v for v in n], [0.0] * dim)
+            blk.set_params(1.0, 1e-3, 0.5, 0.25)
+            r2 = np.random.default_rng(5)
+            blk.set_field(_lib.FIELD_U, r2.uniform(-1, 1, blk.field_shape(_lib.FIELD_U)))
+            nodes = np.sort(r2.choice(blk.ncells * blk.nd, 9, replace=False))
+            pat = r2.uniform(-1, 1, (9, dim, dim))
+            pat = pat + np.swapaxes(pat, 1, 2)
+            w = r2.uniform(-2, 2, 5)
+            if mode == "table":
+                blk.set_source(nodes, w[:, None, None, None] * pat[None])
+            else:
+                blk.set_source_separable(nodes, pat, w)
+            blk.step(7)                                  # two steps beyond the source's five
+            res.append((blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S)))
+            blk.close()
+        assert np.abs(res[0][1]).max() > 0
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (dim, degree)
+    # solver class: the same box x Ricker source as a table and, with the table "too large", factorised
+    out = []
+    for cap in (None, 0):
+        mesh = RectangleMesh(16, 8, 16.0, 8.0)
+        el = ElasticLF4.create(mesh, "DG", 2, dimension=2, solver="explicit", output=False)
+        el.density, el.mu, el.l, el.dt = 1.0, 3.0, 2.0, 1e-3
+        code = "x[0] >= 4.0 && x[0] <= 9.0 && x[1] >= 2.0 && x[1] <= 5.0 ? (1.0 + x[0]) * sin(40.0 * t) : 0.0"
+        el.source_expression = Expression(((code, "0.0"), ("0.0", code)), t=0)
+        el.source_function = Function(el.S)
+        el.source = el.source_expression
+        if cap is not None:
+            el.SOURCE_TABLE_MAX_BYTES = cap
+        u1, s1 = el.run(30 * el.dt * (1 + 1e-9))
+        out.append((u1.dat.data_cells.copy(), s1.dat.data_cells.copy()))
+    scale = np.abs(out[0][1]).max()
+    assert scale > 0 and np.abs(out[0][1] - out[1][1]).max() < 1e-13 * scale
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-13 * max(np.abs(out[0][0]).max(), 1e-300)
+    # not separable: the box moves with t
+    mesh = RectangleMesh(16, 8, 16.0, 8.0)
+    el = ElasticLF4.create(mesh, "DG", 2, dimension=2, solver="explicit", output=False)
+    el.density, el.mu, el.l, el.dt = 1.0, 3.0, 2.0, 1e-3
+    code = "x[0] >= 4.0 + 100.0 * t && x[0] <= 9.0 + 100.0 * t ? 1.0 : 0.0"
+    el.source_expression = Expression(((code, "0.0"), ("0.0", code)), t=0)
+    el.source_function = Function(el.S)
+    el.source = el.source_expression
+    el.SOURCE_TABLE_MAX_BYTES = 0
+    with pytest.raises(MemoryError):
+        el.run(30 * el.dt)
