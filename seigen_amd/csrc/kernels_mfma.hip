@@ -330,32 +330,33 @@ struct ItemRange {
 };
 __device__ __forceinline__ ItemRange item_range(long nitems, int wave, int spread, long chunk) {
   ItemRange r;
+  const long wpb = blockDim.x >> 6;   // waves per block (4; 6 in the three-waves-per-SIMD experiment, SG_FW)
   r.chunk = 0;
   r.xcd = 0;
   r.nitems = nitems;
   if (spread) {  // boundary shells: round-robin over every wave of the grid (over the item list if given)
-    r.lo = (long)blockIdx.x * 4 + wave;
+    r.lo = (long)blockIdx.x * wpb + wave;
     r.hi = nitems;
-    r.step = (long)gridDim.x * 4;
+    r.step = (long)gridDim.x * wpb;
     return r;
   }
   const long nblk = gridDim.x;
   const long xcd = blockIdx.x % 8;
   const long slot = blockIdx.x / 8;
   const long blocks_here = (nblk - xcd + 7) / 8;
-  r.step = blocks_here * 4;
+  r.step = blocks_here * wpb;
   if (chunk > 0) {
     // chunks xcd, xcd + 8, ... of `chunk` consecutive items each
     const long nchunks = (nitems + chunk - 1) / chunk;
     const long mine = (nchunks - xcd + 7) / 8;
     r.chunk = chunk;
     r.xcd = xcd;
-    r.lo = slot * 4 + wave;
+    r.lo = slot * wpb + wave;
     r.hi = mine > 0 ? mine * chunk : 0;
     return r;
   }
   const long ipx = (nitems + 7) / 8;
-  r.lo = xcd * ipx + slot * 4 + wave;
+  r.lo = xcd * ipx + slot * wpb + wave;
   r.hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
   return r;
 }
@@ -370,26 +371,26 @@ __device__ __forceinline__ long item_of(const ItemRange& r, long it) {
 // Operator tiles and mesh tables into LDS, once per block.  All of a thread's loads are issued
 // before the first one is consumed (a plain copy loop compiles to load / wait / write per element:
 // 33 dependent L2 round trips, about 20 us of every launch).
-template <int N, typename R>
+template <int N, typename R, int NT = 256>
 __device__ __forceinline__ void copy_to_lds(R* dst, const R* __restrict__ src) {
-  constexpr int PER = (N + 255) / 256;
+  constexpr int PER = (N + NT - 1) / NT;
   R v[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int i = threadIdx.x + j * 256;
+    const int i = threadIdx.x + j * NT;
     v[j] = (i < N) ? src[i] : R(0);
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int i = threadIdx.x + j * 256;
+    const int i = threadIdx.x + j * NT;
     if (i < N) dst[i] = v[j];
   }
 }
 
-template <int NV, int NL, typename R>
+template <int NV, int NL, typename R, int NT = 256>
 __device__ __forceinline__ void load_tables(R* sAV, R* sAL, const StageArgs& A) {
-  copy_to_lds<NV * 64>(sAV, reinterpret_cast<const R*>(A.fragV));
-  copy_to_lds<NL * 64>(sAL, reinterpret_cast<const R*>(A.fragL));
+  copy_to_lds<NV * 64, R, NT>(sAV, reinterpret_cast<const R*>(A.fragV));
+  copy_to_lds<NL * 64, R, NT>(sAL, reinterpret_cast<const R*>(A.fragL));
   __syncthreads();
 }
 
@@ -808,17 +809,6 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
 
   STAMP_DECL;
-#ifndef SG_XPF
-#define SG_XPF 0
-#endif
-  // Cross-item prefetch (SG_XPF): the own rows of the NEXT item's first k-step are requested when this item's lift
-  // phase begins - half an item before they are needed - so that an item does not open with a full memory latency
-  // in front of its first matrix instruction.  Measured: no gain (8.17-8.20 against 8.17-8.19 ms/step,
-  // profiles/r03/kernel_experiments.txt) - the SIMD's other wave already covers that latency; off by default.
-  R Tnext[9];
-  long pf_item = -1;
-#pragma unroll
-  for (int c = 0; c < 9; ++c) Tnext[c] = R(0);
   for (long it = ir.lo; it < ir.hi; it += ir.step) {
     STAMP(st0);
     const long iti = item_of(ir, it);
@@ -829,11 +819,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     const LaneGeo L = A.all_active ? lane_geo_all(mk.ncube, g, w) : lane_geo(mk, A, g, w);
     const cMfmaClassConst& kc = mk.cls[k];
     const int qsh = q * 8;
-#ifndef SG_NBE_LATE
-#define SG_NBE_LATE 0
-#endif
-    nbr4 nbe = {0, 0, 0, 0};
-    if (!((SG_NBE_LATE >> MODE) & 1)) nbe = load_nbr4(A, item, w);
+    const nbr4 nbe = load_nbr4(A, item, w);
     if (!__any(L.active)) continue;
     const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
     int qo = q * 9 * 16;  // B rows: see mfma_stage_G
@@ -881,14 +867,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #endif
         constexpr int PFV = sizeof(R) == 4 ? 2 : SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
         R Tq[PFV][9];
-        if (SG_XPF && __builtin_amdgcn_readfirstlane(pf_item == item ? 1 : 0)) {
 #pragma unroll
-          for (int c = 0; c < 9; ++c) Tq[0][c] = Tnext[c];
-        } else {
-          load_tensor<SYM>(brow(0), 16, Tq[0]);
-        }
-#pragma unroll
-        for (int s0 = 1; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
+        for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           R T[9];
@@ -933,7 +913,6 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       int noff[4][KSF];
       bool gh[4];
       int fax[4];
-      if ((SG_NBE_LATE >> MODE) & 1) nbe = load_nbr4(A, item, w);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const NbrRef<R> NR = nbr_from_entry<ND, NF, 9>(A, nbe[f], 2 * kc.nb_axis[f] + (kc.nb_dir[f] > 0 ? 1 : 0), own);
@@ -999,17 +978,6 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #else
     do_volume();
     STAMP(st2);
-    if (SG_XPF && KS > 1) {
-      // the next item of this wave (same mapping as the loop header); inactive or missing items are simply not used
-      const long itn = it + ir.step;
-      long nitem = -1;
-      if (itn < ir.hi) {
-        const long in2 = item_of(ir, itn);
-        if (in2 >= 0) nitem = A.item_list ? (long)A.item_list[in2] : in2;
-      }
-      pf_item = nitem;
-      if (nitem >= 0) load_tensor<SYM>(in + (nitem * (long)ND) * 9 * 16 + w + qo, 16, Tnext);
-    }
     SG_PRIO(SG_PRIO_LIFT);
     do_lifts();
 #endif
