@@ -294,6 +294,12 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64")
     # boxes (half an interior + six slabs): MFMA kernels (P3) and generic kernels (P1)
     (3, 3, (9, 9, 9), (3, 3, 3)),
     (3, 1, (7, 8, 9), (3, 3, 3)),
+    # block sides normal to x on the interleaved layouts (16 cubes of an x-row per item): the shell next to an x side is
+    # a whole layout group thick (csrc/handle.hpp shell_width_x), so blocks must be wider than 32 cubes for the launch
+    # that overlaps the exchange to have anything to do; 40 and 36 cubes per block also make groups straddle rows
+    (3, 3, (80, 3, 4), (2, 1, 2)),
+    (3, 4, (120, 2, 2), (3, 1, 1)),
+    (2, 3, (72, 6), (2, 2)),
 ])
 @pytest.mark.parametrize("pipelined", [True, False])
 def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
