@@ -243,22 +243,14 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64")
 
     def cells_of(p):
         """global cell indices of a block, in the block's own cell order"""
-        idx = []
-        rng = [range(p.start[a], p.start[a] + p.n[a]) for a in range(dim)]
+        ax = [np.arange(p.start[a], p.start[a] + p.n[a]) for a in range(dim)]
         if dim == 1:
-            idx.extend(rng[0])
+            cube = ax[0]
         elif dim == 2:
-            for j in rng[1]:
-                for i in rng[0]:
-                    cube = i + n[0] * j
-                    idx.extend(cube * ncls + k for k in range(ncls))
+            cube = (ax[0][None, :] + n[0] * ax[1][:, None]).reshape(-1)
         else:
-            for kz in rng[2]:
-                for j in rng[1]:
-                    for i in rng[0]:
-                        cube = i + n[0] * (j + n[1] * kz)
-                        idx.extend(cube * ncls + k for k in range(ncls))
-        return np.array(idx)
+            cube = (ax[0][None, None, :] + n[0] * (ax[1][None, :, None] + n[1] * ax[2][:, None, None])).reshape(-1)
+        return (cube[:, None] * ncls + np.arange(ncls)[None, :]).reshape(-1)
 
     blocks = []
     for p in parts:
@@ -304,6 +296,15 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64")
 @pytest.mark.parametrize("pipelined", [True, False])
 def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
     _multiblock_case(dim, degree, n, grid, pipelined)
+
+
+def test_two_blocks_across_x_at_production_width(gpu):
+    """Two 64 x 32 x 32-cube P4 blocks side by side along x (the 2 x 2 x 2 grid's kind of neighbour) on the
+    MFMA kernels with everything the production path switches on at that size - group-thick x shell, item lists of the
+    FIRST / SECOND regions, chunked item order, per-item neighbour table with remote-trace slots - bitwise equal to
+    the single 128 x 32 x 32 block, both schedules."""
+    for pipelined in (True, False):
+        _multiblock_case(3, 4, (128, 32, 32), (2, 1, 1), pipelined)
 
 
 @pytest.mark.parametrize("dim,degree,n,grid", [(3, 4, (4, 2, 4), (2, 1, 2)), (2, 3, (10, 9), (1, 3))])
