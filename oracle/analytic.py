@@ -43,3 +43,65 @@ def explosive_line_source_2d(r, times, alpha, rho=1.0, area=1.0, wavelet_dot=ric
         ch = np.cosh(th)
         out[k] = -area / (2 * np.pi * rho * alpha ** 3) * np.sum(w * wavelet_dot(t - (r / alpha) * ch) * ch)
     return out
+
+
+def explosive_line_source_halfspace(x, z, zs, times, alpha, beta, rho=1.0, area=1.0, wavelet=ricker, wavelet_dot=ricker_dot,
+                                    period=3000.0, kmax_decades=14.0, t_window=None):
+    """Particle velocity (v_x, v_z), z pointing DOWN from the free surface z = 0, at horizontal distance x and depth
+    z >= 0 of an explosive line source at depth zs > 0 in a homogeneous half space ("Garvin's problem" with buried
+    receivers) - the problem tests/explosive_source/explosive_source_lf4.py states, in the limit of a small source
+    box and perfect absorbers.
+
+    Direct wave: the closed form above.  Reflected P and converted SV waves (and with them the Rayleigh wave): plane-wave
+    expansion with the free-surface conditions sigma_zz = sigma_xz = 0 solved per horizontal wavenumber k,
+
+        phi  = S [ e^{-nu_a |z - zs|} / (2 nu_a)  +  A e^{-nu_a z} ],     psi = S B e^{-nu_b z},
+        A = - e^{-nu_a zs} / (2 nu_a) * (W^2 + 4 k^2 nu_a nu_b) / D,       B = 4 i k nu_a W e^{-nu_a zs} / (2 nu_a D),
+        W = 2 k^2 - w^2 / beta^2,    D = W^2 - 4 k^2 nu_a nu_b   (Rayleigh function),   nu_c = sqrt(k^2 - w^2 / c^2),
+
+    displacement = grad(phi) + curl(psi e_y), summed over discrete wavenumbers k_n = 2 pi n / period (Bouchon's discrete
+    wavenumber method: the images a distance `period` away arrive after the time window) at complex frequencies
+    w + i gamma (which keeps the branch points and the Rayleigh pole off the path and damps the time wrap-around).
+    Not part of the reference; an exact solution for the reference's own test problem."""
+    times = np.asarray(times, dtype=np.float64)
+    T = float(t_window) if t_window is not None else 2.0 * float(times.max()) + 1.0
+    gamma = np.pi / T
+    dw = 2.0 * np.pi / T
+    # source spectrum at complex frequency: int r(t) e^{i w t} dt, r = wavelet (moment rate), by quadrature
+    tq = np.linspace(0.0, min(T, 1.5), 6001)
+    rq = wavelet(tq)
+    nw = int(np.ceil(2.0 * np.pi * 25.0 / dw))                # up to 25 Hz: the Ricker of the test peaks at 4 Hz
+    wr = dw * np.arange(nw + 1)
+    w = wr + 1j * gamma
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    rhat = trapz(rq[None, :] * np.exp(1j * w[:, None] * tq[None, :]), tq, axis=1)
+    S = area / (rho * alpha ** 2) * rhat                      # velocity = d/dt displacement: moment-rate spectrum
+    dk = 2.0 * np.pi / period
+    kmax = kmax_decades / max(z + zs, 0.25)                   # e^{-nu (z + zs)} < e^{-kmax_decades}
+    n = int(np.ceil(kmax / dk))
+    k = dk * np.arange(-n, n + 1)
+    vx = np.zeros(len(w), dtype=complex)
+    vz = np.zeros(len(w), dtype=complex)
+    for m in range(len(w)):
+        ka2, kb2 = (w[m] / alpha) ** 2, (w[m] / beta) ** 2
+        na, nb = np.sqrt(k * k - ka2), np.sqrt(k * k - kb2)
+        W = 2 * k * k - kb2
+        D = W * W - 4 * k * k * na * nb
+        inc0 = np.exp(-na * zs) / (2 * na)
+        A = -inc0 * (W * W + 4 * k * k * na * nb) / D
+        B = 4j * k * na * W * inc0 / D
+        ea, eb = np.exp(-na * z), np.exp(-nb * z)
+        wx = 1j * k * A * ea + nb * B * eb
+        wz = -na * A * ea + 1j * k * B * eb
+        ph = np.exp(1j * k * x)
+        vx[m] = S[m] * dk / (2 * np.pi) * np.sum(wx * ph)
+        vz[m] = S[m] * dk / (2 * np.pi) * np.sum(wz * ph)
+    ex = np.exp(-1j * wr[:, None] * times[None, :])
+    wgt = np.full(len(w), dw)
+    wgt[0] = 0.5 * dw
+    fx = np.exp(gamma * times) / np.pi * np.real(np.sum((wgt * vx)[:, None] * ex, axis=0))
+    fz = np.exp(gamma * times) / np.pi * np.real(np.sum((wgt * vz)[:, None] * ex, axis=0))
+    # direct wave (closed form); receiver at (x, z - zs) from the source
+    r = float(np.hypot(x, z - zs))
+    vr = explosive_line_source_2d(r, times, alpha, rho, area, wavelet_dot)
+    return fx + vr * x / r, fz + vr * (z - zs) / r

@@ -13,6 +13,8 @@ build container: `python tests/golden/make_golden.py`).
   fullspace_oracle.npz    oracle traces of the explosive source moved into the interior (160 m x 100 m, h = 1.25, P3,
                           dt = 0.0005, projected source), compared with the exact 2-D full-space solution
                           (oracle/analytic.py) in tests/test_oracle_pins.py
+  halfspace_oracle.npz    oracle (C port) traces of the explosive source 180 m from the nearest sponge, for the comparison
+                          with the exact half-space solution (Garvin's problem with buried receivers)
   refc_convergence_hip.npz  NOT made here: receiver traces of the HIP path for the REF-C convergence study, written
                           by tools/refc_convergence.py on a GPU box (gpurun_out/refc_convergence.npz, 'project' rows
                           and the reference's own 'interpolate' h = 2.5 P2 row)
@@ -69,6 +71,40 @@ def fullspace():
     times, tr = ex.run(c["T"], receivers=c["receivers"])
     np.savez_compressed(os.path.join(HERE, "fullspace_oracle.npz"), times=times[9::10], traces=tr[9::10],
                         receivers=np.array(c["receivers"]), src=np.array(c["src"]), Vp=ex.Vp)
+
+
+HALFSPACE = dict(Lx=500.0, Ly=150.0, h=1.25, degree=3, src=(200.0, 149.0), dt=0.0005, T=2.5, every=10,
+                 receivers=((245.3, 149.0), (245.3, 149.7), (295.3, 149.0), (295.3, 147.7)))
+
+
+def halfspace():
+    """The explosive-source set-up with the source 180 m from the nearest sponge (whose abrupt onset reflects), unit-moment
+    projected source, stepped by the oracle's C port (sponge + source: oracle/cport.py, validated against the numpy
+    oracle in tests/test_oracle_cport.py); receiver traces every 10th step for the comparison with the exact
+    half-space solution (oracle/analytic.py explosive_line_source_halfspace) in tests/test_oracle_pins.py."""
+    from oracle.cport import CPort, sponge_blocks
+    c = HALFSPACE
+    ex = harness.ExplosiveSource(Lx=c["Lx"], Ly=c["Ly"], h=c["h"], degree=c["degree"], src=c["src"], source_mode="project")
+    el = ex.elastic
+    m, P = ex.mesh, c["degree"]
+    cp = CPort(m, P)
+    nsteps = int(round(c["T"] / c["dt"]))
+    nodes = np.nonzero(np.abs(ex.pattern).reshape(m.ncells * cp.nd, -1).max(axis=1) > 0)[0]
+    pat = ex.pattern.reshape(m.ncells * cp.nd, 2, 2)[nodes]
+    w = np.array([harness.ricker((k + 1) * c["dt"]) for k in range(nsteps)])
+    cp.set_extra(sponge=sponge_blocks(m, P, ex.sigma, 4), src_nodes=nodes, src_values=w[:, None, None, None] * pat[None])
+    ev = [ex.point_evaluator(x, y) for (x, y) in c["receivers"]]
+    u = np.zeros((m.ncells, cp.nd, 2))
+    s = np.zeros((m.ncells, cp.nd, 2, 2))
+    times, traces = [], []
+    for k0 in range(0, nsteps, c["every"]):
+        u, s = cp.step_ex(u, s, el.density, c["dt"], el.l, el.mu, c["every"], step0=k0, inplace=True)
+        times.append((k0 + c["every"]) * c["dt"])
+        traces.append([[float(phi @ u[cc, :, k]) for k in range(2)] for (cc, phi) in ev])
+        if k0 % 1000 == 0:
+            print("halfspace step", k0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "halfspace_oracle.npz"), times=np.array(times), traces=np.array(traces),
+                        receivers=np.array(c["receivers"]), src=np.array(c["src"]), Vp=ex.Vp, Vs=ex.Vs)
 
 
 STAGE_CASES = [
@@ -161,3 +197,5 @@ if __name__ == "__main__":
         explosive_project()
     if "fullspace" in what:
         fullspace()
+    if "halfspace" in what:
+        halfspace()
