@@ -105,3 +105,18 @@ def explosive_line_source_halfspace(x, z, zs, times, alpha, beta, rho=1.0, area=
     r = float(np.hypot(x, z - zs))
     vr = explosive_line_source_2d(r, times, alpha, rho, area, wavelet_dot)
     return fx + vr * x / r, fz + vr * (z - zs) / r
+
+
+def explosive_point_source_3d(r, times, alpha, rho=1.0, volume=1.0, wavelet=ricker, wavelet_dot=ricker_dot):
+    """Radial particle velocity of an explosive point source in a homogeneous 3-D full space, formulation of
+    seigen/elastic.py:204-219 with the source term  S_ij = volume * r(t) * delta^3(x) * delta_ij  (the limit of a small
+    source box of that volume; BASELINE config 4's source): the displacement potential is
+    phi = volume / (4 pi rho alpha^2 r) * R(t - r/alpha), R' = r, so
+
+        v_r(r, t) = - volume / (4 pi rho alpha^2) * [ r(tau) / r^2 + r'(tau) / (alpha r) ],   tau = t - r / alpha."""
+    times = np.asarray(times, dtype=np.float64)
+    tau = times - r / alpha
+    on = tau > 0
+    out = np.zeros_like(times)
+    out[on] = -volume / (4 * np.pi * rho * alpha ** 2) * (wavelet(tau[on]) / r ** 2 + wavelet_dot(tau[on]) / (alpha * r))
+    return out

@@ -401,6 +401,38 @@ def test_halfspace_analytic_on_the_gpu(gpu):
             assert abs(a - 1.0) < 0.01 and m < 0.01, (x, y, a, m)
 
 
+def test_fullspace_3d_analytic_on_the_gpu(gpu):
+    """3-D MFMA path against the exact full-space solution of an explosive source (oracle/analytic.py
+    explosive_point_source_3d, integrated over the source box): the ingredients of BASELINE config 4 - the explosive
+    test's material, a Ricker stress source (elastic.py:217-218, :285-288) in the 2 x 2 x 2 cubes at the centre of a
+    48^3-cube P3 mesh - at three receivers 25 m away in different directions, before any reflection from the outer
+    boundary arrives.  Amplitude within 0.1 %, relative L2 misfit below 0.1 %, no transverse motion
+    (tools/fullspace3d_check.py, profiles/r03/fullspace3d_check.txt: 1.0000 / 1e-4 at P3 and P4)."""
+    import importlib.util
+    from oracle.analytic import explosive_point_source_3d
+    spec = importlib.util.spec_from_file_location(
+        "fullspace3d_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fullspace3d_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    t, tr, rel, vp, vol = mod.run(n=48, P=3)
+    gx, gw = np.polynomial.legendre.leggauss(4)
+    a = vol ** (1.0 / 3.0)
+    for i in range(len(rel)):
+        r = float(np.linalg.norm(rel[i]))
+        vbox = np.zeros((len(t), 3))
+        for p0, w0 in zip(gx, gw):
+            for p1, w1 in zip(gx, gw):
+                for p2, w2 in zip(gx, gw):
+                    dvec = rel[i] - 0.5 * a * np.array([p0, p1, p2])
+                    rr = float(np.linalg.norm(dvec))
+                    vbox += (w0 * w1 * w2 / 8.0) * explosive_point_source_3d(rr, t, vp, volume=vol)[:, None] * (dvec / rr)[None, :]
+        scale = np.abs(vbox).max()
+        assert scale > 0 and np.abs(tr[:, i, :] - vbox).max() < 2e-3 * scale, (i, np.abs(tr[:, i, :] - vbox).max() / scale)
+        vr, ours = vbox @ (rel[i] / r), tr[:, i, :] @ (rel[i] / r)
+        assert abs(np.dot(ours, vr) / np.dot(vr, vr) - 1.0) < 1e-3
+        assert np.linalg.norm(ours - vr) / np.linalg.norm(vr) < 1e-3
+
+
 def test_pulse_1d(gpu):
     """tests/pulse/pulse_1d_lf4.py (1-D DG1, Gaussian pulse, DG1 sponge at both ends, T = 2: 800 steps)."""
     from seigen_amd.harness.pulse import pulse_1d_lf4
