@@ -120,3 +120,18 @@ def explosive_point_source_3d(r, times, alpha, rho=1.0, volume=1.0, wavelet=rick
     out = np.zeros_like(times)
     out[on] = -volume / (4 * np.pi * rho * alpha ** 2) * (wavelet(tau[on]) / r ** 2 + wavelet_dot(tau[on]) / (alpha * r))
     return out
+
+
+def explosive_box_source_halfspace(x, z, zs, times, alpha, beta, box=1.0, nq=3, **kw):
+    """explosive_line_source_halfspace integrated over a square source box of edge `box` centred at (0, zs) - the exact
+    field of the box source of explosive_source_lf4.py:36-40 with unit moment PER UNIT AREA times box^2 = `area`
+    (Gauss-Legendre nq x nq over the source positions; the solution is linear in the source)."""
+    gx, gw = np.polynomial.legendre.leggauss(nq)
+    vx = np.zeros(len(times))
+    vz = np.zeros(len(times))
+    for a, wa in zip(gx, gw):
+        for b, wb in zip(gx, gw):
+            fx, fz = explosive_line_source_halfspace(x - 0.5 * box * a, z, zs + 0.5 * box * b, times, alpha, beta, **kw)
+            vx += 0.25 * wa * wb * fx
+            vz += 0.25 * wa * wb * fz
+    return vx, vz

@@ -320,23 +320,26 @@ def test_halfspace_analytic_pin():
     surface of a half space, receivers below the surface (oracle/analytic.py explosive_line_source_halfspace) - against
     the oracle (C port with sponge and source; fixture halfspace_oracle.npz, make_golden.py: h = 1.25, P3, unit-moment
     source, the source 180 m from the nearest sponge): direct P, reflected P, converted SV and the Rayleigh wave, both
-    components, within 1 % in amplitude and 1 % in relative L2 misfit.
+    components, within 0.1 % in amplitude and 0.2 % in relative L2 misfit at the receiver 45 m away (0.4 % / 0.7 % at
+    95 m, 2.3 m deep: mesh resolution; the HIP path at h = 0.625 / P4 reaches 1e-4 there too) once the point-source
+    solution is integrated over the 1 m source box.
 
     And what that says about REF-C1..3 (the reference's only stored numbers): at the positions uy.py probes (1 m below
     the surface) REF-C's uy is 0.78 of the exact solution and its ux 1.25-1.5 of it; REF-C fits the exact solution
     best for receivers AT the surface above a source 1 m deep (the receiver over the source within 3 %, the far field a
     consistent 0.81-0.84 in both components at 45 and 95 m; 12 % misfit in shape) - it was not made for the set-up
     explosive_source_lf4.py / uy.py describe."""
-    from oracle.analytic import explosive_line_source_halfspace
+    from oracle.analytic import explosive_box_source_halfspace, explosive_line_source_halfspace
     d = np.load(os.path.join(GOLD, "halfspace_oracle.npz"))
     t, tr, src, Vp, Vs = d["times"], d["traces"], d["src"], float(d["Vp"]), float(d["Vs"])
-    for i, (x, y) in enumerate(d["receivers"]):
-        vx, vz = explosive_line_source_halfspace(x - src[0], 150.0 - y, 150.0 - src[1], t, Vp, Vs)
+    for i, tol_a, tol_m in ((0, 1e-3, 2e-3), (3, 4e-3, 7e-3)):     # 45 m / 1 m deep; 95 m / 2.3 m deep (coarser per wavelength)
+        x, y = d["receivers"][i]
+        vx, vz = explosive_box_source_halfspace(x - src[0], 150.0 - y, 150.0 - src[1], t, Vp, Vs, period=2000.0)
         w = (t > 0.3) & (t < (x - src[0]) / (0.9194 * Vs) + 0.75)
         for ours, exact in ((tr[:, i, 0], vx), (-tr[:, i, 1], vz)):
             a = np.dot(ours[w], exact[w]) / np.dot(exact[w], exact[w])
             m = np.linalg.norm(ours[w] - exact[w]) / np.linalg.norm(exact[w])
-            assert abs(a - 1.0) < 0.01 and m < 0.01, (x, y, a, m)
+            assert abs(a - 1.0) < tol_a and m < tol_m, (x, y, a, m)
     # REF-C2 / C3 against the exact solution at the probe positions of uy.py (x - 45 = 45, 95; 1 m deep)
     refs = [np.loadtxt(os.path.join(GOLD, "ref_c%d.txt" % i)) for i in (1, 2, 3)]
     tt = refs[0][:, 0]

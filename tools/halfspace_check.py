@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """HIP path against the exact half-space solution of a buried explosive line source (oracle/analytic.py
-explosive_line_source_halfspace): the reference's explosive-source set-up with the unit-moment projected source, receivers
+explosive_box_source_halfspace: the point-source solution integrated over the 1 m source box): the reference's explosive-source set-up with the unit-moment projected source, receivers
 inside cells at several depths and two distances; before the reflections from the sponge edges arrive.  Needs a GPU."""
 import os
 import sys
@@ -15,12 +15,12 @@ def main():
     import seigen_amd
     import seigen_amd.helpers as helpers
     import seigen_amd.harness.explosive_source as hes
-    from oracle.analytic import explosive_line_source_halfspace
+    from oracle.analytic import explosive_box_source_halfspace
     helpers.log = seigen_amd.elastic.log = hes.log = lambda s: None
     # the reference's domain puts the source 25 m from the left sponge, whose abrupt onset (sigma 0 -> 1000) reflects:
     # P waves come back to the receivers inside uy.py's windows.  SRC_X / LX move the source away from it.
     LX, SRC_X = float(os.environ.get("HS_LX", "300")), float(os.environ.get("HS_SRC_X", "45"))
-    depths = (0.3, 1.0, 1.3, 2.3, 4.3)
+    depths = (0.3, 1.0, 2.3)
     xs = (SRC_X + 45.3, SRC_X + 95.3)
     recv = [(x, 150.0 - z) for x in xs for z in depths]
     out = {}
@@ -32,14 +32,14 @@ def main():
         print("h %.3f P%d" % (h, P))
         for i, (x, y) in enumerate(recv):
             z = 150.0 - y
-            vx, vz = explosive_line_source_halfspace(x - SRC_X, z, 1.0, times, ex.Vp, ex.Vs)
+            vx, vz = explosive_box_source_halfspace(x - SRC_X, z, 1.0, times, ex.Vp, ex.Vs, period=2000.0)
             t1 = (x - SRC_X) / ex.Vs * 0.9194 ** -1 + 0.75          # end of the Rayleigh wave train
             w = (times > 0.3) & (times < t1)
             res = []
             for ours, exact in ((tr[:, i, 0], vx), (-tr[:, i, 1], vz)):
                 res.append((np.dot(ours[w], exact[w]) / np.dot(exact[w], exact[w]), np.corrcoef(ours[w], exact[w])[0, 1],
                             np.linalg.norm(ours[w] - exact[w]) / np.linalg.norm(exact[w])))
-            print("   x %.1f depth %.1f:  vx ratio %.4f corr %.5f misfit %.4f    vz ratio %.4f corr %.5f misfit %.4f"
+            print("   x %.1f depth %.1f:  vx ratio %.5f corr %.6f misfit %.5f    vz ratio %.5f corr %.6f misfit %.5f"
                   % (x, z, res[0][0], res[0][1], res[0][2], res[1][0], res[1][1], res[1][2]))
         sys.stdout.flush()
     np.savez_compressed(os.path.join(ROOT, "gpurun_out", "halfspace_traces_lx%g.npz" % LX), times=times, recv=np.array(recv), **out)
