@@ -4,13 +4,13 @@ exact full-space solution of an explosive point source (oracle/analytic.py explo
 48^3 cubes x 6 tets, P3, the explosive test's material, a Ricker stress source in the 2 x 2 x 2 cubes around the centre
 (the indicator of exactly those 48 cells, assigned cell by cell - a nodal interpolation of the box would drop or add the
 nodes on its faces: volume 125 m^3), receivers 25 m away, before the first reflection
-from the (free) outer boundary.  Needs a GPU."""
+from the (free) outer boundary.  Needs a GPU.  (Kept under tests/: it uses the oracle's exact solutions as the checker.)"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

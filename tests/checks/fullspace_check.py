@@ -2,13 +2,13 @@
 """Source normalisation and P-wave propagation of the HIP path against the exact 2-D full-space solution
 of an explosive line source (oracle/analytic.py): the explosive-source set-up with the source moved to the
 middle of the domain, unit-moment projected source, receivers 30-45 m away in four directions; compared before
-the first reflection (free surface / sponge edge) can arrive.  Needs a GPU."""
+the first reflection (free surface / sponge edge) can arrive.  Needs a GPU.  (Kept under tests/: it uses the oracle's exact solutions as the checker.)"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

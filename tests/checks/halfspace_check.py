@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """HIP path against the exact half-space solution of a buried explosive line source (oracle/analytic.py
 explosive_box_source_halfspace: the point-source solution integrated over the 1 m source box): the reference's explosive-source set-up with the unit-moment projected source, receivers
-inside cells at several depths and two distances; before the reflections from the sponge edges arrive.  Needs a GPU."""
+inside cells at several depths and two distances; before the reflections from the sponge edges arrive.  Needs a GPU.  (Kept under tests/: it uses the oracle's exact solutions as the checker.)"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -358,7 +358,7 @@ def test_fullspace_analytic_on_the_gpu(gpu):
     explosive-source set-up with the source in the interior, unit-moment projected source, h = 1.25 / P3 and
     h = 0.625 / P4, receivers inside cells 30-45 m away, before any reflection arrives.  Amplitude within 1 %
     (0.5 %), relative L2 misfit below 2 % (0.7 %): the normalisation of the stress source (elastic.py:217-218)
-    and the P-wave speed are right (tools/fullspace_check.py, profiles/r03/fullspace_check.txt)."""
+    and the P-wave speed are right (tests/checks/fullspace_check.py, profiles/r03/fullspace_check.txt)."""
     from oracle.analytic import explosive_line_source_2d
     from seigen_amd.harness.explosive_source import ExplosiveSourceLF4
     src = (150.0, 75.0)
@@ -385,7 +385,7 @@ def test_halfspace_analytic_on_the_gpu(gpu):
     25 m from the left one, whose abrupt onset (sigma 0 -> 1000, explosive_source_lf4.py:45) reflects P waves into the
     receivers' windows.  Against the point-source solution integrated over the 1 m source box: both components, two
     distances and depths (h = 0.625, P4), amplitude within 0.05 %, relative L2 misfit below 0.1 % over the whole wave train
-    (tools/halfspace_check.py, profiles/r03/halfspace_check.txt: 1.0000 / 2e-5 .. 2e-4; 3e-4 .. 5e-3 at h = 1.25, P3)."""
+    (tests/checks/halfspace_check.py, profiles/r03/halfspace_check.txt: 1.0000 / 2e-5 .. 2e-4; 3e-4 .. 5e-3 at h = 1.25, P3)."""
     from oracle.analytic import explosive_box_source_halfspace
     from seigen_amd.harness.explosive_source import ExplosiveSourceLF4
     sx = 300.0
@@ -408,11 +408,11 @@ def test_fullspace_3d_analytic_on_the_gpu(gpu):
     test's material, a Ricker stress source (elastic.py:217-218, :285-288) in the 2 x 2 x 2 cubes at the centre of a
     48^3-cube P3 mesh - at three receivers 25 m away in different directions, before any reflection from the outer
     boundary arrives.  Amplitude within 0.1 %, relative L2 misfit below 0.1 %, no transverse motion
-    (tools/fullspace3d_check.py, profiles/r03/fullspace3d_check.txt: 1.0000 / 1e-4 at P3 and P4)."""
+    (tests/checks/fullspace3d_check.py, profiles/r03/fullspace3d_check.txt: 1.0000 / 1e-4 at P3 and P4)."""
     import importlib.util
     from oracle.analytic import explosive_point_source_3d
     spec = importlib.util.spec_from_file_location(
-        "fullspace3d_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fullspace3d_check.py"))
+        "fullspace3d_check", os.path.join(os.path.dirname(os.path.abspath(__file__)), "checks", "fullspace3d_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     t, tr, rel, vp, vol = mod.run(n=48, P=3)
