@@ -208,7 +208,7 @@ class _LocalExchange(object):
                 b.end_step()
 
 
-def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64"):
+def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64", separable=False):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -232,8 +232,12 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64")
         src_nodes = np.unique(r3.integers(0, single.ncells * nd, size=min(40, single.ncells * nd)))
         sv = r3.uniform(-1, 1, size=(3, len(src_nodes), dim, dim))
         src_vals = 0.5 * (sv + np.swapaxes(sv, -1, -2))
+        src_w = np.array([0.7, -1.3, 0.4])
         single.set_absorption(sigma, 4)
-        single.set_source(src_nodes, src_vals)
+        if separable:       # one slice and a weight per step (sg_set_source_separable)
+            single.set_source_separable(src_nodes, src_vals[0], src_w)
+        else:
+            single.set_source(src_nodes, src_vals)
     single.step(3)
     uref, sref = single.get_field(_lib.FIELD_U), single.get_field(_lib.FIELD_S)
 
@@ -264,8 +268,11 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64")
             b.set_absorption(sigma[sel], 4)
             local = {int(c): i for i, c in enumerate(sel)}        # global cell -> cell of this block
             mine = [j for j, g in enumerate(src_nodes) if int(g) // nd in local]
-            b.set_source(np.array([local[int(src_nodes[j]) // nd] * nd + int(src_nodes[j]) % nd for j in mine], dtype=np.int64),
-                         src_vals[:, mine] if mine else None)
+            mynodes = np.array([local[int(src_nodes[j]) // nd] * nd + int(src_nodes[j]) % nd for j in mine], dtype=np.int64)
+            if separable and mine:
+                b.set_source_separable(mynodes, src_vals[0][mine], src_w)
+            else:
+                b.set_source(mynodes, src_vals[:, mine] if mine else None)
         blocks.append(b)
     ex = _LocalExchange(blocks, parts)
     ex.step(3, pipelined)
@@ -296,6 +303,14 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64")
 @pytest.mark.parametrize("pipelined", [True, False])
 def test_multiblock_equals_single_block(gpu, dim, degree, n, grid, pipelined):
     _multiblock_case(dim, degree, n, grid, pipelined)
+
+
+@pytest.mark.parametrize("dim,degree,n,grid", [(3, 3, (40, 3, 4), (2, 1, 2)), (2, 2, (40, 6), (2, 2))])
+def test_multiblock_separable_source(gpu, dim, degree, n, grid):
+    """A separable source (one slice + a weight per step) in blocks with neighbours: the source of a split stage is
+    added part by part (FIRST, then SECOND) with this step's weight; bitwise equal to the single block (and the single
+    block with a separable source equals the one with the table of products: test_separable_source)."""
+    _multiblock_case(dim, degree, n, grid, True, extras=True, separable=True)
 
 
 def test_two_blocks_across_x_at_production_width(gpu):
