@@ -172,3 +172,32 @@ def test_config5_full_size_time_reversal_heterogeneous(gpu):
     du = np.abs(blk.get_field(_lib.FIELD_U) - u0).max()
     ds = np.abs(blk.get_field(_lib.FIELD_S) - s0).max() / 1e7
     assert du < 1e-10 and ds < 1e-10, (du, ds)
+
+
+@pytest.mark.parametrize("case", ["stiffer", "denser"])
+def test_two_layer_reflection_and_transmission_1d(gpu, case):
+    """The heterogeneous extension against theory on the HIP path (oracle counterpart: tests/test_oracle_pins.py): a
+    pulse in a 1-D bar meets an interface between two media (per-cell lambda, mu, density in the physical update) and
+    splits into a reflected and a transmitted pulse with amplitudes (Z1 - Z2) / (Z1 + Z2) and 2 Z1 / (Z1 + Z2)."""
+    _quiet()
+    import math
+    from seigen_amd import ElasticLF4, Function, IntervalMesh
+    n, L, P = 400, 4.0, 3
+    el = ElasticLF4.create(IntervalMesh(n, L), "DG", P, dimension=1, solver="explicit", output=False)
+    X = el.U.node_coords()[..., 0]
+    xi = 2.0
+    right = X.mean(axis=1) > xi
+    rho1, M1 = 1.0, 1.0
+    rho2, M2 = (1.0, 4.0) if case == "stiffer" else (4.0, 1.0)
+    c1, c2 = math.sqrt(M1 / rho1), math.sqrt(M2 / rho2)
+    Z1, Z2 = rho1 * c1, rho2 * c2
+    el.l, el.mu = np.where(right, M2 / 2.0, M1 / 2.0), np.where(right, M2 / 4.0, M1 / 4.0)
+    el.density, el.density_physical, el.dt = np.where(right, rho2, rho1), True, 0.0005
+    g = lambda x: np.exp(-50.0 * (x - 1.0) ** 2)
+    el.u0.assign(Function(el.U).assign(g(X)[..., None]))
+    el.s0.assign(Function(el.S).assign((-Z1 * g(X))[..., None, None]))
+    T = 1.5
+    u1, s1 = el.run(T)
+    R, Tc = (Z1 - Z2) / (Z1 + Z2), 2 * Z1 / (Z1 + Z2)
+    exact = np.where(X < xi, g(X - c1 * T) + R * g(2 * xi - X - c1 * T), Tc * g(xi + (X - xi) * c1 / c2 - c1 * T))
+    assert np.abs(u1.dat.data_cells[..., 0] - exact).max() < 1e-3, case

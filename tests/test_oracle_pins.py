@@ -416,3 +416,45 @@ def test_stage_vectors_fixture_is_current():
     E = ElasticOperators(m, P)
     np.testing.assert_allclose(E.apply_F(d["c2_T"], d["c2_u"]), d["c2_F"], rtol=0, atol=1e-13)
     np.testing.assert_allclose(E.apply_G(d["c2_u"], 0.7, 0.3), d["c2_G"], rtol=0, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------ heterogeneous material
+@pytest.mark.parametrize("case", ["stiffer", "denser"])
+def test_two_layer_reflection_and_transmission_1d(case):
+    """The build-defined heterogeneous extension (each cell scales its own g by its own lambda, mu; per-cell density in
+    the physical update - DESIGN.md section 2; the reference defines no semantics for discontinuous coefficients)
+    against theory: a pulse in a 1-D bar meets an interface between two media and splits into a reflected and a
+    transmitted pulse with the velocity amplitudes (Z1 - Z2) / (Z1 + Z2) and 2 Z1 / (Z1 + Z2), Z = rho c.  Oracle,
+    400 cells, P3: the field after the interaction equals the exact one to 1e-3 of the incident amplitude."""
+    n, L, P = 400, 4.0, 3
+    m = omesh.IntervalMesh(n, L)
+    orc = OracleLF4(m, P)
+    X = m.node_coords(P)[..., 0]
+    xc = X.mean(axis=1)
+    xi = 2.0                                           # the interface, on a cell boundary
+    right = xc > xi
+    rho1, M1 = 1.0, 1.0                                # lambda + 2 mu = 0.5 + 2 * 0.25
+    if case == "stiffer":
+        rho2, M2 = 1.0, 4.0                            # c2 = 2, Z2 = 2
+    else:
+        rho2, M2 = 4.0, 1.0                            # c2 = 1/2, Z2 = 2
+    c1, c2 = math.sqrt(M1 / rho1), math.sqrt(M2 / rho2)
+    Z1, Z2 = rho1 * c1, rho2 * c2
+    orc.l = np.where(right, M2 / 2.0, M1 / 2.0)         # lambda = M / 2, mu = M / 4: lambda + 2 mu = M
+    orc.mu = np.where(right, M2 / 4.0, M1 / 4.0)
+    orc.density = np.where(right, rho2, rho1)
+    orc.density_physical = True
+    g = lambda x: np.exp(-50.0 * (x - 1.0) ** 2)
+    orc.u0 = g(X)[..., None].copy()
+    orc.s0 = (-Z1 * g(X))[..., None, None].copy()       # right-going in medium 1
+    orc.dt = 0.0005
+    T = 1.5                                             # the pulse (at x = 1) crosses x = 2 at t = 1
+    orc.run(T)
+    R, Tc = (Z1 - Z2) / (Z1 + Z2), 2 * Z1 / (Z1 + Z2)
+    exact = np.where(X < xi, g(X - c1 * T) + R * g(2 * xi - X - c1 * T), Tc * g(xi + (X - xi) * c1 / c2 - c1 * T))
+    err = np.abs(orc.u1[..., 0] - exact).max()
+    assert abs(R + 1.0 / 3.0) < 1e-15 and abs(Tc - 2.0 / 3.0) < 1e-15
+    assert err < 1e-3, (case, err)
+    # and the stress is continuous across the interface, the transmitted one - Z2 * u
+    sx = np.where(X < xi, -Z1 * g(X - c1 * T) + Z1 * R * g(2 * xi - X - c1 * T), -Z2 * Tc * g(xi + (X - xi) * c1 / c2 - c1 * T))
+    assert np.abs(orc.s1[..., 0, 0] - sx).max() < 3e-3 * Z2
