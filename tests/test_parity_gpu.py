@@ -29,6 +29,9 @@ CASES = [
     (3, 3, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
     (3, 4, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
     (3, 4, (3, 1, 2), (1.0, 1.0, 1.0), "left"),
+    # tall ragged blocks: the chunked XCD order of the F stages (from 16 layers up), groups straddling rows and layers
+    (3, 3, (5, 3, 17), (1.0, 0.6, 3.4), "left"),
+    (3, 4, (3, 2, 19), (0.6, 0.4, 3.8), "left"),
 ]
 
 
