@@ -372,6 +372,10 @@ def main():
                          "one GPU: one rank's 128^3 share).  8 ranks without this flag: c3 plus a \"config4\" object")
     ap.add_argument("--c4-cubes", type=int, default=256, help="global cubes per axis of config 4 (tests use less)")
     ap.add_argument("--c4-steps", type=int, default=20, help="timed steps of the appended config-4 measurement")
+    ap.add_argument("--grid-sweep", default="448,480,496,512",
+                    help="multi-GPU weak-scaling runs: persistent-grid sizes (SEIGEN_HIP_GRID_BLOCKS) of the launches that "
+                         "overlap an exchange to time after the main measurement, reported as halo.grid_blocks_sweep "
+                         "(empty string: none)")
     ap.add_argument("--timeout", type=float, default=900.0,
                     help="seconds after which a rank that has not finished dumps its stacks and exits non-zero")
     args = ap.parse_args()
@@ -545,11 +549,31 @@ def main():
     if halo is not None:
         out["halo"] = halo
 
-    # 8 ranks, no explicit workload: BASELINE config 4 in the same job (its own mesh, its own barriers)
-    if args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4"):
+    # multi-GPU, weak-scaling workload: how the step time depends on the share of block slots the launches that run
+    # beside an exchange leave to RCCL's kernels (default 15/16; it was tuned on ONE device against a self-send)
+    if world > 1 and workload == "c3" and args.grid_sweep and "SEIGEN_HIP_GRID_BLOCKS" not in os.environ:
         elastic._exchanger = None
         blk.close()
         del elastic, blk
+        sweep = {}
+        for gb in [v for v in args.grid_sweep.split(",") if v.strip()]:
+            os.environ["SEIGEN_HIP_GRID_BLOCKS"] = gb.strip()
+            el_s, _, _, _, _ = build_config3(args, rank, world)
+            ms_s = measure(el_s, args, comm, 30, 3)
+            sweep[gb.strip()] = ms_s["elapsed"] / ms_s["steps"] * 1e3
+            el_s._exchanger = None
+            el_s.block.close()
+            del el_s
+        del os.environ["SEIGEN_HIP_GRID_BLOCKS"]
+        out["halo"]["grid_blocks_sweep_ms_per_step"] = sweep
+        elastic = blk = None
+
+    # 8 ranks, no explicit workload: BASELINE config 4 in the same job (its own mesh, its own barriers)
+    if args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4"):
+        if elastic is not None:
+            elastic._exchanger = None
+            blk.close()
+            del elastic, blk
         el4, grid4, gn4, wname4, _ = build_config4(args, rank, world, args.c4_steps + 3 + 1)
         m4 = measure(el4, args, comm, args.c4_steps, 3)
         dofs4 = int(round(sum(comm.gather(el4.block.u_dofs + el4.block.s_dofs))))

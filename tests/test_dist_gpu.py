@@ -78,6 +78,9 @@ def test_bench_two_ranks_one_gpu(gpu):
     assert out["config"]["cells"] == 2 * 16 ** 3 * 6
     assert "cpu_baseline" not in out
     _check_halo_block(out, 2)
+    # the persistent-grid sweep of the launches that overlap an exchange (tuning data for the first real multi-GPU run)
+    sw = out["halo"]["grid_blocks_sweep_ms_per_step"]
+    assert sorted(sw) == ["448", "480", "496", "512"] and all(v > 0 for v in sw.values())
 
 
 def _check_halo_block(out, world):
