@@ -41,6 +41,7 @@ struct sg_handle {
   // active (cell group, class) items of each region of a split stage (MFMA / lane paths), by sg_region
   int32_t* region_items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int32_t region_nitems[5] = {-1, -1, -1, -1, -1};  // -1: not built yet
+  bool region_whole[5] = {false, false, false, false, false};  // no listed cell group is cut by the region's boxes
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;

@@ -151,13 +151,22 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       if (nlist < 0) {
         const int64_t gw = h->md.gw, ngroups = h->md.ncube_pad / gw;
         std::vector<char> hit((size_t)ngroups, 0);
+        std::vector<int32_t> cnt((size_t)ngroups, 0);
         for (int bx = 0; bx < a.nbox; ++bx)
           for (int ck = a.boxes_o[bx][2]; ck < a.boxes_o[bx][2] + a.boxes_n[bx][2]; ++ck)
             for (int cj = a.boxes_o[bx][1]; cj < a.boxes_o[bx][1] + a.boxes_n[bx][1]; ++cj)
               for (int ci = a.boxes_o[bx][0]; ci < a.boxes_o[bx][0] + a.boxes_n[bx][0]; ++ci) {
                 int64_t cube = ci + (int64_t)h->cfg.n[0] * (cj + (int64_t)h->cfg.n[1] * ck);
                 hit[(size_t)(cube / gw)] = 1;
+                cnt[(size_t)(cube / gw)] += 1;
               }
+        // Whole groups only (always, on meshes whose rows are a multiple of the group width: a shell in x is one
+        // group thick): the kernels then skip the cube coordinates and the box tests, as in a whole-block launch.
+        // (The boxes of a region are disjoint, so the count of a group tells.)
+        bool whole = true;
+        for (int64_t g = 0; g < ngroups; ++g)
+          if (hit[(size_t)g] && cnt[(size_t)g] != std::min<int64_t>(gw, h->md.ncube - g * gw)) whole = false;
+        h->region_whole[region] = whole;
         std::vector<int32_t> items;
         for (int64_t g = 0; g < ngroups; ++g)
           if (hit[(size_t)g])
@@ -170,6 +179,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       }
       a.item_list = list;
       a.nlist = nlist;
+      if (h->use_mfma && h->region_whole[region] && !std::getenv("SEIGEN_HIP_NO_WHOLE")) a.all_active = 1;
     }
     a.nitems = a.item_list ? a.nlist : (int32_t)std::min<int64_t>((h->md.ncube_pad / h->md.gw) * h->ncls, INT32_MAX);
     int rc = h->use_mfma   ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)

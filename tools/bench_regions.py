@@ -18,6 +18,8 @@ from seigen_amd.backend import HipBlock  # noqa: E402
 from seigen_amd.parallel import STAGE_INPUT, STAGE_OUTPUT  # noqa: E402
 
 PIPELINED = "--unpipelined" not in sys.argv
+WHOLE = "--whole" in sys.argv        # experiment: neighbours present (ghost-reading kernels), but one launch per stage
+NOPACK = "--nopack" in sys.argv      # experiment: how much of the overhead the pack launches are
 
 
 def run(mask, n=(64, 64, 64), degree=4, steps=10):
@@ -39,14 +41,15 @@ def run(mask, n=(64, 64, 64), degree=4, steps=10):
 
     def step():
         for stage in range(6):
-            if not sides:
+            if not sides or WHOLE:
                 blk.run_stage(stage, _lib.REGION_ALL)
                 continue
             if PIPELINED:      # HaloExchanger.step
                 field = STAGE_OUTPUT[stage]
                 kind = "s" if field in (_lib.FIELD_S, _lib.FIELD_SH) else "u"
                 blk.run_stage(stage, _lib.REGION_FIRST)
-                blk.halo_pack_sides(field, {s: bufs[(kind, s)][0].data_ptr() for s in sides})
+                if not NOPACK:
+                    blk.halo_pack_sides(field, {s: bufs[(kind, s)][0].data_ptr() for s in sides})
                 blk.run_stage(stage, _lib.REGION_SECOND)
                 continue
             field = STAGE_INPUT[stage]
@@ -127,6 +130,10 @@ if __name__ == "__main__":
             b = breakdown(mask)
             print("%-28s packs %.3f  %s %.3f  %s %.3f ms/step" % (name, b["pack"], "first" if PIPELINED else "interior",
                                                                   b["interior"], "second" if PIPELINED else "shell", b["shell"]))
+        sys.exit(0)
+    if "--mask" in sys.argv:      # one case only (for rocprofv3 --kernel-trace --stats: sums per kernel name)
+        mask = int(sys.argv[sys.argv.index("--mask") + 1], 0)
+        print("mask %s  %.3f ms/step" % (bin(mask), run(mask)))
         sys.exit(0)
     for name, mask in (("no neighbours (REGION_ALL)", 0), ("z- and z+", 0b110000), ("y+, z-, z+", 0b111000),
                        ("x+, y+, z+", 0b101010)):
