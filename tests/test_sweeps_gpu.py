@@ -7,8 +7,8 @@
   (tests/golden/eigenmode_errors.json, tests/golden/make_golden.py) to 1e-9 absolute
   (north star: within 1e-6 of the reference), plus the observed orders of convergence.
 * ``ElasticLF4.create(..., solver=...)`` (seigen/elastic.py:50-64): 'parloop' / 'fusion' /
-  'tiling' run the same arithmetic as 'explicit' (bitwise here), 'implicit' is outside the hot path
-  and raises at run(), an unknown string raises ValueError.
+  'tiling' run the same arithmetic as 'explicit' (bitwise here), 'implicit' runs it with the implicit
+  forms' density convention, an unknown string raises ValueError.
 """
 import json
 import math
@@ -90,11 +90,43 @@ def test_solver_strings_share_the_explicit_path(gpu, solver):
     np.testing.assert_array_equal(s1.dat.data, sb.dat.data)
 
 
-def test_implicit_solver_is_out_of_scope_and_says_so(gpu):
+def test_implicit_solver_is_the_explicit_path_with_the_implicit_density_convention(gpu):
+    """seigen/elastic.py:318-332: every KSP system is a block-diagonal DG mass matrix, so the implicit class runs the
+    explicit arithmetic; only form_u1 differs (:175-178 against :341-345).  rho = 1: bitwise the explicit result;
+    rho = 2: the oracle's LF4 with the density on the left-hand side, and NOT the explicit class's result."""
     _quiet()
-    from seigen_amd import ImplicitElasticLF4
+    from oracle import mesh as omesh
+    from oracle.lf4 import OracleLF4
+    from seigen_amd import ElasticLF4, Function, ImplicitElasticLF4, UnitSquareMesh
     from seigen_amd.harness.eigenmode import Eigenmode2DLF4
-    em = Eigenmode2DLF4(4, 1, 0.0625, solver="implicit", output=False)
-    assert isinstance(em.elastic, ImplicitElasticLF4)
-    with pytest.raises(NotImplementedError, match="implicit"):
-        em.eigenmode2d(T=1.0)
+    N, P = 8, 2
+    dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
+    base = Eigenmode2DLF4(N, P, dt, solver="explicit", output=False)
+    ub, sb = base.eigenmode2d(T=1.0)
+    em = Eigenmode2DLF4(N, P, dt, solver="implicit", output=False)
+    assert isinstance(em.elastic, ImplicitElasticLF4) and em.elastic.density_physical
+    u1, s1 = em.eigenmode2d(T=1.0)
+    np.testing.assert_array_equal(u1.dat.data, ub.dat.data)
+    np.testing.assert_array_equal(s1.dat.data, sb.dat.data)
+
+    rng = np.random.default_rng(5)
+    res = {}
+    for solver in ("implicit", "explicit"):
+        el = ElasticLF4.create(UnitSquareMesh(N, N), "DG", P, dimension=2, solver=solver, output=False)
+        el.density, el.l, el.mu, el.dt = 2.0, 0.5, 0.25, dt
+        if solver == "implicit":
+            u0 = rng.uniform(-1, 1, (el.U.ncells, el.U.nd, 2))
+            s0 = rng.uniform(-1, 1, (el.S.ncells, el.S.nd, 2, 2))
+            s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        el.u0.assign(Function(el.U).assign(u0))
+        el.s0.assign(Function(el.S).assign(s0))
+        u, s = el.run(10 * dt * (1 + 1e-9))
+        res[solver] = (u.dat.data_cells.copy(), s.dat.data_cells.copy())
+    orc = OracleLF4(omesh.structured(2, (N, N), (1.0, 1.0)), P)
+    orc.dt, orc.l, orc.mu, orc.density, orc.density_physical = dt, 0.5, 0.25, 2.0, True
+    orc.u0, orc.s0 = u0.copy(), s0.copy()
+    for k in range(10):
+        orc.step((k + 1) * dt)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(res["implicit"][0], orc.u1) < 1e-12 and rel(res["implicit"][1], orc.s1) < 1e-12
+    assert rel(res["explicit"][0], orc.u1) > 1e-2
