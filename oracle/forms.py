@@ -43,13 +43,14 @@ class ScalarOperators(object):
         self.mesh = mesh
         self.P = P
         d = self.dim = mesh.dim
-        nd = self.nd = refelem.nnodes(d, P)
+        kind = self.kind = getattr(mesh, "kind", "simplex")
+        nd = self.nd = refelem.el_nnodes(d, P, kind)
         nc = mesh.ncells
         self.N = nc * nd
 
         # ---- cell integrals (dx) ------------------------------------------------
-        xq, wq = refelem.simplex_quadrature(d, 2 * P + qdeg_extra)
-        phi, dphi = refelem.tabulate(d, P, xq)          # [q,a], [q,a,r]
+        xq, wq = refelem.el_quadrature(d, 2 * P + qdeg_extra, kind)
+        phi, dphi = refelem.el_tabulate(d, P, xq, kind)          # [q,a], [q,a,r]
         absdet = np.abs(mesh.detJ)
         Mref = np.einsum('q,qa,qb->ab', wq, phi, phi)
         self.Mref = Mref
@@ -81,16 +82,16 @@ class ScalarOperators(object):
         def trace_table(cells, faces, xphys):
             """phi of `cells` at physical points xphys [n,q,d] -> [n,q,nd]."""
             xi = np.einsum('nmi,nqi->nqm', mesh.Jinv[cells], xphys - mesh.v0[cells][:, None, :])
-            ph, _ = refelem.tabulate(d, P, xi.reshape(-1, d))
+            ph, _ = refelem.el_tabulate(d, P, xi.reshape(-1, d), kind)
             return ph.reshape(len(cells), nqf, nd)
 
         def facet_points(cells, faces):
             X = np.empty((len(cells), nqf, d))
-            for ff in range(d + 1):
+            for ff in range(refelem.el_nfaces(d, kind)):
                 sel = np.nonzero(faces == ff)[0]
                 if len(sel) == 0:
                     continue
-                fv = refelem.face_vertices(d, ff)
+                fv = refelem.el_face_vertices(d, ff, kind)
                 V = mesh.vertices[mesh.cells[cells[sel]][:, fv]]      # [n, d, d]
                 X[sel] = np.einsum('qv,nvi->nqi', baryf, V)
             return X
@@ -145,9 +146,9 @@ class ScalarOperators(object):
         nodal values [nc, nd_q] (elastic.py:207-208; the DG4 sponge of
         tests/explosive_source/explosive_source_lf4.py:43-45)."""
         mesh, d, P = self.mesh, self.dim, self.P
-        xq, wq = refelem.simplex_quadrature(d, 2 * P + sigma_degree)
-        phi, _ = refelem.tabulate(d, P, xq)
-        psi, _ = refelem.tabulate(d, sigma_degree, xq)
+        xq, wq = refelem.el_quadrature(d, 2 * P + sigma_degree, self.kind)
+        phi, _ = refelem.el_tabulate(d, P, xq, self.kind)
+        psi, _ = refelem.el_tabulate(d, sigma_degree, xq, self.kind)
         sig_q = np.einsum('qc,nc->nq', psi, np.asarray(sigma_nodes).reshape(mesh.ncells, -1))
         loc = np.einsum('q,n,nq,qa,qb->nab', wq, np.abs(mesh.detJ), sig_q, phi, phi)
         loc = np.einsum('nab,nbc->nac', self.Minv_loc, loc)

@@ -15,9 +15,9 @@ from .lf4 import OracleLF4
 # ----------------------------------------------------------------------------- norms
 def l2_norm(mesh, P, e):
     """sqrt(int |e|^2 dx) of a DG_P field e [nc, nd, ...] (exact: mass matrix)."""
-    d = mesh.dim
-    xq, wq = refelem.simplex_quadrature(d, 2 * P)
-    phi, _ = refelem.tabulate(d, P, xq)
+    d, kind = mesh.dim, getattr(mesh, "kind", "simplex")
+    xq, wq = refelem.el_quadrature(d, 2 * P, kind)
+    phi, _ = refelem.el_tabulate(d, P, xq, kind)
     Mref = np.einsum('q,qa,qb->ab', wq, phi, phi)
     e2 = e.reshape(mesh.ncells, e.shape[1], -1)
     return math.sqrt(np.einsum('c,cak,ab,cbk->', np.abs(mesh.detJ), e2, Mref, e2))
@@ -29,12 +29,12 @@ def projected_abs_norm(mesh, P, e, Pproj):
     component-wise abs of the DG_P field e, L2-projected into DG_Pproj, then
     norm().  [upstream] quadrature degree = Pproj + P (UFL degree estimation:
     abs() keeps the degree of its operand)."""
-    d = mesh.dim
-    xq, wq = refelem.simplex_quadrature(d, Pproj + P)
-    phi, _ = refelem.tabulate(d, P, xq)
-    psi, _ = refelem.tabulate(d, Pproj, xq)
-    xm, wm = refelem.simplex_quadrature(d, 2 * Pproj)
-    psm, _ = refelem.tabulate(d, Pproj, xm)
+    d, kind = mesh.dim, getattr(mesh, "kind", "simplex")
+    xq, wq = refelem.el_quadrature(d, Pproj + P, kind)
+    phi, _ = refelem.el_tabulate(d, P, xq, kind)
+    psi, _ = refelem.el_tabulate(d, Pproj, xq, kind)
+    xm, wm = refelem.el_quadrature(d, 2 * Pproj, kind)
+    psm, _ = refelem.el_tabulate(d, Pproj, xm, kind)
     Mproj = np.einsum('q,qa,qb->ab', wm, psm, psm)
     Minv = np.linalg.inv(Mproj)
     e2 = e.reshape(mesh.ncells, e.shape[1], -1)
@@ -45,8 +45,8 @@ def projected_abs_norm(mesh, P, e, Pproj):
 
 # ----------------------------------------------------------------------------- eigenmode
 class Eigenmode2D(object):
-    def __init__(self, N, degree, dt, diagonal="left"):
-        self.mesh = omesh.UnitSquareMesh(N, N, diagonal)                 # eigenmode_2d.py:11
+    def __init__(self, N, degree, dt, diagonal="left", quadrilateral=False):
+        self.mesh = omesh.UnitSquareMesh(N, N, diagonal, quadrilateral=quadrilateral)   # eigenmode_2d.py:11
         self.elastic = OracleLF4(self.mesh, degree)
         self.elastic.density = 1.0                                        # :17-20
         self.elastic.dt = dt

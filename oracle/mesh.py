@@ -50,13 +50,16 @@ def class_table(dim, diagonal="left"):
 
 
 class Mesh(object):
-    """vertices [nv, dim]; cells [nc, dim+1] vertex ids."""
+    """vertices [nv, dim]; cells [nc, dim+1] vertex ids (kind "simplex"), or [nc, 4] for the affine quadrilaterals
+    of kind "tensor" (local vertices (0,0), (1,0), (0,1), (1,1): refelem.QUAD_FACE_VERTICES)."""
 
-    def __init__(self, vertices, cells):
+    def __init__(self, vertices, cells, kind="simplex"):
         self.vertices = np.asarray(vertices, dtype=np.float64)
         self.cells = np.asarray(cells, dtype=np.int64)
         self.dim = self.vertices.shape[1]
         self.ncells = len(self.cells)
+        self.kind = kind
+        self.nfaces = refelem.el_nfaces(self.dim, kind)
         self._geometry()
         self._facets()
 
@@ -65,7 +68,7 @@ class Mesh(object):
         X = self.vertices[self.cells]              # [nc, d+1, d]
         self.v0 = X[:, 0, :]
         # J[:, i, m] = d x_i / d xi_m
-        self.J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))
+        self.J = np.transpose(X[:, 1:d + 1, :] - X[:, :1, :], (0, 2, 1))   # (quadrilaterals: affine, edges 0-1 and 0-2)
         self.detJ = np.linalg.det(self.J)
         self.Jinv = np.linalg.inv(self.J)          # [nc, m, i] = d xi_m / d x_i
 
@@ -75,8 +78,9 @@ class Mesh(object):
         interior facet in ascending (cell, face) order."""
         d = self.dim
         nc = self.ncells
-        fv = np.array([refelem.face_vertices(d, f) for f in range(d + 1)], dtype=np.int64).reshape(d + 1, -1)
-        keys = np.sort(self.cells[:, fv], axis=2).reshape(nc * (d + 1), -1)      # rows in (cell, face) order
+        nfc = self.nfaces
+        fv = np.array([refelem.el_face_vertices(d, f, self.kind) for f in range(nfc)], dtype=np.int64).reshape(nfc, -1)
+        keys = np.sort(self.cells[:, fv], axis=2).reshape(nc * nfc, -1)          # rows in (cell, face) order
         order = np.lexsort(keys.T[::-1])                                          # stable: ties keep (cell, face) order
         ks = keys[order]
         same = np.zeros(len(order), dtype=bool)
@@ -88,9 +92,9 @@ class Mesh(object):
         paired[first] = True
         paired[first + 1] = True
         a, b = order[first], order[first + 1]
-        self.interior_facets = np.stack([a // (d + 1), a % (d + 1), b // (d + 1), b % (d + 1)], axis=1).astype(np.int64).reshape(-1, 4)
+        self.interior_facets = np.stack([a // nfc, a % nfc, b // nfc, b % nfc], axis=1).astype(np.int64).reshape(-1, 4)
         e = order[~paired]
-        self.exterior_facets = np.stack([e // (d + 1), e % (d + 1)], axis=1).astype(np.int64).reshape(-1, 2)
+        self.exterior_facets = np.stack([e // nfc, e % nfc], axis=1).astype(np.int64).reshape(-1, 2)
 
     def facet_geometry(self, cell, f):
         """Outward unit normal and measure of local face f of the given cells
@@ -100,14 +104,14 @@ class Mesh(object):
         f = np.asarray(f)
         n = np.empty((len(cell), d))
         area = np.empty(len(cell))
-        for ff in range(d + 1):
+        for ff in range(self.nfaces):
             sel = np.nonzero(f == ff)[0]
             if len(sel) == 0:
                 continue
-            fv = refelem.face_vertices(d, ff)
+            fv = refelem.el_face_vertices(d, ff, self.kind)
             X = self.vertices[self.cells[cell[sel]]]      # [n, d+1, d]
             P0 = X[:, fv[0], :]
-            opp = X[:, ff, :]
+            opp = X[:, ff, :] if self.kind == "simplex" else X.mean(axis=1)   # a point on the inner side of the facet
             if d == 1:
                 nn = np.ones((len(sel), 1))
                 ar = np.ones(len(sel))
@@ -130,16 +134,19 @@ class Mesh(object):
 
     def node_coords(self, P):
         """[nc, nd, dim] physical coordinates of the DG nodes."""
-        xi = refelem.node_ref_coords(self.dim, P)           # [nd, d]
+        xi = refelem.el_node_ref_coords(self.dim, P, self.kind)           # [nd, d]
         return self.v0[:, None, :] + np.einsum('cim,am->cai', self.J, xi)
 
 
-def structured(dim, n, L, diagonal="left", origin=None):
-    """n = cells per axis (tuple), L = extents (tuple)."""
+def structured(dim, n, L, diagonal="left", origin=None, quadrilateral=False):
+    """n = cells per axis (tuple), L = extents (tuple).  quadrilateral (2-D): the squares themselves are the cells
+    ([upstream] ``UnitSquareMesh(N, N, quadrilateral=True)``)."""
     n = tuple(int(x) for x in n)
     L = tuple(float(x) for x in L)
     origin = (0.0,) * dim if origin is None else tuple(origin)
-    classes = class_table(dim, diagonal)
+    if quadrilateral and dim != 2:
+        raise ValueError("tensor-product cells: 2-D only")
+    classes = [[(0, 0), (1, 0), (0, 1), (1, 1)]] if quadrilateral else class_table(dim, diagonal)
     nvx = [k + 1 for k in n]
     # vertex id with x fastest
     strides = [1]
@@ -157,16 +164,16 @@ def structured(dim, n, L, diagonal="left", origin=None):
     cube = np.transpose(cube, tuple(reversed(range(dim))) + (dim,)).reshape(-1, dim)        # x fastest
     off = np.array(classes, dtype=np.int64)                                                 # [ncls, dim+1, dim]
     st = np.array(strides, dtype=np.int64)
-    cells = ((cube[:, None, None, :] + off[None]) * st).sum(axis=-1).reshape(-1, dim + 1)
-    return Mesh(vertices, cells)
+    cells = ((cube[:, None, None, :] + off[None]) * st).sum(axis=-1).reshape(-1, off.shape[1])
+    return Mesh(vertices, cells, "tensor" if quadrilateral else "simplex")
 
 
-def UnitSquareMesh(nx, ny, diagonal="left"):
-    return structured(2, (nx, ny), (1.0, 1.0), diagonal)
+def UnitSquareMesh(nx, ny, diagonal="left", quadrilateral=False):
+    return structured(2, (nx, ny), (1.0, 1.0), diagonal, quadrilateral=quadrilateral)
 
 
-def RectangleMesh(nx, ny, Lx, Ly, diagonal="left"):
-    return structured(2, (nx, ny), (Lx, Ly), diagonal)
+def RectangleMesh(nx, ny, Lx, Ly, diagonal="left", quadrilateral=False):
+    return structured(2, (nx, ny), (Lx, Ly), diagonal, quadrilateral=quadrilateral)
 
 
 def UnitCubeMesh(nx, ny, nz):

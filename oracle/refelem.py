@@ -139,3 +139,73 @@ def face_nodes(dim, P, f):
 
 def node_ref_coords(dim, P):
     return lattice(dim, P).astype(np.float64) / P
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tensor-product cells (quadrilaterals).  [upstream] On a quadrilateral mesh ``FunctionSpace(mesh, "DG", k)`` -
+# the call of seigen/elastic.py:81-82, which is family-agnostic - is DQ_k: the tensor product of two interval
+# DiscontinuousLagrange elements, i.e. the Lagrange basis at the (k+1)^2 equispaced lattice points of the unit
+# square.  Node order: first reference coordinate fastest (this build's convention, as for simplices).
+# Local vertices: 0 (0,0), 1 (1,0), 2 (0,1), 3 (1,1); faces: 0 x=0, 1 x=1, 2 y=0, 3 y=1.
+# The functions below dispatch on `kind` ("simplex" / "tensor"); the simplex ones above are unchanged.
+QUAD_FACE_VERTICES = [[0, 2], [1, 3], [0, 1], [2, 3]]
+
+
+def el_lattice(dim, P, kind="simplex"):
+    if kind == "simplex" or dim == 1:
+        return lattice(dim, P)
+    if dim != 2:
+        raise ValueError("tensor-product cells: 2-D only")
+    return np.array([(a1, a2) for a2 in range(P + 1) for a1 in range(P + 1)], dtype=np.int64)
+
+
+def el_nnodes(dim, P, kind="simplex"):
+    return len(el_lattice(dim, P, kind))
+
+
+def el_nfaces(dim, kind="simplex"):
+    return dim + 1 if kind == "simplex" else 2 * dim
+
+
+def el_tabulate(dim, P, xi, kind="simplex"):
+    if kind == "simplex" or dim == 1:
+        return tabulate(dim, P, xi)
+    xi = np.atleast_2d(np.asarray(xi, dtype=np.float64))
+    lat = el_lattice(dim, P, kind)
+    one = [tabulate(1, P, xi[:, m:m + 1]) for m in range(dim)]      # ([npts, P+1], [npts, P+1, 1]) per axis
+    phi = np.ones((len(xi), len(lat)))
+    dphi = np.ones((len(xi), len(lat), dim))
+    for m in range(dim):
+        v, dv = one[m][0][:, lat[:, m]], one[m][1][:, lat[:, m], 0]
+        phi *= v
+        for r in range(dim):
+            dphi[:, :, r] *= dv if r == m else v
+    return phi, dphi
+
+
+def el_quadrature(dim, degree, kind="simplex"):
+    """Exact for total degree <= `degree` on simplices; for degree <= `degree` PER VARIABLE on tensor cells
+    (Gauss-Legendre products).  Weights sum to the reference cell's measure."""
+    if kind == "simplex" or dim <= 1:
+        return simplex_quadrature(dim, degree)
+    t, w = _gj01(max(1, degree // 2 + 1), 0.0)
+    pts = np.array([(ti, tj) for tj in t for ti in t])
+    wts = np.array([wi * wj for wj in w for wi in w])
+    return pts, wts
+
+
+def el_face_vertices(dim, f, kind="simplex"):
+    if kind == "simplex":
+        return face_vertices(dim, f)
+    return QUAD_FACE_VERTICES[f]
+
+
+def el_face_nodes(dim, P, f, kind="simplex"):
+    if kind == "simplex":
+        return face_nodes(dim, P, f)
+    lat = el_lattice(dim, P, kind)
+    return np.nonzero(lat[:, f // 2] == (P if f % 2 else 0))[0]
+
+
+def el_node_ref_coords(dim, P, kind="simplex"):
+    return el_lattice(dim, P, kind).astype(np.float64) / P

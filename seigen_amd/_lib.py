@@ -72,6 +72,8 @@ SYMBOLS = {
     "sg_reference_operator": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
     "sg_region_boxes": (C.c_int, [C.POINTER(SgConfig), C.c_int, _P, C.c_int]),
     "sg_tabulate": (C.c_int, [C.c_int, C.c_int, C.c_int64, _P, _P]),
+    "sg_tabulate_cell": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),
+    "sg_reference_operator_cell": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
     "sg_mesh_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
 }
 

@@ -23,7 +23,7 @@ class HipBlock(object):
             cfg.n[a] = int(n[a]) if a < dim else 1
             cfg.h[a] = float(h[a]) if a < dim else 1.0
             cfg.origin[a] = float(origin[a]) if a < dim else 0.0
-        cfg.diagonal = 1 if diagonal == "right" else 0
+        cfg.diagonal = {"left": 0, "right": 1, "quadrilateral": 2}[diagonal]   # 2: the squares are the cells
         cfg.nbr_mask = int(nbr_mask)
         cfg.device = int(device)
         cfg.stream = C.c_void_p(stream) if stream else None
@@ -76,6 +76,8 @@ class HipBlock(object):
         degree = self.degree if degree is None else int(degree)
         nq = {1: degree + 1, 2: (degree + 1) * (degree + 2) // 2,
               3: (degree + 1) * (degree + 2) * (degree + 3) // 6}[self.dim]
+        if self.nfaces == 2 * self.dim and self.dim > 1:      # tensor-product cells
+            nq = (degree + 1) ** self.dim
         out = np.empty((self.ncells, nq, self.dim))
         check(self.lib.sg_node_coords(self.h, degree, out.ctypes.data, out.nbytes), self.h)
         return out

@@ -9,6 +9,10 @@ std::string g_create_err;
 // MFMA and tile kernels, 64 for the lane kernels, 1 = host layout for the generic kernel).
 KernelPath choose_kernel_path(const sg_config& cfg) {
   KernelPath kp;
+  if (cfg.diagonal == SG_DIAGONAL_QUAD) {   // quadrilateral cells: the table-driven generic kernels (host layout)
+    kp.gw = 1;
+    return kp;
+  }
   const int ncls = cfg.dim == 1 ? 1 : (cfg.dim == 2 ? 2 : 6);
   // kernel path: MFMA kernels (interleaved layout) where they exist, unless SEIGEN_HIP_PATH=generic
   const char* path_env = std::getenv("SEIGEN_HIP_PATH");
@@ -121,7 +125,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   HIPCHECK(h, hipSetDevice(cfg->device));
 
   try {
-    h->re = make_refelem(cfg->dim, cfg->degree);
+    h->re = make_refelem(cfg->dim, cfg->degree, cfg->diagonal == SG_DIAGONAL_QUAD ? KIND_TENSOR : KIND_SIMPLEX);
     std::memset(&h->md, 0, sizeof(MeshDev));
     h->md.nd = h->re.nd;
     h->md.nf = h->re.nf;
@@ -365,11 +369,21 @@ int sg_sync(sg_handle* h) {
 int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t nbytes) {
   if (!cfg || !out || degree < 1 || degree > 8 || cfg->dim < 1 || cfg->dim > 3) return SG_ERR_ARG;
   const int d = cfg->dim;
+  const bool quad = cfg->diagonal == SG_DIAGONAL_QUAD;
+  if (quad && d != 2) return SG_ERR_ARG;
+  const int kind = quad ? KIND_TENSOR : KIND_SIMPLEX;
   std::vector<int> lat;
-  lattice_points(d, degree, lat);
-  const int nq = num_nodes(d, degree);
+  lattice_points(d, degree, lat, kind);
+  const int nq = num_nodes(d, degree, kind);
   int off[MAX_CLS][4][3], ncls;
-  class_vertices(d, cfg->diagonal, ncls, off);
+  if (quad) {   // vertex 0 the low corner, vertex 1 / 2 one cell along x / y: the affine map of refelem.hpp's unit square
+    std::memset(off, 0, sizeof(off));
+    ncls = 1;
+    off[0][1][0] = 1;
+    off[0][2][1] = 1;
+  } else {
+    class_vertices(d, cfg->diagonal, ncls, off);
+  }
   int n[3] = {1, 1, 1};
   for (int a = 0; a < d; ++a) n[a] = cfg->n[a];
   if (nbytes != (size_t)n[0] * n[1] * n[2] * ncls * nq * d * sizeof(double)) return SG_ERR_ARG;
@@ -471,9 +485,9 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   if (!sigma_nodes) return SG_OK;
   if (sigma_degree < 1 || sigma_degree > 6) return fail(h, SG_ERR_ARG, "sigma_degree must be 1..6");
   const int d = h->cfg.dim, nd = h->re.nd;
-  const int nq = num_nodes(d, sigma_degree);
+  const int nq = num_nodes(d, sigma_degree, h->re.kind);
   // B_e[a][b] = sum_c A[a][c][b] sigma_{e,c}  for cells with a non-zero sigma
-  std::vector<double> A = sponge_tensor(d, h->cfg.degree, sigma_degree);
+  std::vector<double> A = sponge_tensor(d, h->cfg.degree, sigma_degree, h->re.kind);
   std::vector<int32_t> slot((size_t)h->ncells, -1);
   std::vector<double> B;
   int32_t nslots = 0;
@@ -654,13 +668,18 @@ int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in) {
 }
 
 int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out, size_t nbytes) {
+  return sg_reference_operator_cell(0, dim, degree, which, q, out, nbytes);
+}
+
+int64_t sg_reference_operator_cell(int cell_type, int dim, int degree, int which, int q, double* out, size_t nbytes) {
   std::vector<double> v;
+  if (cell_type != KIND_SIMPLEX && cell_type != KIND_TENSOR) return SG_ERR_ARG;
   try {
     if (which == 3) {
       if (q < 1 || q > 6 || dim < 1 || dim > 3 || degree < 1 || degree > 4) return SG_ERR_ARG;
-      v = sponge_tensor(dim, degree, q);
+      v = sponge_tensor(dim, degree, q, cell_type);
     } else {
-      RefElem re = make_refelem(dim, degree);
+      RefElem re = make_refelem(dim, degree, cell_type);
       if (which == 0) v = re.D;
       else if (which == 1) v = re.L;
       else if (which == 2) v = re.Mhat;
@@ -679,8 +698,13 @@ int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out
 }
 
 int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi) {
+  return sg_tabulate_cell(0, dim, degree, npts, xi, phi);
+}
+
+int sg_tabulate_cell(int cell_type, int dim, int degree, int64_t npts, const double* xi, double* phi) {
   if (dim < 1 || dim > 3 || degree < 1 || degree > 8 || npts < 0 || !xi || !phi) return SG_ERR_ARG;
-  tabulate(dim, degree, (int)npts, xi, phi);
+  if (cell_type != KIND_SIMPLEX && !(cell_type == KIND_TENSOR && dim <= 2)) return SG_ERR_ARG;
+  tabulate(dim, degree, (int)npts, xi, phi, cell_type);
   return SG_OK;
 }
 
@@ -688,7 +712,7 @@ int sg_mesh_tables(int dim, int degree, int diagonal, const double* h, int32_t* 
                    double* jinv) {
   if (!h || !nb || !nb_node || !cn || !jinv) return SG_ERR_ARG;
   try {
-    RefElem re = make_refelem(dim, degree);
+    RefElem re = make_refelem(dim, degree, diagonal == SG_DIAGONAL_QUAD ? KIND_TENSOR : KIND_SIMPLEX);
     MeshDev md;
     std::memset(&md, 0, sizeof(md));
     md.nd = re.nd;

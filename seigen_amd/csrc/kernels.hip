@@ -20,9 +20,9 @@
 
 namespace sg {
 
-template <int DIM, int P>
-struct Geo : ElemDims<DIM, P> {
-  using ElemDims<DIM, P>::ND;
+template <int DIM, int P, int TP = 0>
+struct Geo : ElemDims<DIM, P, TP> {
+  using ElemDims<DIM, P, TP>::ND;
   static constexpr int BLOCK = 256;
   static constexpr int EB_RAW = BLOCK / ND;
   static constexpr int EB = EB_RAW > 32 ? 32 : EB_RAW;  // cells per workgroup
@@ -42,9 +42,9 @@ __device__ __forceinline__ long cube2d(int axis, const int c[3], const int n[3])
   return c[0] + (long)n[0] * c[1];
 }
 
-template <int DIM, int P, int KIND>
+template <int DIM, int P, int KIND, int TP = 0>
 __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
-  using G = Geo<DIM, P>;
+  using G = Geo<DIM, P, TP>;
   constexpr int ND = G::ND, NF = G::NF, NFACES = G::NFACES, NCLS = G::NCLS, EB = G::EB;
   constexpr int NC = (KIND == 0) ? DIM * DIM : DIM;  // input components per node
   constexpr int NT = 256;
@@ -297,18 +297,29 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
   }
 }
 
-template <int DIM, int P>
+template <int DIM, int P, int TP = 0>
 static int launch_dp(int kind, const StageArgs& a, hipStream_t s) {
-  using G = Geo<DIM, P>;
+  using G = Geo<DIM, P, TP>;
   long nelem = (long)a.box_n[0] * a.box_n[1] * a.box_n[2] * G::NCLS;
   if (nelem <= 0) return 0;
   long nbatch = (nelem + G::EB - 1) / G::EB;
   long grid = nbatch < 256L * 8 ? nbatch : 256L * 8;
   if (kind == 0)
-    hipLaunchKernelGGL((stage_kernel<DIM, P, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stage_kernel<DIM, P, 0, TP>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((stage_kernel<DIM, P, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stage_kernel<DIM, P, 1, TP>), dim3((unsigned)grid), dim3(256), 0, s, a);
   return (int)hipGetLastError();
+}
+
+// quadrilateral cells (tensor-product element): the same kernel over the tables of build_quad_tables
+static int launch_quad(int kind, int P, const StageArgs& a, hipStream_t s) {
+  switch (P) {
+    case 1: return launch_dp<2, 1, 1>(kind, a, s);
+    case 2: return launch_dp<2, 2, 1>(kind, a, s);
+    case 3: return launch_dp<2, 3, 1>(kind, a, s);
+    case 4: return launch_dp<2, 4, 1>(kind, a, s);
+  }
+  return -1;
 }
 
 template <int DIM>
@@ -324,6 +335,7 @@ static int launch_d(int kind, int P, const StageArgs& a, hipStream_t s) {
 
 int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.tensor) return dim == 2 ? launch_quad(kind, P, a, s) : -1;
   switch (dim) {
     case 1: return launch_d<1>(kind, P, a, s);
     case 2: return launch_d<2>(kind, P, a, s);

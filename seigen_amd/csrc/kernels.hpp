@@ -12,12 +12,14 @@ constexpr int SG_MAX_BOXES = 7;
 
 // Node / facet counts of the P_k simplex element, shared by the three kernel families
 // (kernels.hip `Geo`, kernels_lane.hip `LG`, kernels_mfma.hip `MG`).
-template <int DIM, int P>
+// TP = 1: the tensor-product element on quadrilaterals (DIM = 2; generic kernels only).
+template <int DIM, int P, int TP = 0>
 struct ElemDims {
-  static constexpr int ND = (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
+  static constexpr int ND = TP ? (P + 1) * (P + 1)
+                               : (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
   static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
-  static constexpr int NFACES = DIM + 1;
-  static constexpr int NCLS = (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
+  static constexpr int NFACES = TP ? 2 * DIM : DIM + 1;
+  static constexpr int NCLS = TP ? 1 : (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
 };
 
 // What the MFMA stage kernels need to know about the mesh, laid out for SCALAR loads: everything is uniform over
@@ -63,6 +65,7 @@ struct StageArgs {
   // tests): 256 B per item read with one 16-byte load per lane, against 76 KB of cell data.
   const int32_t* nbr_tab;
   int32_t all_active;      // the launch covers the whole block (no region boxes to test)
+  int32_t tensor;          // generic path: quadrilateral cells (ElemDims<2, P, 1>)
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null

@@ -65,8 +65,44 @@ static void invert_small(int d, const double J[3][3], double Ji[3][3], double& d
   }
 }
 
+// Quadrilateral cells (diagonal == SG_DIAGONAL_QUAD): the squares themselves, one class, four facets
+// (0: x = 0, 1: x = 1, 2: y = 0, 3: y = 1, refelem.hpp); facet nodes run along the transverse axis on both
+// sides of a facet, so facet node b meets the neighbour's facet node b.
+static void build_quad_tables(int P, const double h[3], const int* fnode, MeshDev& md) {
+  md.dim = 2;
+  md.P = P;
+  md.ncls = 1;
+  md.nfaces = 4;
+  md.halo_per_cube = 1;
+  const int nf = md.nf;
+  for (int f = 0; f < 4; ++f)
+    for (int b = 0; b < nf; ++b) md.fnode[f][b] = (uint8_t)fnode[f * nf + b];
+  for (int r = 0; r < 3; ++r)
+    for (int j = 0; j < 3; ++j) md.Jinv[0][r][j] = (r == j && r < 2) ? 1.0 / h[r] : 0.0;
+  for (int f = 0; f < 4; ++f) {
+    const int axis = f / 2, dir = (f % 2) ? 1 : -1;
+    for (int j = 0; j < 3; ++j) md.cn[0][f][j] = (j == axis) ? dir / h[axis] : 0.0;   // |F| / |K| = 1 / h_axis
+    md.nb_axis[0][f] = axis;
+    md.nb_dir[0][f] = dir;
+    md.nb_cls[0][f] = 0;
+    md.nb_face[0][f] = f ^ 1;
+    md.face_ord[0][f] = 0;
+    md.side_cls[f][0] = 0;      // block side 2 * axis + (dir > 0) = f
+    md.side_face[f][0] = (int8_t)f;
+    for (int b = 0; b < nf; ++b) {
+      md.nb_node[0][f][b] = md.fnode[f ^ 1][b];
+      md.nb_fnode[0][f][b] = (uint8_t)b;
+    }
+  }
+}
+
 void build_mesh_tables(int dim, int P, int diagonal, const double h[3], const int* fnode, const int* lattice,
                        MeshDev& md) {
+  if (diagonal == SG_DIAGONAL_QUAD) {
+    if (dim != 2) throw std::runtime_error("quadrilateral cells: 2-D only");
+    build_quad_tables(P, h, fnode, md);
+    return;
+  }
   int off[MAX_CLS][4][3];
   int ncls;
   class_vertices(dim, diagonal, ncls, off);

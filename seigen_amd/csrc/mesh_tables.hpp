@@ -12,6 +12,7 @@
 
 namespace sg {
 
+constexpr int SG_DIAGONAL_QUAD = 2;   // sg_config::diagonal: the squares are the cells (tensor-product element)
 constexpr int MAX_CLS = 6;
 constexpr int MAX_FACES = 4;
 constexpr int MAX_NF = 15;

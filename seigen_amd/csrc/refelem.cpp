@@ -9,18 +9,26 @@ namespace sg {
 
 typedef long double real;
 
-int num_nodes(int dim, int P) {
+int num_nodes(int dim, int P, int kind) {
   if (dim == 0) return 1;
   if (dim == 1) return P + 1;
+  if (kind == KIND_TENSOR) return dim == 2 ? (P + 1) * (P + 1) : (P + 1) * (P + 1) * (P + 1);
   if (dim == 2) return (P + 1) * (P + 2) / 2;
   return (P + 1) * (P + 2) * (P + 3) / 6;
 }
 
-void lattice_points(int dim, int P, std::vector<int>& out) {
+void lattice_points(int dim, int P, std::vector<int>& out, int kind) {
   out.clear();
   if (dim == 0) return;
   if (dim == 1) {
     for (int a = 0; a <= P; ++a) out.push_back(a);
+  } else if (kind == KIND_TENSOR) {
+    if (dim != 2) throw std::runtime_error("tensor-product cells: 2-D only");
+    for (int a2 = 0; a2 <= P; ++a2)
+      for (int a1 = 0; a1 <= P; ++a1) {
+        out.push_back(a1);
+        out.push_back(a2);
+      }
   } else if (dim == 2) {
     for (int a2 = 0; a2 <= P; ++a2)
       for (int a1 = 0; a1 <= P - a2; ++a1) {
@@ -44,10 +52,14 @@ static real factorial(int n) {
   return f;
 }
 
-// int over the unit dim-simplex of xi^g = prod g_i! / (|g| + dim)!
-static real mono_integral(int dim, const int* g) {
+// int over the unit dim-simplex of xi^g = prod g_i! / (|g| + dim)!;  over the unit square / cube: prod 1 / (g_i + 1)
+static real mono_integral(int dim, const int* g, int kind = KIND_SIMPLEX) {
   int s = 0;
   real num = 1;
+  if (kind == KIND_TENSOR && dim > 1) {
+    for (int i = 0; i < dim; ++i) num /= (real)(g[i] + 1);
+    return num;
+  }
   for (int i = 0; i < dim; ++i) {
     s += g[i];
     num *= factorial(g[i]);
@@ -90,7 +102,7 @@ static void invert(std::vector<real>& A, int n) {
 // Monomial coefficients of the Lagrange basis: phi_a = sum_m C[m*nd + a] xi^gamma_m,
 // gamma_m = lattice point m (the lattice doubles as the exponent set of P_k).
 static std::vector<real> lagrange_coeffs(int dim, int P, const std::vector<int>& lat) {
-  int nd = num_nodes(dim, P);
+  int nd = (int)lat.size() / (dim > 0 ? dim : 1);
   std::vector<real> V(nd * nd);
   for (int a = 0; a < nd; ++a)
     for (int m = 0; m < nd; ++m) {
@@ -109,8 +121,8 @@ struct MassPack {
   std::vector<real> M, Minv;
 };
 
-static MassPack mass_matrix(int dim, int P) {
-  int nd = num_nodes(dim, P);
+static MassPack mass_matrix(int dim, int P, int kind = KIND_SIMPLEX) {
+  int nd = num_nodes(dim, P, kind);
   MassPack mp;
   mp.M.assign(nd * nd, 0);
   if (dim == 0) {
@@ -119,7 +131,7 @@ static MassPack mass_matrix(int dim, int P) {
     return mp;
   }
   std::vector<int> lat;
-  lattice_points(dim, P, lat);
+  lattice_points(dim, P, lat, kind);
   std::vector<real> C = lagrange_coeffs(dim, P, lat);
   // Mmono[m][n]
   std::vector<real> Mm(nd * nd);
@@ -127,7 +139,7 @@ static MassPack mass_matrix(int dim, int P) {
   for (int m = 0; m < nd; ++m)
     for (int n = 0; n < nd; ++n) {
       for (int i = 0; i < dim; ++i) g[i] = lat[m * dim + i] + lat[n * dim + i];
-      Mm[m * nd + n] = mono_integral(dim, g);
+      Mm[m * nd + n] = mono_integral(dim, g, kind);
     }
   // M = C^T Mm C
   std::vector<real> T(nd * nd, 0);
@@ -158,18 +170,65 @@ static int lattice_index(int dim, int P, const std::vector<int>& lat, const int*
   return -1;
 }
 
-RefElem make_refelem(int dim, int P) {
-  if (dim < 1 || dim > 3 || P < 1 || P > 4) throw std::runtime_error("dim must be 1..3 and degree 1..4");
+// The tensor-product element from the interval element (Kronecker products: node a = a1 + (P+1) a2):
+//   Mhat = M1(y) x M1(x),  D_0 = I x D1,  D_1 = D1 x I,
+//   L_f[(a2, a1)][b] = M1^-1[a_axis][at] delta(a_transverse, b)   (face f: axis f / 2 at node at = 0 or P),
+// so the conditioning is the interval's (a 25 x 25 Vandermonde matrix of tensor monomials would cost five digits).
+static RefElem make_tensor_refelem(int dim, int P) {
+  if (dim != 2) throw std::runtime_error("tensor-product cells are implemented in 2-D (quadrilaterals) only");
+  const RefElem r1 = make_refelem(1, P, KIND_SIMPLEX);
+  const int n1 = P + 1, nd = n1 * n1;
   RefElem re;
   re.dim = dim;
   re.P = P;
-  re.nd = num_nodes(dim, P);
-  re.nf = num_nodes(dim - 1, P);
-  re.nfaces = dim + 1;
-  lattice_points(dim, P, re.lattice);
+  re.kind = KIND_TENSOR;
+  re.nd = nd;
+  re.nf = n1;
+  re.nfaces = 4;
+  lattice_points(dim, P, re.lattice, KIND_TENSOR);
+  re.Mhat.assign((size_t)nd * nd, 0.0);
+  re.Minv.assign((size_t)nd * nd, 0.0);
+  re.D.assign((size_t)2 * nd * nd, 0.0);
+  for (int a2 = 0; a2 < n1; ++a2)
+    for (int a1 = 0; a1 < n1; ++a1)
+      for (int b2 = 0; b2 < n1; ++b2)
+        for (int b1 = 0; b1 < n1; ++b1) {
+          const int a = a1 + n1 * a2, b = b1 + n1 * b2;
+          re.Mhat[(size_t)a * nd + b] = r1.Mhat[a1 * n1 + b1] * r1.Mhat[a2 * n1 + b2];
+          re.Minv[(size_t)a * nd + b] = r1.Minv[a1 * n1 + b1] * r1.Minv[a2 * n1 + b2];
+          if (a2 == b2) re.D[((size_t)0 * nd + a) * nd + b] = r1.D[a1 * n1 + b1];
+          if (a1 == b1) re.D[((size_t)1 * nd + a) * nd + b] = r1.D[a2 * n1 + b2];
+        }
+  re.fnode.assign((size_t)4 * n1, -1);
+  re.L.assign((size_t)4 * nd * n1, 0.0);
+  for (int f = 0; f < 4; ++f) {
+    const int axis = f / 2, at = (f % 2) ? P : 0;
+    for (int b = 0; b < n1; ++b) re.fnode[(size_t)f * n1 + b] = axis == 0 ? at + n1 * b : b + n1 * at;
+    for (int a2 = 0; a2 < n1; ++a2)
+      for (int a1 = 0; a1 < n1; ++a1) {
+        const int a = a1 + n1 * a2, along = axis == 0 ? a1 : a2, across = axis == 0 ? a2 : a1;
+        re.L[((size_t)f * nd + a) * n1 + across] = r1.Minv[along * n1 + at];
+      }
+  }
+  return re;
+}
+
+RefElem make_refelem(int dim, int P, int kind) {
+  if (dim < 1 || dim > 3 || P < 1 || P > 4) throw std::runtime_error("dim must be 1..3 and degree 1..4");
+  if (kind != KIND_SIMPLEX && !(kind == KIND_TENSOR && dim == 2))
+    throw std::runtime_error("tensor-product cells are implemented in 2-D (quadrilaterals) only");
+  if (kind == KIND_TENSOR) return make_tensor_refelem(dim, P);
+  RefElem re;
+  re.dim = dim;
+  re.P = P;
+  re.kind = kind;
+  re.nd = num_nodes(dim, P, kind);
+  re.nf = num_nodes(dim - 1, P, kind);
+  re.nfaces = kind == KIND_TENSOR ? 2 * dim : dim + 1;
+  lattice_points(dim, P, re.lattice, kind);
   const int nd = re.nd, nf = re.nf;
   std::vector<real> C = lagrange_coeffs(dim, P, re.lattice);
-  MassPack mp = mass_matrix(dim, P);
+  MassPack mp = mass_matrix(dim, P, kind);
 
   // Shat_r[a][b] = int d(phi_a)/d(xi_r) phi_b
   re.D.assign((size_t)dim * nd * nd, 0.0);
@@ -183,7 +242,7 @@ RefElem make_refelem(int dim, int P) {
       for (int n = 0; n < nd; ++n) {
         for (int i = 0; i < dim; ++i) g[i] = re.lattice[m * dim + i] + re.lattice[n * dim + i];
         g[r] -= 1;
-        Sm[m * nd + n] = (real)gr * mono_integral(dim, g);
+        Sm[m * nd + n] = (real)gr * mono_integral(dim, g, kind);
       }
     }
     std::vector<real> T(nd * nd, 0), S(nd * nd, 0);
@@ -216,9 +275,9 @@ RefElem make_refelem(int dim, int P) {
   // facets: face f is opposite vertex f; its nodes have barycentric lambda_f = 0.
   // The restriction of the P_k Lagrange basis to a facet is the (dim-1)-simplex P_k
   // Lagrange basis on the facet's own lattice, so Mface_unit = (dim-1)! * Mhat^{(dim-1)}.
-  MassPack fm = mass_matrix(dim - 1, P);
+  MassPack fm = mass_matrix(dim - 1, P, kind);
   std::vector<int> flat;
-  lattice_points(dim - 1, P, flat);
+  lattice_points(dim - 1, P, flat, kind);
   real fact = factorial(dim - 1);
   re.fnode.assign((size_t)re.nfaces * nf, -1);
   re.L.assign((size_t)re.nfaces * nd * nf, 0.0);
@@ -262,10 +321,24 @@ RefElem make_refelem(int dim, int P) {
   return re;
 }
 
-void tabulate(int dim, int P, int npts, const double* xi, double* phi) {
-  int nd = num_nodes(dim, P);
+void tabulate(int dim, int P, int npts, const double* xi, double* phi, int kind) {
+  if (kind == KIND_TENSOR && dim == 2) {
+    const int n1 = P + 1;
+    std::vector<double> x(npts), y(npts), px((size_t)npts * n1), py((size_t)npts * n1);
+    for (int p = 0; p < npts; ++p) {
+      x[p] = xi[2 * p];
+      y[p] = xi[2 * p + 1];
+    }
+    tabulate(1, P, npts, x.data(), px.data(), KIND_SIMPLEX);
+    tabulate(1, P, npts, y.data(), py.data(), KIND_SIMPLEX);
+    for (int p = 0; p < npts; ++p)
+      for (int a2 = 0; a2 < n1; ++a2)
+        for (int a1 = 0; a1 < n1; ++a1) phi[(size_t)p * n1 * n1 + a1 + n1 * a2] = px[(size_t)p * n1 + a1] * py[(size_t)p * n1 + a2];
+    return;
+  }
+  int nd = num_nodes(dim, P, kind);
   std::vector<int> lat;
-  lattice_points(dim, P, lat);
+  lattice_points(dim, P, lat, kind);
   std::vector<real> C = lagrange_coeffs(dim, P, lat);
   std::vector<real> mono(nd);
   for (int p = 0; p < npts; ++p) {
@@ -283,14 +356,28 @@ void tabulate(int dim, int P, int npts, const double* xi, double* phi) {
   }
 }
 
-std::vector<double> sponge_tensor(int dim, int P, int q) {
-  int nd = num_nodes(dim, P), nq = num_nodes(dim, q);
+std::vector<double> sponge_tensor(int dim, int P, int q, int kind) {
+  if (kind == KIND_TENSOR && dim == 2) {   // A[(a2,a1)][(c2,c1)][(b2,b1)] = A1[a1][c1][b1] A1[a2][c2][b2]
+    const std::vector<double> A1 = sponge_tensor(1, P, q, KIND_SIMPLEX);
+    const int n1 = P + 1, q1 = q + 1, nd2 = n1 * n1, nq2 = q1 * q1;
+    std::vector<double> A((size_t)nd2 * nq2 * nd2);
+    for (int a2 = 0; a2 < n1; ++a2)
+      for (int a1 = 0; a1 < n1; ++a1)
+        for (int c2 = 0; c2 < q1; ++c2)
+          for (int c1 = 0; c1 < q1; ++c1)
+            for (int b2 = 0; b2 < n1; ++b2)
+              for (int b1 = 0; b1 < n1; ++b1)
+                A[((size_t)(a1 + n1 * a2) * nq2 + (c1 + q1 * c2)) * nd2 + (b1 + n1 * b2)] =
+                    A1[((size_t)a1 * q1 + c1) * n1 + b1] * A1[((size_t)a2 * q1 + c2) * n1 + b2];
+    return A;
+  }
+  int nd = num_nodes(dim, P, kind), nq = num_nodes(dim, q, kind);
   std::vector<int> latP, latQ;
-  lattice_points(dim, P, latP);
-  lattice_points(dim, q, latQ);
+  lattice_points(dim, P, latP, kind);
+  lattice_points(dim, q, latQ, kind);
   std::vector<real> CP = lagrange_coeffs(dim, P, latP);
   std::vector<real> CQ = lagrange_coeffs(dim, q, latQ);
-  MassPack mp = mass_matrix(dim, P);
+  MassPack mp = mass_matrix(dim, P, kind);
   // I3[m][k][n] = int mono_m mono_k mono_n
   std::vector<real> T0((size_t)nd * nq * nd), T1((size_t)nd * nq * nd);
   int g[3];
@@ -298,7 +385,7 @@ std::vector<double> sponge_tensor(int dim, int P, int q) {
     for (int k = 0; k < nq; ++k)
       for (int n = 0; n < nd; ++n) {
         for (int i = 0; i < dim; ++i) g[i] = latP[m * dim + i] + latQ[k * dim + i] + latP[n * dim + i];
-        T0[((size_t)m * nq + k) * nd + n] = mono_integral(dim, g);
+        T0[((size_t)m * nq + k) * nd + n] = mono_integral(dim, g, kind);
       }
   // contract n -> b
   for (int m = 0; m < nd; ++m)

@@ -95,6 +95,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.mk = h->mk_dev;
   a.nbr_tab = h->nbr_tab;
   a.all_active = region == SG_REGION_ALL ? 1 : 0;
+  a.tensor = h->re.kind == KIND_TENSOR ? 1 : 0;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
   a.sym = h->sym ? 1 : 0;

@@ -141,7 +141,8 @@ class ElasticLF4(object):
     def _create_block(self):
         part = self.mesh.partition
         origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
-        block = HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin, self.mesh.diagonal,
+        block = HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin,
+                         "quadrilateral" if self.mesh.quadrilateral else self.mesh.diagonal,
                          part.nbr_mask, device=_device_for_rank(), dtype=self.dtype)
         self._torch_stream = None
         if part.world > 1:

@@ -15,7 +15,9 @@ from . import _lib
 from .expression import Expression
 
 
-def _nnodes(dim, degree):
+def _nnodes(dim, degree, kind=0):
+    if kind == 1 and dim > 1:
+        return (degree + 1) ** dim
     return {1: degree + 1, 2: (degree + 1) * (degree + 2) // 2,
             3: (degree + 1) * (degree + 2) * (degree + 3) // 6}[dim]
 
@@ -32,7 +34,7 @@ def block_config(mesh, degree=1, device=0):
             cfg.origin[a] = mesh.origin[a] + part.start[a] * mesh.h[a]
         else:
             cfg.n[a], cfg.h[a], cfg.origin[a] = 1, 1.0, 0.0
-    cfg.diagonal = 1 if mesh.diagonal == "right" else 0
+    cfg.diagonal = 2 if mesh.quadrilateral else (1 if mesh.diagonal == "right" else 0)
     cfg.nbr_mask = part.nbr_mask
     cfg.device = device
     cfg.stream = None
@@ -43,7 +45,9 @@ class FunctionSpace(object):
     value_shape = ()
 
     def __init__(self, mesh, family, degree, name=None):
-        if family not in ("DG", "Discontinuous Lagrange"):
+        if family == "DQ" and not mesh.quadrilateral:
+            raise ValueError("family 'DQ' needs a quadrilateral mesh")
+        if family not in ("DG", "Discontinuous Lagrange", "DQ"):
             raise NotImplementedError("seigen_amd implements the discontinuous-Galerkin path only "
                                       "(family='DG'); got %r" % (family,))
         if not (1 <= int(degree) <= 8):
@@ -53,7 +57,7 @@ class FunctionSpace(object):
         self.degree = int(degree)
         self.name = name
         self.dim = mesh.dim
-        self.nd = _nnodes(mesh.dim, self.degree)
+        self.nd = _nnodes(mesh.dim, self.degree, mesh.cell_kind)
         self._coords = None
 
     def ufl_element(self):
@@ -96,7 +100,7 @@ class FunctionSpace(object):
         `max_nodes` nodes at a time (a 128^3-cube P4 block has 440 M nodes = 10.6 GB of coordinates)."""
         mesh, part = self.mesh, self.mesh.partition
         d = self.dim
-        ncls = {1: 1, 2: 2, 3: 6}[d]
+        ncls = mesh.cells_per_block
         per_layer = int(np.prod(part.n[:d - 1])) * ncls if d > 1 else ncls
         layers = max(1, int(max_nodes // max(1, per_layer * self.nd)))
         lib = _lib.load()
@@ -249,6 +253,8 @@ def locate(space, point):
     X = space.node_coords()
     # lattice corners: nodes (0,..), (P,0,..), (0,P,..), (0,0,P)
     corner = {1: [0, P], 2: [0, P, space.nd - 1], 3: [0, P, (P + 1) * (P + 2) // 2 - 1, space.nd - 1]}[dim]
+    if mesh.quadrilateral:
+        corner = [0, P, P * (P + 1)]              # (0,0), (1,0), (0,1) of the unit square
     lins = []
     for cube in cands:
         lin, mul = 0, 1
@@ -262,7 +268,7 @@ def locate(space, point):
             V = X[cell, corner]                       # [dim+1, dim]
             J = (V[1:] - V[0]).T
             xi = np.linalg.solve(J, p - V[0])
-            if xi.min() >= -1e-12 and xi.sum() <= 1.0 + 1e-12:
+            if xi.min() >= -1e-12 and (xi.max() if mesh.quadrilateral else xi.sum()) <= 1.0 + 1e-12:
                 return cell, xi
     return None
 
@@ -275,7 +281,7 @@ def evaluate_at(function, point, cell_xi=None):
     if loc is None:
         return None
     cell, xi = loc
-    phi = tabulate(space.dim, space.degree, xi[None, :])[0]
+    phi = tabulate(space.dim, space.degree, xi[None, :], space.mesh.cell_kind)[0]
     if function._binding is not None:
         block, field = function._binding
         vals = block.get_field_range(field, cell, 1)[0]
@@ -314,6 +320,8 @@ def project_box_indicator(space, lo, hi):
     from .norms import simplex_rule, tabulate
     if space.dim != 2:
         raise NotImplementedError("project_box_indicator: 2-D spaces")
+    if space.mesh.quadrilateral:
+        raise NotImplementedError("project_box_indicator: triangular meshes")
     mesh, P, nd = space.mesh, space.degree, space.nd
     part = mesh.partition
     lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
@@ -360,9 +368,10 @@ def project_box_indicator(space, lo, hi):
 
 def integral(function):
     """int f dx of a DG Function, per value component (local block of this rank)."""
-    from .norms import simplex_rule, tabulate, _cell_volume_factor
+    from .norms import cell_rule, tabulate, _cell_volume_factor
     space = function.function_space()
-    xq, wq = simplex_rule(space.dim, space.degree)
-    w = wq @ tabulate(space.dim, space.degree, xq)
+    kind = space.mesh.cell_kind
+    xq, wq = cell_rule(space.dim, space.degree, kind)
+    w = wq @ tabulate(space.dim, space.degree, xq, kind)
     v = function.dat.data_cells
     return _cell_volume_factor(space.mesh) * np.tensordot(w, v.sum(axis=0), axes=(0, 0))

@@ -8,9 +8,11 @@ from seigen_amd import (ElasticLF4, Expression, Function, UnitCubeMesh, UnitSqua
 
 class Eigenmode2DLF4():
 
-    def __init__(self, N, degree, dt, solver='explicit', output=True, diagonal="left"):
+    def __init__(self, N, degree, dt, solver='explicit', output=True, diagonal="left", quadrilateral=False):
         with timed_region('mesh generation'):
-            self.mesh = UnitSquareMesh(N, N, diagonal)
+            # quadrilateral=True: the same script on UnitSquareMesh(N, N, quadrilateral=True) - create() is
+            # family-agnostic (seigen/elastic.py:27-64, :81-82); "DG" then means the tensor-product element
+            self.mesh = UnitSquareMesh(N, N, diagonal, quadrilateral=quadrilateral)
 
         self.elastic = ElasticLF4.create(self.mesh, "DG", degree, dimension=2,
                                          solver=solver, output=output)

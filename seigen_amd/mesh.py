@@ -110,13 +110,18 @@ class Partition(object):
 
 
 class Mesh(object):
-    def __init__(self, n, L, diagonal="left"):
+    def __init__(self, n, L, diagonal="left", quadrilateral=False):
         self.dim = len(n)
         self.n = tuple(int(x) for x in n)
         self.L = tuple(float(x) for x in L)
         if diagonal not in ("left", "right"):
             raise ValueError("diagonal must be 'left' or 'right'")
+        if quadrilateral and self.dim != 2:
+            raise NotImplementedError("tensor-product cells are implemented in 2-D (quadrilateral=True) only")
         self.diagonal = diagonal
+        # [upstream] RectangleMesh / UnitSquareMesh(..., quadrilateral=True): the squares are the cells and
+        # FunctionSpace(mesh, "DG", k) (seigen/elastic.py:81-82) becomes the tensor-product element DQ_k
+        self.quadrilateral = bool(quadrilateral)
         self.h = tuple(l / k for l, k in zip(self.L, self.n))
         self.origin = (0.0,) * self.dim
         self._partition = None
@@ -138,7 +143,12 @@ class Mesh(object):
 
     @property
     def cells_per_block(self):
-        return {1: 1, 2: 2, 3: 6}[self.dim]
+        return 1 if self.quadrilateral else {1: 1, 2: 2, 3: 6}[self.dim]
+
+    @property
+    def cell_kind(self):
+        """0: simplices, 1: tensor-product cells (the `cell_type` of sg_tabulate_cell, include/seigen_hip.h)."""
+        return 1 if self.quadrilateral else 0
 
     def num_cells(self):
         return int(np.prod(self.n)) * self.cells_per_block
@@ -152,12 +162,12 @@ def UnitIntervalMesh(ncells):
     return Mesh((ncells,), (1.0,))
 
 
-def RectangleMesh(nx, ny, Lx, Ly, diagonal="left"):
-    return Mesh((nx, ny), (Lx, Ly), diagonal)
+def RectangleMesh(nx, ny, Lx, Ly, diagonal="left", quadrilateral=False):
+    return Mesh((nx, ny), (Lx, Ly), diagonal, quadrilateral)
 
 
-def UnitSquareMesh(nx, ny, diagonal="left"):
-    return Mesh((nx, ny), (1.0, 1.0), diagonal)
+def UnitSquareMesh(nx, ny, diagonal="left", quadrilateral=False):
+    return Mesh((nx, ny), (1.0, 1.0), diagonal, quadrilateral)
 
 
 def BoxMesh(nx, ny, nz, Lx, Ly, Lz):

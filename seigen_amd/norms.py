@@ -38,17 +38,30 @@ def simplex_rule(dim, degree):
     return pts, np.array([x * y * z for x in wu for y in ws for z in wr])
 
 
-def tabulate(dim, degree, xi):
+def cell_rule(dim, degree, kind=0):
+    """Quadrature on the reference cell: the simplex rule, or (kind 1, tensor-product cells) the Gauss-Legendre
+    product rule exact to `degree` PER VARIABLE on the unit square."""
+    if kind == 0 or dim == 1:
+        return simplex_rule(dim, degree)
+    t, w = _gj01(max(1, degree // 2 + 1), 0.0)
+    pts = np.array([(a, b) for b in t for a in t])
+    return pts, np.array([x * y for y in w for x in w])
+
+
+def tabulate(dim, degree, xi, kind=0):
     xi = np.ascontiguousarray(xi, dtype=np.float64).reshape(-1, dim)
     nd = {1: degree + 1, 2: (degree + 1) * (degree + 2) // 2,
           3: (degree + 1) * (degree + 2) * (degree + 3) // 6}[dim]
+    if kind == 1 and dim > 1:
+        nd = (degree + 1) ** dim
     phi = np.empty((xi.shape[0], nd))
-    _lib.check(_lib.load().sg_tabulate(dim, degree, xi.shape[0], xi.ctypes.data, phi.ctypes.data))
+    _lib.check(_lib.load().sg_tabulate_cell(kind, dim, degree, xi.shape[0], xi.ctypes.data, phi.ctypes.data))
     return phi
 
 
 def _cell_volume_factor(mesh):
-    """|det J| of every cell class (all equal on a structured simplicial mesh)."""
+    """|det J| of every cell class (all equal on a structured mesh; the rules' weights sum to the measure of
+    the reference cell)."""
     return float(np.prod(mesh.h))
 
 
@@ -66,9 +79,9 @@ def _global_sqrt(local_sq):
 def norm(f):
     """L2 norm of a DG Function: sqrt(assemble(inner(f, f)*dx)) [upstream]."""
     space = f.function_space()
-    dim, P = space.dim, space.degree
-    xq, wq = simplex_rule(dim, 2 * P)
-    phi = tabulate(dim, P, xq)
+    dim, P, kind = space.dim, space.degree, space.mesh.cell_kind
+    xq, wq = cell_rule(dim, 2 * P, kind)
+    phi = tabulate(dim, P, xq, kind)
     M = np.einsum('q,qa,qb->ab', wq, phi, phi)
     v = f.dat.data_cells.reshape(space.ncells, space.nd, -1)
     return _global_sqrt(_cell_volume_factor(space.mesh) * np.einsum('cak,ab,cbk->', v, M, v))
@@ -79,13 +92,13 @@ def projected_abs_error_norm(f, exact, proj_degree):
     (eigenmode_2d.py:49-55: proj_degree 6; eigenmode_3d.py:53-59: 3).
     [upstream] quadrature degree = proj_degree + degree (UFL: abs keeps the degree)."""
     space = f.function_space()
-    dim, P = space.dim, space.degree
+    dim, P, kind = space.dim, space.degree, space.mesh.cell_kind
     e = (f.dat.data_cells - exact.dat.data_cells).reshape(space.ncells, space.nd, -1)
-    xq, wq = simplex_rule(dim, proj_degree + P)
-    phi = tabulate(dim, P, xq)
-    psi = tabulate(dim, proj_degree, xq)
-    xm, wm = simplex_rule(dim, 2 * proj_degree)
-    pm = tabulate(dim, proj_degree, xm)
+    xq, wq = cell_rule(dim, proj_degree + P, kind)
+    phi = tabulate(dim, P, xq, kind)
+    psi = tabulate(dim, proj_degree, xq, kind)
+    xm, wm = cell_rule(dim, 2 * proj_degree, kind)
+    pm = tabulate(dim, proj_degree, xm, kind)
     Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))
     eq = np.abs(np.einsum('qa,cak->cqk', phi, e))
     b = np.einsum('q,qa,cqk->cak', wq, psi, eq)

@@ -15,9 +15,12 @@ import numpy as np
 _VTK_CELL = {1: 3, 2: 5, 3: 10}   # VTK_LINE, VTK_TRIANGLE, VTK_TETRA
 
 
-def vertex_nodes(dim, degree):
-    """Indices of the cell's vertices among its lattice nodes (first reference coordinate fastest)."""
+def vertex_nodes(dim, degree, quadrilateral=False):
+    """Indices of the cell's vertices among its lattice nodes (first reference coordinate fastest); for a
+    quadrilateral in VTK_QUAD order (counter-clockwise)."""
     k = int(degree)
+    if quadrilateral:
+        return [0, k, (k + 1) * (k + 1) - 1, k * (k + 1)]
     if dim == 1:
         return [0, k]
     if dim == 2:
@@ -48,7 +51,7 @@ def write_vtu(path, points, point_data):
         f.write('\n</DataArray>\n<DataArray type="Int64" Name="offsets" format="ascii">\n')
         f.write(" ".join("%d" % ((c + 1) * nv) for c in range(ncells)))
         f.write('\n</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n')
-        f.write(" ".join([str(_VTK_CELL[dim])] * ncells))
+        f.write(" ".join([str(9 if (dim == 2 and nv == 4) else _VTK_CELL[dim])] * ncells))   # 9: VTK_QUAD
         f.write('\n</DataArray>\n</Cells>\n<PointData>\n')
         for name, arr in point_data.items():
             a = np.asarray(arr, dtype=np.float64)
@@ -92,7 +95,7 @@ class VtuStream(object):
     def write(self, function, time=None):
         space = function.function_space()
         dim, degree = space.mesh.dim, space.degree
-        vn = vertex_nodes(dim, degree)
+        vn = vertex_nodes(dim, degree, space.mesh.quadrilateral)
         X = space.node_coords()[:, vn, :]
         vals = function.dat.data_cells[:, vn]
         suffix = "_r%d" % self.rank if self.world > 1 else ""

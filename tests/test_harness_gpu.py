@@ -208,7 +208,7 @@ class _LocalExchange(object):
                 b.end_step()
 
 
-def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64", separable=False):
+def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64", separable=False, diagonal="left"):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -217,7 +217,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64",
     from seigen_amd.mesh import Partition
     L = tuple(1.0 for _ in range(dim))
     h = [L[a] / n[a] for a in range(dim)]
-    single = HipBlock(dim, degree, n, h, [0.0] * dim, dtype=dtype)
+    single = HipBlock(dim, degree, n, h, [0.0] * dim, diagonal, dtype=dtype)
     u0 = seeded(single.field_shape(_lib.FIELD_U), 11)
     s0 = seeded(single.field_shape(_lib.FIELD_S), 12)
     dt = 0.02 * min(h) / degree ** 2
@@ -227,7 +227,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64",
     nd = single.nd
     if extras:      # a sponge and a time-dependent source scattered over the mesh (shell cells included)
         r3 = np.random.default_rng(77)
-        nq = {1: 5, 2: 15, 3: 35}[dim]
+        nq = 25 if diagonal == "quadrilateral" else {1: 5, 2: 15, 3: 35}[dim]
         sigma = np.where(r3.uniform(size=(single.ncells, nq)) > 0.6, 3.0, 0.0)
         src_nodes = np.unique(r3.integers(0, single.ncells * nd, size=min(40, single.ncells * nd)))
         sv = r3.uniform(-1, 1, size=(3, len(src_nodes), dim, dim))
@@ -243,7 +243,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64",
 
     world = int(np.prod(grid))
     parts = [Partition(n, r, world, grid) for r in range(world)]
-    ncls = {1: 1, 2: 2, 3: 6}[dim]
+    ncls = 1 if diagonal == "quadrilateral" else {1: 1, 2: 2, 3: 6}[dim]
 
     def cells_of(p):
         """global cell indices of a block, in the block's own cell order"""
@@ -259,7 +259,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64",
     blocks = []
     for p in parts:
         origin = [p.start[a] * h[a] for a in range(dim)]
-        b = HipBlock(dim, degree, p.n, h, origin, "left", p.nbr_mask, dtype=dtype)
+        b = HipBlock(dim, degree, p.n, h, origin, diagonal, p.nbr_mask, dtype=dtype)
         sel = cells_of(p)
         b.set_params(1.0, dt, 0.5, 0.25)
         b.set_field(_lib.FIELD_U, u0[sel])

@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-11
 
+
+def tol_of(degree, diagonal):
+    """1e-11, except DQ_4 (5e-11): the oracle inverts each cell's 25 x 25 mass matrix of the equispaced tensor basis
+    in double precision; the library builds the element from long-double interval operators."""
+    return 5 * TOL if (diagonal == "quadrilateral" and degree == 4) else TOL
+
 CASES = [
     # dim, degree, n, L, diagonal
     (1, 1, (7,), (2.0,), "left"),
@@ -32,6 +38,11 @@ CASES = [
     # tall ragged blocks: the chunked XCD order of the F stages (from 16 layers up), groups straddling rows and layers
     (3, 3, (5, 3, 17), (1.0, 0.6, 3.4), "left"),
     (3, 4, (3, 2, 19), (0.6, 0.4, 3.8), "left"),
+    # quadrilateral cells, tensor-product element DQ_k (sg_config::diagonal = 2)
+    (2, 1, (4, 3), (1.0, 1.5), "quadrilateral"),
+    (2, 2, (5, 4), (2.0, 1.0), "quadrilateral"),
+    (2, 3, (3, 3), (1.0, 1.0), "quadrilateral"),
+    (2, 4, (4, 5), (1.0, 1.0), "quadrilateral"),
 ]
 
 
@@ -64,11 +75,11 @@ def test_apply_F_and_G(gpu, dim, degree, n, L, diagonal):
     blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
     got = blk.get_field(_lib.FIELD_UH)
     exp = E.apply_F(T, u)
-    assert rel_err(got, exp) < TOL
+    assert rel_err(got, exp) < tol_of(degree, diagonal)
     blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
     got = blk.get_field(_lib.FIELD_SH)
     exp = E.apply_G(u, lam, mu)
-    assert rel_err(got, exp) < TOL
+    assert rel_err(got, exp) < tol_of(degree, diagonal)
 
 
 @pytest.mark.parametrize("dim,degree,n,L,diagonal", CASES)
@@ -89,11 +100,12 @@ def test_full_steps(gpu, dim, degree, n, L, diagonal):
     blk.step(3)
     for k in range(3):
         orc.step((k + 1) * orc.dt)
-    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 10 * TOL
-    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
+    tol = 10 * tol_of(degree, diagonal)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < tol
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < tol
     # intermediate fields left behind by the last step
-    assert rel_err(blk.get_field(_lib.FIELD_UH), orc.last["utemp"]) < 10 * TOL
-    assert rel_err(blk.get_field(_lib.FIELD_SH), orc.last["sh1"]) < 10 * TOL
+    assert rel_err(blk.get_field(_lib.FIELD_UH), orc.last["utemp"]) < tol
+    assert rel_err(blk.get_field(_lib.FIELD_SH), orc.last["sh1"]) < tol
 
 
 def test_density_quirk(gpu):

@@ -1,0 +1,130 @@
+"""Quadrilateral meshes (tensor-product element DQ_k) on the HIP path - SURVEY 8(f) rank 4.
+
+``ElasticLF4.create(mesh, family, degree, dimension)`` (seigen/elastic.py:27-64) is family-agnostic and builds its
+spaces with ``FunctionSpace(mesh, family, degree)`` (:81-82); on ``UnitSquareMesh(N, N, quadrilateral=True)`` that is
+[upstream] the tensor product of two interval DG elements.  The reference's tests never use such a mesh, so there is
+nothing reference-held to pin: parity is against the oracle's quadrature assembly of the same forms on the same
+cells (oracle/refelem.py el_*, oracle/mesh.py kind "tensor"), plus convergence to the analytic eigenmode.
+Stage-level parity and whole steps on quadrilaterals are in tests/test_parity_gpu.py (CASES, "quadrilateral")."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import mesh as omesh
+from oracle.forms import ElasticOperators
+from oracle.harness import Eigenmode2D
+from oracle.lf4 import OracleLF4
+from tests.util import rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _quiet():
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    import seigen_amd.harness.eigenmode as he
+    helpers.log = lambda s: None
+    seigen_amd.elastic.log = lambda s: None
+    he.log = lambda s: None
+
+
+@pytest.mark.parametrize("P,N", [(1, 8), (2, 8), (3, 4), (4, 4)])
+def test_eigenmode_on_quadrilaterals_matches_oracle(gpu, P, N):
+    """tests/eigenmode/eigenmode_2d.py on UnitSquareMesh(N, N, quadrilateral=True): the error functional of
+    :49-63 through the harness equals the oracle's to 1e-9 (north star: 1e-6)."""
+    _quiet()
+    from seigen_amd.harness.eigenmode import Eigenmode2DLF4
+    dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
+    em = Eigenmode2DLF4(N, P, dt, solver="explicit", output=False, quadrilateral=True)
+    assert em.elastic.U.nd == (P + 1) ** 2 and em.elastic.U.ncells == N * N
+    u1, s1 = em.eigenmode2d(T=5.0)
+    u_error, s_error = em.eigenmode_error(u1, s1)
+    oe = Eigenmode2D(N, P, dt, quadrilateral=True)
+    ou, os_ = oe.run(5.0)
+    e = oe.errors(ou, os_)
+    assert abs(u_error - e["u_error"]) < 1e-9 and abs(s_error - e["s_error"]) < 1e-9, (u_error, s_error, e)
+    # the fields themselves after 80-320 steps: different summation order only (1e-9 at P4, whose equispaced 25-node
+    # basis is the worst conditioned)
+    assert rel_err(u1.dat.data_cells, ou) < 1e-8 and rel_err(s1.dat.data_cells, os_) < 1e-8
+
+
+def test_eigenmode_converges_on_quadrilaterals(gpu):
+    _quiet()
+    from seigen_amd.harness.eigenmode import Eigenmode2DLF4
+    for P, floor in ((1, 1.0), (2, 2.5), (3, 2.7)):
+        errs = []
+        for N in (8, 16):
+            dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
+            em = Eigenmode2DLF4(N, P, dt, solver="explicit", output=False, quadrilateral=True)
+            u1, s1 = em.eigenmode2d(T=5.0)
+            errs.append(em.eigenmode_error(u1, s1))
+        ou = math.log2(errs[0][0] / errs[1][0])
+        os_ = math.log2(errs[0][1] / errs[1][1])
+        assert ou > floor and os_ > floor, (P, ou, os_)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_sponge_source_and_material_on_quadrilaterals(gpu, P):
+    """The extras of the explosive-source set-up on quadrilateral cells: DG4 sponge (elastic.py:207-208), a nodal
+    source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    n, L = (6, 5), (3.0, 2.5)
+    h = [L[a] / n[a] for a in range(2)]
+    blk = HipBlock(2, P, n, h, [0.0, 0.0], "quadrilateral")
+    m = omesh.structured(2, n, L, quadrilateral=True)
+    orc = OracleLF4(m, P)
+    nc = m.ncells
+    rng = np.random.default_rng(3)
+    lam, mu = rng.uniform(0.4, 0.8, nc), rng.uniform(0.2, 0.4, nc)
+    orc.dt, orc.l, orc.mu, orc.density = 0.02 * min(h) / P ** 2, lam, mu, 1.0
+    X4 = m.node_coords(4)
+    sigma = np.where(X4[..., 0] < 1.0, 30.0 * (1.0 - X4[..., 0]), 0.0)          # DG4 nodal values [nc, 25]
+    orc.E.set_absorption(sigma, 4)
+    nsteps = 12
+    nodes = np.array([2 * (P + 1) ** 2 + 1, 14 * (P + 1) ** 2 + 3, 14 * (P + 1) ** 2 + 4])
+    vals = rng.uniform(-1, 1, (nsteps, len(nodes), 2, 2))
+    vals = 0.5 * (vals + np.swapaxes(vals, -1, -2))
+
+    def source(k):
+        S = np.zeros((nc * (P + 1) ** 2, 2, 2))
+        S[nodes] = vals[k]
+        return S.reshape(nc, (P + 1) ** 2, 2, 2)
+
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 6)
+    s0 = seeded(blk.field_shape(_lib.FIELD_S), 7)
+    orc.s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+    blk.set_params(1.0, orc.dt, lam, mu)
+    blk.set_absorption(sigma, 4)
+    blk.set_source(nodes, vals)
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(nsteps)
+    for k in range(nsteps):
+        orc.source = lambda t, k=k: source(k)
+        orc.step((k + 1) * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 1e-10
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
+
+
+def test_quadrilateral_blocks_equal_the_single_block(gpu):
+    """2 x 2 blocks of quadrilateral cells exchanging packed traces = the single block, bit for bit (the halo
+    layer of elastic.py:404-436 is direction- and cell-type-agnostic)."""
+    from tests.test_harness_gpu import _multiblock_case
+    for pipelined in (True, False):
+        _multiblock_case(2, 3, (8, 6), (2, 2), pipelined, extras=True, diagonal="quadrilateral")
+    _multiblock_case(2, 2, (7, 5), (3, 1), True, diagonal="quadrilateral")
+
+
+def test_function_evaluation_and_integral_on_quadrilaterals(gpu):
+    from seigen_amd import Function, UnitSquareMesh, VectorFunctionSpace
+    from seigen_amd.expression import Expression
+    from seigen_amd.functionspace import evaluate_at, integral
+    mesh = UnitSquareMesh(4, 3, quadrilateral=True)
+    U = VectorFunctionSpace(mesh, "DG", 3)
+    f = Function(U).interpolate(Expression(("x[0]*x[0]*x[1]", "1 + x[0] - 2*x[1]*x[1]*x[1]")))
+    for p in ((0.3, 0.7), (0.99, 0.01), (0.5, 1.0 / 3.0), (1.0, 1.0)):
+        v = evaluate_at(f, p)
+        np.testing.assert_allclose(v, [p[0] ** 2 * p[1], 1 + p[0] - 2 * p[1] ** 3], atol=1e-13)
+    np.testing.assert_allclose(integral(f), [1.0 / 6.0, 1.0], atol=1e-13)

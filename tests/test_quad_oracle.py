@@ -1,0 +1,118 @@
+"""Quadrilateral cells / tensor-product element DQ_k without a GPU: the oracle's restatement on quadrilaterals
+(oracle/refelem.py el_*, oracle/mesh.py kind "tensor") and the library's device-free tables for that cell type
+(sg_reference_operator_cell, sg_tabulate_cell, sg_mesh_tables / sg_block_node_coords with diagonal = 2) against
+each other.  The reference holds no vectors for such meshes (its tests use triangles and tetrahedra only)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import mesh as omesh, refelem
+from oracle.forms import ElasticOperators
+from oracle.harness import Eigenmode2D
+
+
+def _ops(P):
+    """D_r = Mhat^-1 Shat_r and L_f of the unit square by Gauss quadrature (the definitions of csrc/refelem.hpp)."""
+    xq, wq = refelem.el_quadrature(2, 2 * P, "tensor")
+    phi, dphi = refelem.el_tabulate(2, P, xq, "tensor")
+    M = np.einsum('q,qa,qb->ab', wq, phi, phi)
+    Minv = np.linalg.inv(M)
+    D = np.stack([Minv @ np.einsum('q,qa,qb->ab', wq, dphi[:, :, r], phi) for r in range(2)])
+    t, w = refelem.el_quadrature(1, 2 * P, "tensor")
+    L, fn = [], []
+    for f in range(4):
+        axis, at = f // 2, float(f % 2)
+        pts = np.zeros((len(t), 2))
+        pts[:, axis] = at
+        pts[:, 1 - axis] = t[:, 0]
+        ph, _ = refelem.el_tabulate(2, P, pts, "tensor")
+        nodes = refelem.el_face_nodes(2, P, f, "tensor")
+        L.append(Minv @ np.einsum('q,qa,qb->ab', w, ph, ph[:, nodes]))
+        fn.append(nodes)
+    return M, D, np.stack(L), np.stack(fn)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_library_tables_of_the_tensor_product_element(P):
+    from seigen_amd import _lib
+    lib = _lib.load()
+    nd, nf = (P + 1) ** 2, P + 1
+    M, D, L, fn = _ops(P)
+
+    def op(which, shape):
+        out = np.empty(shape)
+        n = lib.sg_reference_operator_cell(1, 2, P, which, 0, out.ctypes.data, out.nbytes)
+        assert n == out.size, n
+        return out
+    scale = lambda a: np.abs(a).max()
+    assert np.abs(op(2, (nd, nd)) - M).max() < 1e-14 * scale(M)
+    assert np.abs(op(0, (2, nd, nd)) - D).max() < 1e-9 * scale(D)        # the check inverts M in double precision
+    assert np.abs(op(1, (4, nd, nf)) - L).max() < 1e-9 * scale(L)
+    assert np.array_equal(op(4, (4, nf)).astype(int), fn)
+    xi = np.random.default_rng(P).uniform(0, 1, (17, 2))
+    phi = np.empty((17, nd))
+    assert lib.sg_tabulate_cell(1, 2, P, 17, xi.ctypes.data, phi.ctypes.data) == 0
+    np.testing.assert_allclose(phi, refelem.el_tabulate(2, P, xi, "tensor")[0], atol=1e-12)
+    # a simplex call with the tensor entry points, and an unsupported cell type
+    assert lib.sg_tabulate_cell(0, 2, P, 17, xi.ctypes.data, np.empty((17, (P + 1) * (P + 2) // 2)).ctypes.data) == 0
+    assert lib.sg_tabulate_cell(2, 2, P, 17, xi.ctypes.data, phi.ctypes.data) < 0
+    assert lib.sg_reference_operator_cell(1, 3, P, 0, 0, None, 0) < 0     # hexahedra are not built
+
+
+def test_node_coordinates_and_neighbour_tables_of_a_quadrilateral_block():
+    from seigen_amd import _lib
+    lib = _lib.load()
+    P, n, L = 3, (4, 3), (2.0, 1.5)
+    cfg = _lib.SgConfig()
+    cfg.dim, cfg.degree, cfg.diagonal = 2, P, 2
+    for a in range(3):
+        cfg.n[a] = n[a] if a < 2 else 1
+        cfg.h[a] = L[a] / n[a] if a < 2 else 1.0
+        cfg.origin[a] = (0.5, -1.0, 0.0)[a]
+    X = np.empty((n[0] * n[1], (P + 1) ** 2, 2))
+    assert lib.sg_block_node_coords(C.byref(cfg), P, X.ctypes.data, X.nbytes) == 0
+    m = omesh.structured(2, n, L, origin=(0.5, -1.0), quadrilateral=True)
+    np.testing.assert_allclose(X, m.node_coords(P), atol=1e-13)
+    # facets: the oracle finds them from vertex ids, the library from the structure
+    h = np.array([L[0] / n[0], L[1] / n[1], 1.0])
+    nb = np.zeros((1, 4, 5), dtype=np.int32)
+    nbn = np.zeros((1, 4, P + 1), dtype=np.int32)
+    cn = np.zeros((1, 4, 3))
+    jinv = np.zeros((1, 3, 3))
+    assert lib.sg_mesh_tables(2, P, 2, h.ctypes.data, nb.ctypes.data, nbn.ctypes.data, cn.ctypes.data, jinv.ctypes.data) == 0
+    assert m.nfaces == 4 and len(m.interior_facets) == (n[0] - 1) * n[1] + n[0] * (n[1] - 1)
+    for (c1, f1, c2, f2) in m.interior_facets:
+        for (c, f, co, fo) in ((c1, f1, c2, f2), (c2, f2, c1, f1)):
+            axis, d, _, face, _ = nb[0, f]
+            assert co == c + d * (1 if axis == 0 else n[0]) and face == fo
+            nrm, area = m.facet_geometry(np.array([c]), np.array([f]))
+            np.testing.assert_allclose(cn[0, f, :2], nrm[0] * area[0] / abs(m.detJ[c]), atol=1e-14)
+            # matching nodes sit at the same place
+            mine = refelem.el_face_nodes(2, P, f, "tensor")
+            np.testing.assert_allclose(m.node_coords(P)[c, mine], m.node_coords(P)[co, nbn[0, f]], atol=1e-13)
+
+
+def test_oracle_on_quadrilaterals_reproduces_polynomials_and_converges():
+    m = omesh.structured(2, (3, 4), (1.5, 1.0), quadrilateral=True)
+    for P in (1, 2, 3):
+        E = ElasticOperators(m, P)
+        X = m.node_coords(P)
+        x, y = X[..., 0], X[..., 1]
+        # a field in Q_P: continuous, so F is the strong divergence in the interior ... traction-free boundary aside
+        u = np.stack([x ** P * y + 1.0, x - 2.0 * y ** P], axis=-1)
+        W = E.apply_G(u, 0.0, 0.5)            # mu (grad u + grad u^T), exterior facets use the own trace: exact
+        du = np.zeros(X.shape[:2] + (2, 2))
+        du[..., 0, 0] = P * x ** (P - 1) * y
+        du[..., 0, 1] = x ** P
+        du[..., 1, 0] = 1.0
+        du[..., 1, 1] = -2.0 * P * y ** (P - 1)
+        np.testing.assert_allclose(W, 0.5 * (du + np.swapaxes(du, -1, -2)), atol=1e-10)
+    errs = []
+    for N in (4, 8):
+        em = Eigenmode2D(N, 2, 0.5 * (1.0 / N) / 2.0, quadrilateral=True)
+        u1, s1 = em.run(5.0)
+        e = em.errors(u1, s1)
+        errs.append((e["u_error"], e["s_error"]))
+    assert math.log2(errs[0][0] / errs[1][0]) > 2.5 and math.log2(errs[0][1] / errs[1][1]) > 2.5

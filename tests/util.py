@@ -6,6 +6,8 @@ from oracle.lf4 import OracleLF4
 
 
 def oracle_mesh(dim, n, L, diagonal="left"):
+    if diagonal == "quadrilateral":       # the squares are the cells (tensor-product element)
+        return omesh.structured(dim, n, L, quadrilateral=True)
     return omesh.structured(dim, n, L, diagonal)
 
 
