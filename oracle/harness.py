@@ -206,10 +206,10 @@ class ExplosiveSource(object):
     every mesh).  The last two are build-defined, for the REF-C convergence study."""
 
     def __init__(self, Lx=300.0, Ly=150.0, h=2.5, degree=2, diagonal="left",
-                 src=(45.0, None), sponge=20.0, sigma_degree=4, source_mode="interpolate"):
+                 src=(45.0, None), sponge=20.0, sigma_degree=4, source_mode="interpolate", quadrilateral=False):
         nx, ny = int(Lx / h), int(Ly / h)
         self.Lx, self.Ly, self.h = Lx, Ly, h
-        self.mesh = omesh.RectangleMesh(nx, ny, Lx, Ly, diagonal)         # :9-10
+        self.mesh = omesh.RectangleMesh(nx, ny, Lx, Ly, diagonal, quadrilateral=quadrilateral)   # :9-10
         el = self.elastic = OracleLF4(self.mesh, degree)
         el.density = 1.0                                                  # :21-23
         el.mu = 3600.0
@@ -250,10 +250,10 @@ class ExplosiveSource(object):
         m = self.mesh
         P = self.elastic.degree
         xi = np.einsum('cmi,ci->cm', m.Jinv, np.array([x, y])[None, :] - m.v0)
-        lam0 = 1.0 - xi.sum(axis=1)
+        lam0 = (1.0 - xi.max(axis=1)) if m.kind == "tensor" else (1.0 - xi.sum(axis=1))
         inside = (xi.min(axis=1) >= -1e-12) & (lam0 >= -1e-12)
         c = int(np.nonzero(inside)[0][0])
-        phi, _ = refelem.tabulate(2, P, xi[c][None, :])
+        phi, _ = refelem.el_tabulate(2, P, xi[c][None, :], m.kind)
         return c, phi[0]
 
     def run(self, T=2.5, receivers=((45.0, 149.0), (90.0, 149.0), (140.0, 149.0))):

@@ -108,6 +108,31 @@ def test_sponge_source_and_material_on_quadrilaterals(gpu, P):
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
 
 
+def test_explosive_source_harness_on_quadrilaterals(gpu):
+    """tests/explosive_source/explosive_source_lf4.py on RectangleMesh(..., quadrilateral=True), a 100 m x 50 m cut
+    at h = 2.5, P2: box-Ricker source (:36-40), DG4 sponge (:43-45), receivers as uy.py:36-43 - traces and final
+    fields against the oracle's run of the same set-up."""
+    _quiet()
+    from oracle.harness import ExplosiveSource
+    from seigen_amd.harness.explosive_source import ExplosiveSourceLF4
+    import seigen_amd.harness.explosive_source as hx
+    hx.log = lambda s: None
+    Lx, Ly, h, dt, nsteps = 100.0, 50.0, 2.5, 0.001, 60
+    recv = ((45.0, 49.0), (60.0, 49.0), (52.3, 41.7))
+    es = ExplosiveSourceLF4()
+    es.setup(Lx, Ly, h, degree=2, dt=dt, quadrilateral=True)
+    t, tr = es.record_receivers(nsteps * dt * (1 + 1e-9), receivers=recv, every=5)
+    orc = ExplosiveSource(Lx, Ly, h, 2, quadrilateral=True)
+    orc.elastic.dt = dt
+    ot, otr = orc.run(nsteps * dt * (1 + 1e-9), receivers=recv)
+    assert len(ot) == nsteps and len(t) == nsteps // 5
+    np.testing.assert_allclose(t, ot[4::5], rtol=0, atol=1e-12)
+    scale = np.abs(otr).max()
+    assert scale > 0 and np.abs(tr - otr[4::5]).max() < 1e-9 * scale
+    assert rel_err(es.elastic.u1.dat.data_cells, orc.elastic.u1) < 1e-9
+    assert rel_err(es.elastic.s1.dat.data_cells, orc.elastic.s1) < 1e-9
+
+
 def test_quadrilateral_blocks_equal_the_single_block(gpu):
     """2 x 2 blocks of quadrilateral cells exchanging packed traces = the single block, bit for bit (the halo
     layer of elastic.py:404-436 is direction- and cell-type-agnostic)."""

@@ -64,14 +64,21 @@ def timed(elastic, steps, warmup):
                 value=dofs * steps / (dev_ms * 1e-3) / 1e6, finite=bool(np.isfinite(u).all()))
 
 
-def config2(steps, warmup, n=512):
+def config2(steps, warmup, n=512, quadrilateral=False):
     h = 2.5
     ex = ExplosiveSourceLF4()
     # Courant number 0.05 (default of the reference's tiling harness, tests/tiling/utils.py:51-52):
     # the 0.5 of explosive_source_lf4.py:31 is unstable with the explicit sponge
-    el = ex.setup(Lx=n * h, Ly=n * h, h=h, degree=2, courant_number=0.05)
+    el = ex.setup(Lx=n * h, Ly=n * h, h=h, degree=2, courant_number=0.05, quadrilateral=quadrilateral)
     r = timed(el, steps, warmup)
     r["config"] = "c2: 2D explosive source %dx%d squares, P2, sponge+source" % (n, n)
+    return r
+
+
+def config2_quad(steps, warmup):
+    """config 2's set-up on quadrilateral cells (DQ_2, nine nodes per square): the table-driven generic kernels"""
+    r = config2(steps, warmup, quadrilateral=True)
+    r["config"] = r["config"].replace("c2:", "c2q (quadrilaterals, generic kernels):")
     return r
 
 
@@ -140,7 +147,8 @@ if __name__ == "__main__":
     args = ap.parse_args()
     STAGES = args.stages
     for c in args.configs:
-        r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share}[c](args.steps, args.warmup)
+        r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share,
+             "c2q": config2_quad}[c](args.steps, args.warmup)
         r["algorithmic_GBps"] = r["value"] * 1e6 * 64 / 1e9
         r["hbm_frac"] = r["algorithmic_GBps"] / 8000.0
         print(json.dumps(r))
