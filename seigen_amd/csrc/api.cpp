@@ -9,8 +9,14 @@ std::string g_create_err;
 // MFMA and tile kernels, 64 for the lane kernels, 1 = host layout for the generic kernel).
 KernelPath choose_kernel_path(const sg_config& cfg) {
   KernelPath kp;
-  if (cfg.diagonal == SG_DIAGONAL_QUAD) {   // quadrilateral cells: the table-driven generic kernels (host layout)
-    kp.gw = 1;
+  if (cfg.diagonal == SG_DIAGONAL_QUAD) {
+    // quadrilateral cells: the MFMA tile kernels for DQ_1..3 (at most one 16-row tile), else the table-driven
+    // generic kernels (host layout); same size threshold and SEIGEN_HIP_PATH overrides as for triangles
+    const char* pe = std::getenv("SEIGEN_HIP_PATH");
+    const bool fg = pe && std::strcmp(pe, "generic") == 0, ft = pe && std::strcmp(pe, "tile") == 0;
+    kp.tile = cfg.dim == 2 && tile2d_supported_quad(cfg.degree) && !fg &&
+              (ft || (int64_t)cfg.n[0] * cfg.n[1] >= SG_TILE2D_MIN_CELLS / 2);
+    kp.gw = kp.tile ? 16 : 1;
     return kp;
   }
   const int ncls = cfg.dim == 1 ? 1 : (cfg.dim == 2 ? 2 : 6);
@@ -608,13 +614,13 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
     // tile kernels: item (16 squares of one class) -> slot, and per slot a dense (node, cell) -> value-row table, so
     // that the G stages add the source themselves (one launch less per G stage).  A node listed twice keeps the
     // separate launch (which adds both entries).
-    const int64_t nd = h->re.nd, nitems = h->md.ncube_pad / 16 * 2;
+    const int64_t nd = h->re.nd, ncl = h->ncls, nitems = h->md.ncube_pad / 16 * ncl;
     std::vector<int32_t> slot((size_t)nitems, -1), idx;
     bool dup = false;
     for (int64_t j = 0; j < nnz && !dup; ++j) {
       const int64_t node = nodes[order[(size_t)j]];
-      const int64_t e = node / nd, b = node % nd, cube = e / 2, cls = e % 2;
-      const int64_t item = (cube / 16) * 2 + cls;
+      const int64_t e = node / nd, b = node % nd, cube = e / ncl, cls = e % ncl;
+      const int64_t item = (cube / 16) * ncl + cls;
       if (slot[(size_t)item] < 0) {
         slot[(size_t)item] = (int32_t)(idx.size() / (size_t)(nd * 16));
         idx.resize(idx.size() + (size_t)(nd * 16), -1);

@@ -123,12 +123,13 @@ int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems,
 // T2Const is the part of MeshDev these kernels use, passed by value in the kernarg segment so that no load
 // depends on another one (kernels_tile2d.hip): sizes, class constants, neighbour rules, and the node
 // permutations packed four byte entries to a word (entry q of word [ks] = row 4 ks + q).
+// (facet arrays hold four entries: quadrilateral cells have four facets, triangles use the first three)
 struct T2Class {            // everything that depends on the triangle class, contiguous: one batch of scalar loads
-  double Jinv[2][2], cn[3][2];
-  int32_t nb_axis[3], nb_dir[3], nb_cls[3];
-  int32_t slot_ord[3];      // ordinal of the matching facet among the neighbour cube's facets on that side
-  uint32_t tfw[3][2];       // neighbour ELEMENT node matching my facet node (MeshDev::nb_node)
-  uint32_t tgw[3][2];       // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
+  double Jinv[2][2], cn[4][2];
+  int32_t nb_axis[4], nb_dir[4], nb_cls[4];
+  int32_t slot_ord[4];      // ordinal of the matching facet among the neighbour cube's facets on that side
+  uint32_t tfw[4][2];       // neighbour ELEMENT node matching my facet node (MeshDev::nb_node)
+  uint32_t tgw[4][2];       // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
 };
 struct T2Const {
   int32_t n0, n1, ncube, ngroups;
@@ -136,11 +137,12 @@ struct T2Const {
   int32_t halo_per_cube;
   int32_t gpr;              // groups of 16 squares that cover at least one row of the block (+1: a group may straddle rows)
   double inv_n0;            // 1 / n0
-  uint32_t tpw[3][2];       // my element node of facet node (MeshDev::fnode)
+  uint32_t tpw[4][2];       // my element node of facet node (MeshDev::fnode)
   T2Class cls[2];
 };
 T2Const tile2d_const(const MeshDev& md_host);
 bool tile2d_supported(int dim, int P);
+bool tile2d_supported_quad(int P);   // quadrilateral cells (StageArgs::tensor): DQ_1..3
 int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, long nitems, void* stream);
 
 // host layout [cell][node][comp] <-> device layout (MeshDev::gw) for `ncells` cells from `cell0`

@@ -28,22 +28,28 @@
 // half of the own trace in G).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "kernels.hpp"
 #include "mfma_tables.hpp"   // SG_T2_LARGE_FROM
 
 namespace sg {
 
-template <int P>
-struct TG : ElemDims<2, P> {
-  using ElemDims<2, P>::ND;
-  using ElemDims<2, P>::NF;
+// TP = 1: quadrilateral cells, tensor-product element DQ_P (one class per square, four facets; P <= 3: at most
+// one 16-row tile)
+template <int P, int TP = 0>
+struct TG : ElemDims<2, P, TP> {
+  using ElemDims<2, P, TP>::ND;
+  using ElemDims<2, P, TP>::NF;
+  using ElemDims<2, P, TP>::NFACES;
+  using ElemDims<2, P, TP>::NCLS;
   static constexpr int KS = (ND + 3) / 4;    // k-steps over the element nodes
   static constexpr int KSF = (NF + 3) / 4;   // k-steps over the facet nodes
   static constexpr int S4 = (ND + 3) / 4;    // row-quads of the result
   static constexpr bool LARGE = ND > SG_T2_LARGE_FROM;     // one 16-row tile (P3, P4) or S4 4-row tiles (P1, P2)
   static constexpr int RT = LARGE ? 1 : S4;  // A fragments per (operator, k-step)
   static constexpr int NFRAG_V = 2 * KS * RT;
-  static constexpr int NFRAG_L = 3 * KSF * RT;
+  static constexpr int NFRAG_L = NFACES * KSF * RT;
 };
 
 typedef double t2d4 __attribute__((ext_vector_type(4)));
@@ -72,10 +78,11 @@ __device__ __forceinline__ void t2_st(double* ubase, unsigned boff, double v) {
 // row q of a packed table word (four byte entries: the rows 4 ks + q, q = 0..3, of one k-step)
 __device__ __forceinline__ int t2_row(uint32_t word, int q) { return (int)((word >> (8 * q)) & 0xffu); }
 
-template <int P, int KIND, int MODE, int SYM, int GHOST>
+template <int P, int KIND, int MODE, int SYM, int GHOST, int TP = 0>
 __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2Const C) {
-  using G = TG<P>;
+  using G = TG<P, TP>;
   constexpr int ND = G::ND, NF = G::NF, KS = G::KS, KSF = G::KSF, S4 = G::S4, RT = G::RT;
+  constexpr int NFC = G::NFACES, NCLS = G::NCLS;
   constexpr bool LARGE = G::LARGE;
   constexpr int NC = (KIND == 0) ? 4 : 2;  // input components per node
   const int lane = threadIdx.x & 63;
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   double* out = A.out;
 
   const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (stages.cpp)
-  const int nitems = listed ? A.nlist : C.ngroups * 2;
+  const int nitems = listed ? A.nlist : C.ngroups * NCLS;
   // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2); ranges start on
   // even items and every stride is even, so a wave keeps its class
   const int nblk = (int)gridDim.x, xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   const int i0 = A.spread ? (int)blockIdx.x * 4 + wave : xcd * ipx + slot * 4 + wave;
   const int i1 = A.spread ? nitems : hi;
   const int istep = A.spread ? nblk * 4 : blocks_here * 4;
-  const int k = i0 & 1;  // class of every item of this wave (item lists hold (group, 0), (group, 1) pairs)
+  const int k = (NCLS == 2) ? (i0 & 1) : 0;  // class of every item of this wave (item lists hold (group, 0), (group, 1) pairs)
   const T2Class& K = C.cls[k];
 
   // ---- operator fragments: registers, once per wave -----------------------------------------
@@ -106,19 +113,19 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = A.fragL[j * 64 + lane];
 
   // ---- class constants: one batch of scalar loads from the kernarg segment at an offset that depends on k only
-  double Jv[2][2], cnv[3][2];
+  double Jv[2][2], cnv[NFC][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int j = 0; j < 2; ++j) Jv[r][j] = K.Jinv[r][j];
 #pragma unroll
-  for (int f = 0; f < 3; ++f)
+  for (int f = 0; f < NFC; ++f)
 #pragma unroll
     for (int j = 0; j < 2; ++j) cnv[f][j] = K.cn[f][j];
-  int f_axis[3], f_dir[3], f_kn[3], f_ord[3];
-  uint32_t f_tf[3][KSF], f_tg[3][KSF];
+  int f_axis[NFC], f_dir[NFC], f_kn[NFC], f_ord[NFC];
+  uint32_t f_tf[NFC][KSF], f_tg[NFC][KSF];
 #pragma unroll
-  for (int f = 0; f < 3; ++f) {
+  for (int f = 0; f < NFC; ++f) {
     f_axis[f] = K.nb_axis[f];
     f_dir[f] = K.nb_dir[f];
     f_kn[f] = K.nb_cls[f];
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 
   for (int it = i0; it < i1; it += istep) {
     const int item = __builtin_amdgcn_readfirstlane(listed ? A.item_list[it] : it);
-    const int g = item >> 1;
+    const int g = (NCLS == 2) ? (item >> 1) : item;
     // ---- this lane's cell (a padding lane stands in for the group's first square, masked) -------------
     const int c = g * 16 + w;
     const bool valid = c < C.ncube;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       if (!__any(active)) continue;
     }
     const double* ownb = in + ((long)item * ND) * NC * 16;   // wave-uniform
-    const int e = (int)cl * 2 + k;  // cell index in the host numbering
+    const int e = (int)cl * NCLS + k;  // cell index in the host numbering
     // G: does this item hold source nodes?  (a scalar load that is consumed only in the epilogue)
     const int sslot_src = (KIND == 1 && A.src_slot != nullptr) ? A.src_slot[item] : -1;
 
@@ -185,22 +192,22 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
     //      they are small and non-negative.  GHOST = 1 lanes may read a packed remote trace instead:
     //      a lane pointer then.
     const int g0 = (g > C.gpr) ? g - C.gpr : 0;
-    const double* nbb = in + ((long)g0 * 2 * ND) * NC * 16;  // wave-uniform
-    double tn[3][KSF][NC];
-    double wf[3];
+    const double* nbb = in + ((long)g0 * NCLS * ND) * NC * 16;  // wave-uniform
+    double tn[NFC][KSF][NC];
+    double wf[NFC];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < NFC; ++f) {
       const int axis = f_axis[f], kn = f_kn[f], dir = f_dir[f];
       unsigned noff;  // bytes from nbb to the neighbour cell (component 0 of node 0, this lane's column)
       const double* gp = nullptr;
       bool ghost = false, physical = false;
       if (axis < 0) {
-        noff = (unsigned)(((((g - g0) * 2 + kn) * ND) * NC * 16 + w) * 8);
+        noff = (unsigned)(((((g - g0) * NCLS + kn) * ND) * NC * 16 + w) * 8);
       } else {
         const int cn = cc[axis] + dir;
         const bool inside = cn >= 0 && cn < (axis == 0 ? n0 : n1);
         const int nc = inside ? (int)cl + dir * (axis == 0 ? 1 : n0) : (int)cl;
-        noff = (unsigned)((((((nc >> 4) - g0) * 2 + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15)) * 8);
+        noff = (unsigned)((((((nc >> 4) - g0) * NCLS + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15)) * 8);
         physical = !inside;
         if (GHOST) {
           const int side = 2 * axis + (dir > 0 ? 1 : 0);
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           }
       // lifts of w_f (c n)_j T(nbr)_ij
 #pragma unroll
-      for (int f = 0; f < 3; ++f)
+      for (int f = 0; f < NFC; ++f)
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
@@ -306,7 +313,8 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
           for (int m = 0; m < S4; ++m) s[m][0] = s[m][1] = 0.0;
           // chunks of CH columns: all of a chunk's loads are in flight together (one round trip per chunk)
-          constexpr int CH = ND <= 6 ? ND : 5;
+          constexpr int CH = ND <= 6 ? ND : (ND % 5 == 0 ? 5 : (ND % 4 == 0 ? 4 : 3));
+          static_assert(ND % CH == 0, "the sponge column chunks must tile the element's nodes");
 #pragma nounroll
           for (int b0 = 0; b0 < ND; b0 += CH) {
             double uu[CH][2], bb[S4][CH];
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         fold(-Jv[r][0], -Jv[r][1], acc);
       }
 #pragma unroll
-      for (int f = 0; f < 3; ++f) {
+      for (int f = 0; f < NFC; ++f) {
         t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks)
@@ -449,9 +457,11 @@ T2Const tile2d_const(const MeshDev& md) {
     }
     return wd;
   };
-  for (int f = 0; f < 3; ++f) {
+  std::memset(C.tpw, 0, sizeof(C.tpw));
+  std::memset(C.cls, 0, sizeof(C.cls));
+  for (int f = 0; f < md.nfaces; ++f) {
     for (int ks = 0; ks < 2; ++ks) C.tpw[f][ks] = ks < ksf ? pack([&](int bb) { return md.fnode[f][bb]; }, ks) : 0u;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < md.ncls; ++k) {
       T2Class& K = C.cls[k];
       K.nb_axis[f] = md.nb_axis[k][f];
       K.nb_dir[f] = md.nb_dir[k][f];
@@ -465,13 +475,13 @@ T2Const tile2d_const(const MeshDev& md) {
       for (int j = 0; j < 2; ++j) K.cn[f][j] = md.cn[k][f][j];
     }
   }
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < md.ncls; ++k)
     for (int r = 0; r < 2; ++r)
       for (int j = 0; j < 2; ++j) C.cls[k].Jinv[r][j] = md.Jinv[k][r][j];
   return C;
 }
 
-template <int P, int SYM, int GHOST>
+template <int P, int SYM, int GHOST, int TP = 0>
 static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
   long blocks = (nitems + 3) / 4;
   const long cap = a.grid_blocks > 0 ? a.grid_blocks : 2048;
@@ -480,30 +490,39 @@ static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems
   const dim3 grid((unsigned)blocks), block(256);
   if (kind == 0) {
     if (a.mode == 0)
-      hipLaunchKernelGGL((tile2d_stage<P, 0, 0, SYM, GHOST>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 0, 0, SYM, GHOST, TP>), grid, block, 0, s, a, c);
     else
-      hipLaunchKernelGGL((tile2d_stage<P, 0, 1, SYM, GHOST>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 0, 1, SYM, GHOST, TP>), grid, block, 0, s, a, c);
   } else {
     if (a.mode == 0)
-      hipLaunchKernelGGL((tile2d_stage<P, 1, 0, SYM, GHOST>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 1, 0, SYM, GHOST, TP>), grid, block, 0, s, a, c);
     else
-      hipLaunchKernelGGL((tile2d_stage<P, 1, 1, SYM, GHOST>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 1, 1, SYM, GHOST, TP>), grid, block, 0, s, a, c);
   }
   return (int)hipGetLastError();
 }
 
-template <int P>
+template <int P, int TP = 0>
 static int launch_t2p(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
   bool ghosts = false;
   for (int sd = 0; sd < 4; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
-  if (a.sym) return ghosts ? launch_t2<P, 1, 1>(kind, a, c, nitems, s) : launch_t2<P, 1, 0>(kind, a, c, nitems, s);
-  return ghosts ? launch_t2<P, 0, 1>(kind, a, c, nitems, s) : launch_t2<P, 0, 0>(kind, a, c, nitems, s);
+  if (a.sym) return ghosts ? launch_t2<P, 1, 1, TP>(kind, a, c, nitems, s) : launch_t2<P, 1, 0, TP>(kind, a, c, nitems, s);
+  return ghosts ? launch_t2<P, 0, 1, TP>(kind, a, c, nitems, s) : launch_t2<P, 0, 0, TP>(kind, a, c, nitems, s);
 }
 
 bool tile2d_supported(int dim, int P) { return dim == 2 && P >= 1 && P <= 4; }
+bool tile2d_supported_quad(int P) { return P >= 1 && P <= 3; }   // DQ_4 has 25 rows: two tiles (not built)
 
 int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, long nitems, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.tensor) {
+    switch (P) {
+      case 1: return launch_t2p<1, 1>(kind, a, c, nitems, s);
+      case 2: return launch_t2p<2, 1>(kind, a, c, nitems, s);
+      case 3: return launch_t2p<3, 1>(kind, a, c, nitems, s);
+    }
+    return -1;
+  }
   switch (P) {
     case 1: return launch_t2p<1>(kind, a, c, nitems, s);
     case 2: return launch_t2p<2>(kind, a, c, nitems, s);

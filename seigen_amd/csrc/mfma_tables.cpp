@@ -30,8 +30,18 @@ MfmaGeom mfma_geom(const RefElem& re) {
 // i.e. it has the shape of the volume term.  The facet lifts then only carry the
 // NEIGHBOUR half (and a correction on domain-boundary facets, kernels_mfma.hip).
 // In d dimensions (c n)_f = -grad(lambda_f)/(d-1)!, so the factor is 1/(2 (d-1)!): 1/4 on tetrahedra, 1/2 on triangles.
+// Quadrilaterals (tensor-product element): (c n) of the facets 2r / 2r + 1 is -/+ row r of Jinv, so
+//   C_r = 1/2 (L_{2r+1} R_{2r+1} - L_{2r} R_{2r}).
 static inline double Eval(const RefElem& re, int r, int a, int b) {
   if (a >= re.nd || b >= re.nd) return 0.0;
+  if (re.kind == KIND_TENSOR) {
+    double v = re.D[((size_t)r * re.nd + a) * re.nd + b];
+    for (int bf = 0; bf < re.nf; ++bf) {
+      if (re.fnode[(size_t)(2 * r + 1) * re.nf + bf] == b) v -= 0.5 * re.L[((size_t)(2 * r + 1) * re.nd + a) * re.nf + bf];
+      if (re.fnode[(size_t)(2 * r) * re.nf + bf] == b) v += 0.5 * re.L[((size_t)(2 * r) * re.nd + a) * re.nf + bf];
+    }
+    return v;
+  }
   const double cfold = (re.dim == 3) ? 0.25 : 0.5;
   double v = re.D[((size_t)r * re.nd + a) * re.nd + b];
   for (int bf = 0; bf < re.nf; ++bf) {

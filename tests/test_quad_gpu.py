@@ -64,10 +64,13 @@ def test_eigenmode_converges_on_quadrilaterals(gpu):
         assert ou > floor and os_ > floor, (P, ou, os_)
 
 
-@pytest.mark.parametrize("P", [2, 4])
-def test_sponge_source_and_material_on_quadrilaterals(gpu, P):
+@pytest.mark.parametrize("P,path", [(1, None), (2, None), (2, "generic"), (3, None), (4, None)])
+def test_sponge_source_and_material_on_quadrilaterals(gpu, monkeypatch, P, path):
     """The extras of the explosive-source set-up on quadrilateral cells: DG4 sponge (elastic.py:207-208), a nodal
-    source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle."""
+    source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle - on the MFMA tile kernels
+    (DQ_1..3 by default), the generic kernels (DQ_4; DQ_2 forced)."""
+    if path:
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
     from seigen_amd import _lib
     from seigen_amd.backend import HipBlock
     n, L = (6, 5), (3.0, 2.5)
@@ -108,6 +111,42 @@ def test_sponge_source_and_material_on_quadrilaterals(gpu, P):
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
 
 
+@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("n", [(37, 23), (16, 1), (5, 40), (129, 3)])
+def test_quadrilateral_tile_kernels_agree_with_the_generic_kernels(gpu, monkeypatch, P, n):
+    """Ragged blocks (cell groups of 16 straddling rows, one-row and narrow blocks): the MFMA tile kernels against
+    the table-driven generic kernels, with sponge, source, per-cell material and per-cell physical density."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(P * 100 + n[0])
+    h = [0.7, 1.3]
+    res = {}
+    for path in ("generic", "tile"):
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        blk = HipBlock(2, P, n, h, [0.0, 0.0], "quadrilateral")
+        nc, nd = blk.ncells, blk.nd
+        if path == "generic":
+            lam, mu, rho = rng.uniform(0.4, 0.8, nc), rng.uniform(0.2, 0.4, nc), rng.uniform(0.8, 1.6, nc)
+            sigma = np.where(rng.uniform(size=(nc, 25)) > 0.7, 20.0, 0.0)
+            nodes = np.unique(rng.integers(0, nc * nd, size=min(30, nc * nd)))
+            vals = rng.uniform(-1, 1, (5, len(nodes), 2, 2))
+            vals = 0.5 * (vals + np.swapaxes(vals, -1, -2))
+            u0 = seeded(blk.field_shape(_lib.FIELD_U), 1)
+            s0 = seeded(blk.field_shape(_lib.FIELD_S), 2)
+            s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        blk.set_params(1.0, 0.01 * min(h) / P ** 2, lam, mu)
+        blk.set_density(rho, physical=True)
+        blk.set_absorption(sigma, 4)
+        blk.set_source(nodes, vals)
+        blk.set_field(_lib.FIELD_U, u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.step(5)
+        res[path] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    assert rel_err(res["tile"][0], res["generic"][0]) < 1e-12
+    assert rel_err(res["tile"][1], res["generic"][1]) < 1e-12
+
+
 def test_explosive_source_harness_on_quadrilaterals(gpu):
     """tests/explosive_source/explosive_source_lf4.py on RectangleMesh(..., quadrilateral=True), a 100 m x 50 m cut
     at h = 2.5, P2: box-Ricker source (:36-40), DG4 sponge (:43-45), receivers as uy.py:36-43 - traces and final
@@ -138,8 +177,10 @@ def test_quadrilateral_blocks_equal_the_single_block(gpu):
     layer of elastic.py:404-436 is direction- and cell-type-agnostic)."""
     from tests.test_harness_gpu import _multiblock_case
     for pipelined in (True, False):
-        _multiblock_case(2, 3, (8, 6), (2, 2), pipelined, extras=True, diagonal="quadrilateral")
+        _multiblock_case(2, 3, (8, 6), (2, 2), pipelined, extras=True, diagonal="quadrilateral")      # tile kernels
+        _multiblock_case(2, 4, (6, 6), (2, 2), pipelined, extras=True, diagonal="quadrilateral")      # generic kernels
     _multiblock_case(2, 2, (7, 5), (3, 1), True, diagonal="quadrilateral")
+    _multiblock_case(2, 2, (72, 6), (2, 2), True, extras=True, separable=True, diagonal="quadrilateral")   # x sides, wide rows
 
 
 def test_function_evaluation_and_integral_on_quadrilaterals(gpu):

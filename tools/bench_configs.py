@@ -76,9 +76,10 @@ def config2(steps, warmup, n=512, quadrilateral=False):
 
 
 def config2_quad(steps, warmup):
-    """config 2's set-up on quadrilateral cells (DQ_2, nine nodes per square): the table-driven generic kernels"""
+    """config 2's set-up on quadrilateral cells (DQ_2, nine nodes per square): MFMA tile kernels (SEIGEN_HIP_PATH=generic:
+    the table-driven generic kernels)"""
     r = config2(steps, warmup, quadrilateral=True)
-    r["config"] = r["config"].replace("c2:", "c2q (quadrilaterals, generic kernels):")
+    r["config"] = r["config"].replace("c2:", "c2q (quadrilaterals, DQ_2):")
     return r
 
 
