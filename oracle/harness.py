@@ -162,6 +162,24 @@ def project_box_indicator(mesh, P, lo, hi):
     triangle it can touch, fan-triangulated and integrated with a rule exact for P_k.  (Build-defined
     source of the REF-C convergence study, not in the reference - see ExplosiveSource.source_mode.)"""
     lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    if getattr(mesh, "kind", "simplex") == "tensor":
+        # axis-parallel rectangles: K n box is a rectangle; Gauss-Legendre product rule on it
+        nd = refelem.el_nnodes(2, P, "tensor")
+        out = np.zeros((mesh.ncells, nd))
+        X = mesh.vertices[mesh.cells]                          # [nc, 4, 2]
+        xq, wq = refelem.el_quadrature(2, P, "tensor")
+        xm, wm = refelem.el_quadrature(2, 2 * P, "tensor")
+        pm, _ = refelem.el_tabulate(2, P, xm, "tensor")
+        Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))
+        for c in range(mesh.ncells):
+            a0, a1 = np.maximum(lo, X[c].min(axis=0)), np.minimum(hi, X[c].max(axis=0))
+            if (a1 - a0).min() <= 0:
+                continue
+            xp = a0 + xq * (a1 - a0)
+            xi = np.einsum('mi,qi->qm', mesh.Jinv[c], xp - mesh.v0[c])
+            phi, _ = refelem.el_tabulate(2, P, xi, "tensor")
+            out[c] = Minv @ (np.prod(a1 - a0) * (wq @ phi)) / abs(mesh.detJ[c])
+        return out
     nd = refelem.nnodes(2, P)
     out = np.zeros((mesh.ncells, nd))
     X = mesh.vertices[mesh.cells]                              # [nc, 3, 2]

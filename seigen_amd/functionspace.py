@@ -320,11 +320,34 @@ def project_box_indicator(space, lo, hi):
     from .norms import simplex_rule, tabulate
     if space.dim != 2:
         raise NotImplementedError("project_box_indicator: 2-D spaces")
-    if space.mesh.quadrilateral:
-        raise NotImplementedError("project_box_indicator: triangular meshes")
     mesh, P, nd = space.mesh, space.degree, space.nd
     part = mesh.partition
     lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    if mesh.quadrilateral:
+        # the cells are axis-parallel rectangles: K n box is a rectangle, integrated with a Gauss-Legendre
+        # product rule exact for the basis (degree P per variable)
+        from .norms import cell_rule
+        xq, wq = cell_rule(2, P, 1)
+        xm, wm = cell_rule(2, 2 * P, 1)
+        pm = tabulate(2, P, xm, 1)
+        Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))
+        out = np.zeros((space.ncells, nd))
+        h = np.asarray(mesh.h[:2])
+        rng = []
+        for a in range(2):
+            i0 = int(np.floor((lo[a] - mesh.origin[a]) / mesh.h[a])) - part.start[a]
+            i1 = int(np.floor((hi[a] - mesh.origin[a]) / mesh.h[a])) - part.start[a]
+            rng.append(range(max(i0, 0), min(i1, part.n[a] - 1) + 1))
+        for j in rng[1]:
+            for i in rng[0]:
+                c0 = np.array([mesh.origin[0] + (part.start[0] + i) * h[0], mesh.origin[1] + (part.start[1] + j) * h[1]])
+                a0, a1 = np.maximum(lo, c0), np.minimum(hi, c0 + h)
+                if (a1 - a0).min() <= 0:
+                    continue
+                xi = ((a0 + xq * (a1 - a0)) - c0) / h                  # reference points of the sub-rectangle's rule
+                b = np.prod(a1 - a0) * (wq @ tabulate(2, P, xi, 1))
+                out[j * part.n[0] + i] = Minv @ b / np.prod(h)
+        return out
     xq, wq = simplex_rule(2, P)
     xm, wm = simplex_rule(2, 2 * P)
     pm = tabulate(2, P, xm)

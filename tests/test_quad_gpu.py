@@ -181,16 +181,3 @@ def test_quadrilateral_blocks_equal_the_single_block(gpu):
         _multiblock_case(2, 4, (6, 6), (2, 2), pipelined, extras=True, diagonal="quadrilateral")      # generic kernels
     _multiblock_case(2, 2, (7, 5), (3, 1), True, diagonal="quadrilateral")
     _multiblock_case(2, 2, (72, 6), (2, 2), True, extras=True, separable=True, diagonal="quadrilateral")   # x sides, wide rows
-
-
-def test_function_evaluation_and_integral_on_quadrilaterals(gpu):
-    from seigen_amd import Function, UnitSquareMesh, VectorFunctionSpace
-    from seigen_amd.expression import Expression
-    from seigen_amd.functionspace import evaluate_at, integral
-    mesh = UnitSquareMesh(4, 3, quadrilateral=True)
-    U = VectorFunctionSpace(mesh, "DG", 3)
-    f = Function(U).interpolate(Expression(("x[0]*x[0]*x[1]", "1 + x[0] - 2*x[1]*x[1]*x[1]")))
-    for p in ((0.3, 0.7), (0.99, 0.01), (0.5, 1.0 / 3.0), (1.0, 1.0)):
-        v = evaluate_at(f, p)
-        np.testing.assert_allclose(v, [p[0] ** 2 * p[1], 1 + p[0] - 2 * p[1] ** 3], atol=1e-13)
-    np.testing.assert_allclose(integral(f), [1.0 / 6.0, 1.0], atol=1e-13)

@@ -116,3 +116,39 @@ def test_oracle_on_quadrilaterals_reproduces_polynomials_and_converges():
         e = em.errors(u1, s1)
         errs.append((e["u_error"], e["s_error"]))
     assert math.log2(errs[0][0] / errs[1][0]) > 2.5 and math.log2(errs[0][1] / errs[1][1]) > 2.5
+
+
+# ---- host layer on quadrilateral meshes (device-free entry points of the library only) ----------------------------
+def test_box_projection_on_quadrilaterals():
+    """source_mode='project' of the explosive-source harness: the L2 projection of the source box has the box's
+    area on every mesh, equals the oracle's, and reproduces an indicator that the mesh resolves."""
+    from oracle.harness import project_box_indicator as oracle_project
+    from seigen_amd import Function, FunctionSpace, RectangleMesh
+    from seigen_amd.functionspace import integral, project_box_indicator
+    for P in (1, 2, 3):
+        mesh = RectangleMesh(7, 5, 3.5, 2.0, quadrilateral=True)
+        V = FunctionSpace(mesh, "DG", P)
+        lo, hi = (0.8, 0.3), (2.1, 1.45)
+        c = project_box_indicator(V, lo, hi)
+        f = Function(V).assign(c)
+        assert abs(float(integral(f)) - (hi[0] - lo[0]) * (hi[1] - lo[1])) < 1e-13
+        m = omesh.structured(2, (7, 5), (3.5, 2.0), quadrilateral=True)
+        np.testing.assert_allclose(c, oracle_project(m, P, lo, hi), atol=1e-12)
+        c2 = project_box_indicator(V, (0.5, 0.4), (2.0, 1.2))              # cell boundaries: the indicator is in the space
+        X = V.node_coords()
+        inside = (X[..., 0].min(1) >= 0.5 - 1e-12) & (X[..., 0].max(1) <= 2.0 + 1e-12) & \
+                 (X[..., 1].min(1) >= 0.4 - 1e-12) & (X[..., 1].max(1) <= 1.2 + 1e-12)
+        np.testing.assert_allclose(c2, np.where(inside[:, None], 1.0, 0.0) * np.ones_like(c2), atol=1e-11)
+
+
+def test_function_evaluation_and_integral_on_quadrilaterals():
+    from seigen_amd import Function, UnitSquareMesh, VectorFunctionSpace
+    from seigen_amd.expression import Expression
+    from seigen_amd.functionspace import evaluate_at, integral
+    mesh = UnitSquareMesh(4, 3, quadrilateral=True)
+    U = VectorFunctionSpace(mesh, "DG", 3)
+    f = Function(U).interpolate(Expression(("x[0]*x[0]*x[1]", "1 + x[0] - 2*x[1]*x[1]*x[1]")))
+    for p in ((0.3, 0.7), (0.99, 0.01), (0.5, 1.0 / 3.0), (1.0, 1.0)):
+        v = evaluate_at(f, p)
+        np.testing.assert_allclose(v, [p[0] ** 2 * p[1], 1 + p[0] - 2 * p[1] ** 3], atol=1e-13)
+    np.testing.assert_allclose(integral(f), [1.0 / 6.0, 1.0], atol=1e-13)
