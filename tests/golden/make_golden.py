@@ -178,7 +178,20 @@ def eigenmode_errors():
             e = em.errors(u1, s1)
             res["3d"].append(dict(P=P, N=N, dt=dt, **e))
             print("3d", P, N, e, flush=True)
-    for k in ("2d", "3d"):
+    # the 2-D sweep on UnitSquareMesh(N, N, quadrilateral=True) (tensor-product element; build-defined row)
+    res.setdefault("2d_quadrilateral", [])
+    haveq = {(r["P"], r["N"]) for r in res["2d_quadrilateral"]}
+    for P in (1, 2, 3, 4):
+        for N in (4, 8, 16):
+            if (P, N) in haveq:
+                continue
+            dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
+            em = harness.Eigenmode2D(N, P, dt, quadrilateral=True)
+            u1, s1 = em.run()
+            e = em.errors(u1, s1)
+            res["2d_quadrilateral"].append(dict(P=P, N=N, dt=dt, **e))
+            print("2d quadrilateral", P, N, e, flush=True)
+    for k in ("2d", "3d", "2d_quadrilateral"):
         res[k].sort(key=lambda r: (r["P"], r["N"]))
     json.dump(res, open(path, "w"), indent=1)
 

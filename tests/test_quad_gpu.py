@@ -49,18 +49,26 @@ def test_eigenmode_on_quadrilaterals_matches_oracle(gpu, P, N):
     assert rel_err(u1.dat.data_cells, ou) < 1e-8 and rel_err(s1.dat.data_cells, os_) < 1e-8
 
 
-def test_eigenmode_converges_on_quadrilaterals(gpu):
+def test_eigenmode_sweep_on_quadrilaterals_matches_goldens_and_converges(gpu):
+    """The sweep of eigenmode_2d.py:68-84 (P1..4, N = 4, 8, 16) on quadrilateral meshes against the oracle's committed
+    error functionals (tests/golden/eigenmode_errors.json "2d_quadrilateral") to 1e-9, and the observed orders."""
+    import json
+    import os
     _quiet()
     from seigen_amd.harness.eigenmode import Eigenmode2DLF4
-    for P, floor in ((1, 1.0), (2, 2.5), (3, 2.7)):
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eigenmode_errors.json")))
+    rows = {(r["P"], r["N"]): r for r in gold["2d_quadrilateral"]}
+    assert len(rows) == 12
+    for P, floor in ((1, 1.0), (2, 2.5), (3, 2.7), (4, 4.5)):
         errs = []
-        for N in (8, 16):
-            dt = 0.5 * (1.0 / N) / 2.0 ** (P - 1)
-            em = Eigenmode2DLF4(N, P, dt, solver="explicit", output=False, quadrilateral=True)
+        for N in (4, 8, 16):
+            g = rows[(P, N)]
+            em = Eigenmode2DLF4(N, P, g["dt"], solver="explicit", output=False, quadrilateral=True)
             u1, s1 = em.eigenmode2d(T=5.0)
             errs.append(em.eigenmode_error(u1, s1))
-        ou = math.log2(errs[0][0] / errs[1][0])
-        os_ = math.log2(errs[0][1] / errs[1][1])
+            assert abs(errs[-1][0] - g["u_error"]) < 1e-9 and abs(errs[-1][1] - g["s_error"]) < 1e-9, (P, N, errs[-1], g)
+        ou = math.log2(errs[1][0] / errs[2][0])
+        os_ = math.log2(errs[1][1] / errs[2][1])
         assert ou > floor and os_ > floor, (P, ou, os_)
 
 

@@ -118,6 +118,21 @@ def test_oracle_on_quadrilaterals_reproduces_polynomials_and_converges():
     assert math.log2(errs[0][0] / errs[1][0]) > 2.5 and math.log2(errs[0][1] / errs[1][1]) > 2.5
 
 
+def test_oracle_quadrilateral_sweep_matches_committed_goldens():
+    """tests/golden/eigenmode_errors.json "2d_quadrilateral" (make_golden.py eigen): the coarse rows, recomputed."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eigenmode_errors.json")))
+    rows = {(r["P"], r["N"]): r for r in gold["2d_quadrilateral"]}
+    assert len(rows) == 12
+    for (P, N) in ((1, 8), (2, 8), (3, 4), (4, 4)):
+        g = rows[(P, N)]
+        em = Eigenmode2D(N, P, g["dt"], quadrilateral=True)
+        u1, s1 = em.run(5.0)
+        e = em.errors(u1, s1)
+        assert abs(e["u_error"] - g["u_error"]) < 1e-12 and abs(e["s_error"] - g["s_error"]) < 1e-12
+
+
 # ---- host layer on quadrilateral meshes (device-free entry points of the library only) ----------------------------
 def test_box_projection_on_quadrilaterals():
     """source_mode='project' of the explosive-source harness: the L2 projection of the source box has the box's
