@@ -183,6 +183,16 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
  * bitwise what sg_set_source gives for the table of those products. */
 int sg_set_source_separable(sg_handle* h, int64_t nnz, const int64_t* nodes, const double* pattern, int64_t nsteps,
                             const double* weights);
+/* The reference's explosive source itself, from its parameters (tests/explosive_source/explosive_source_lf4.py:36-40):
+ *   S_ij(x, t) = delta_ij w(t) at the DG nodes x inside the CLOSED box lo <= x <= hi (the nodal interpolation of the
+ *   box indicator, elastic.py:149-154), w(t) = (-1 + 2 a (t - t0)^2) exp(-a (t - t0)^2),
+ * for the steps k = 0 .. nsteps-1 counted from this call, evaluated at t = t_first + k * dt_step (elastic.py:285-288
+ * sets t to the time of the step before re-interpolating: t_first = dt, dt_step = dt for a run from t = 0).
+ * lo, hi: dim doubles each.  Node coordinates are those of sg_node_coords.  A convenience over
+ * sg_set_source_separable (same storage, same rounding rule); a box that contains no node of this block disables
+ * the source of the block. */
+int sg_set_source_box_ricker(sg_handle* h, const double* lo, const double* hi, double a, double t0, double t_first,
+                             double dt_step, int64_t nsteps);
 
 /* ---- the hot path ---------------------------------------------------------------- */
 /* whole steps (all six stages, source included); replaces the body of

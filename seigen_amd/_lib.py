@@ -55,6 +55,7 @@ SYMBOLS = {
     "sg_set_absorption": (C.c_int, [_P, _P, C.c_int]),
     "sg_set_source": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P]),
     "sg_set_source_separable": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P]),
+    "sg_set_source_box_ricker": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]),
     "sg_step": (C.c_int, [_P, C.c_int64]),
     "sg_run_stage": (C.c_int, [_P, C.c_int, C.c_int]),
     "sg_end_step": (C.c_int, [_P]),

@@ -153,6 +153,14 @@ class HipBlock(object):
         check(self.lib.sg_set_source(self.h, nodes.size, nodes.ctypes.data, -1 if static else values.shape[0],
                                      values.ctypes.data), self.h)
 
+    def set_source_box_ricker(self, lo, hi, a, t0, t_first, dt_step, nsteps):
+        """The reference's box-Ricker source from its parameters (sg_set_source_box_ricker, include/seigen_hip.h)."""
+        lo, hi = _f64(lo).ravel(), _f64(hi).ravel()
+        if lo.size != self.dim or hi.size != self.dim:
+            raise ValueError("lo and hi hold one coordinate per dimension")
+        check(self.lib.sg_set_source_box_ricker(self.h, lo.ctypes.data, hi.ctypes.data, float(a), float(t0),
+                                                float(t_first), float(dt_step), int(nsteps)), self.h)
+
     def set_source_separable(self, nodes, pattern, weights):
         """S(node, step k) = weights[k] * pattern[node]: nodes [nnz], pattern [nnz, d, d], weights [nsteps]."""
         nodes = np.ascontiguousarray(nodes, dtype=np.int64).ravel()

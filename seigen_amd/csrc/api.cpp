@@ -372,43 +372,64 @@ int sg_sync(sg_handle* h) {
   return SG_OK;
 }
 
+// Node coordinates of a block: the affine image of the reference lattice under every cell's vertex map (one
+// arithmetic, shared by sg_block_node_coords and the source box test of sg_set_source_box_ricker).
+struct NodeGeom {
+  int d = 0, degree = 0, nq = 0, ncls = 0;
+  std::vector<int> lat;
+  int off[MAX_CLS][4][3];
+  const sg_config* cfg = nullptr;
+  bool init(const sg_config* c, int deg) {
+    cfg = c;
+    d = c->dim;
+    degree = deg;
+    const bool quad = c->diagonal == SG_DIAGONAL_QUAD;
+    if (quad && d != 2) return false;
+    const int kind = quad ? KIND_TENSOR : KIND_SIMPLEX;
+    lattice_points(d, degree, lat, kind);
+    nq = num_nodes(d, degree, kind);
+    if (quad) {   // vertex 0 the low corner, vertex 1 / 2 one cell along x / y: the affine map of refelem.hpp's unit square
+      std::memset(off, 0, sizeof(off));
+      ncls = 1;
+      off[0][1][0] = 1;
+      off[0][2][1] = 1;
+    } else {
+      class_vertices(d, c->diagonal, ncls, off);
+    }
+    return true;
+  }
+  // coordinates of node a of the cell of class k in cube c
+  void node(const int c[3], int k, int a, double x[3]) const {
+    double X[4][3];
+    for (int v = 0; v <= d; ++v)
+      for (int i = 0; i < d; ++i) X[v][i] = cfg->origin[i] + (double)(c[i] + off[k][v][i]) * cfg->h[i];
+    for (int i = 0; i < d; ++i) {
+      double xv = X[0][i];
+      for (int m = 0; m < d; ++m) xv += (X[m + 1][i] - X[0][i]) * ((double)lat[a * d + m] / (double)degree);
+      x[i] = xv;
+    }
+  }
+};
+
 int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t nbytes) {
   if (!cfg || !out || degree < 1 || degree > 8 || cfg->dim < 1 || cfg->dim > 3) return SG_ERR_ARG;
-  const int d = cfg->dim;
-  const bool quad = cfg->diagonal == SG_DIAGONAL_QUAD;
-  if (quad && d != 2) return SG_ERR_ARG;
-  const int kind = quad ? KIND_TENSOR : KIND_SIMPLEX;
-  std::vector<int> lat;
-  lattice_points(d, degree, lat, kind);
-  const int nq = num_nodes(d, degree, kind);
-  int off[MAX_CLS][4][3], ncls;
-  if (quad) {   // vertex 0 the low corner, vertex 1 / 2 one cell along x / y: the affine map of refelem.hpp's unit square
-    std::memset(off, 0, sizeof(off));
-    ncls = 1;
-    off[0][1][0] = 1;
-    off[0][2][1] = 1;
-  } else {
-    class_vertices(d, cfg->diagonal, ncls, off);
-  }
+  NodeGeom G;
+  if (!G.init(cfg, degree)) return SG_ERR_ARG;
+  const int d = G.d;
   int n[3] = {1, 1, 1};
   for (int a = 0; a < d; ++a) n[a] = cfg->n[a];
-  if (nbytes != (size_t)n[0] * n[1] * n[2] * ncls * nq * d * sizeof(double)) return SG_ERR_ARG;
+  if (nbytes != (size_t)n[0] * n[1] * n[2] * G.ncls * G.nq * d * sizeof(double)) return SG_ERR_ARG;
   size_t o = 0;
   for (int ck = 0; ck < n[2]; ++ck)
     for (int cj = 0; cj < n[1]; ++cj)
       for (int ci = 0; ci < n[0]; ++ci) {
-        int c[3] = {ci, cj, ck};
-        for (int k = 0; k < ncls; ++k) {
-          double X[4][3];
-          for (int v = 0; v <= d; ++v)
-            for (int i = 0; i < d; ++i) X[v][i] = cfg->origin[i] + (double)(c[i] + off[k][v][i]) * cfg->h[i];
-          for (int a = 0; a < nq; ++a)
-            for (int i = 0; i < d; ++i) {
-              double x = X[0][i];
-              for (int m = 0; m < d; ++m) x += (X[m + 1][i] - X[0][i]) * ((double)lat[a * d + m] / (double)degree);
-              out[o++] = x;
-            }
-        }
+        const int c[3] = {ci, cj, ck};
+        for (int k = 0; k < G.ncls; ++k)
+          for (int a = 0; a < G.nq; ++a) {
+            double x[3];
+            G.node(c, k, a, x);
+            for (int i = 0; i < d; ++i) out[o++] = x[i];
+          }
       }
   return SG_OK;
 }
@@ -653,6 +674,47 @@ int sg_set_source_separable(sg_handle* h, int64_t nnz, const int64_t* nodes, con
   h->src_weights.assign(weights, weights + nsteps);
   h->src_nsteps = nsteps;
   return SG_OK;
+}
+
+int sg_set_source_box_ricker(sg_handle* h, const double* lo, const double* hi, double a, double t0, double t_first,
+                             double dt_step, int64_t nsteps) {
+  if (!h || !lo || !hi || nsteps < 0) return SG_ERR_ARG;
+  const int d = h->cfg.dim;
+  NodeGeom G;
+  if (!G.init(&h->cfg, h->cfg.degree)) return SG_ERR_ARG;
+  // cubes that can hold a node of the box: those overlapping it (closed on both sides)
+  int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+  for (int i = 0; i < d; ++i) {
+    if (!(lo[i] <= hi[i])) return fail(h, SG_ERR_ARG, "source box: lo must not exceed hi");
+    const double t0c = std::floor((lo[i] - h->cfg.origin[i]) / h->cfg.h[i]) - 1.0;
+    const double t1c = std::floor((hi[i] - h->cfg.origin[i]) / h->cfg.h[i]) + 1.0;
+    c0[i] = (int)std::max(0.0, std::min(t0c, (double)h->cfg.n[i]));
+    c1[i] = (int)std::max(-1.0, std::min(t1c, (double)h->cfg.n[i] - 1.0));
+  }
+  std::vector<int64_t> nodes;
+  for (int ck = c0[2]; ck <= c1[2]; ++ck)
+    for (int cj = c0[1]; cj <= c1[1]; ++cj)
+      for (int ci = c0[0]; ci <= c1[0]; ++ci) {
+        const int c[3] = {ci, cj, ck};
+        const int64_t cube = ci + (int64_t)h->cfg.n[0] * (cj + (int64_t)h->cfg.n[1] * ck);
+        for (int k = 0; k < G.ncls; ++k)
+          for (int b = 0; b < G.nq; ++b) {
+            double x[3];
+            G.node(c, k, b, x);
+            bool in = true;
+            for (int i = 0; i < d; ++i) in = in && x[i] >= lo[i] && x[i] <= hi[i];
+            if (in) nodes.push_back((cube * G.ncls + k) * G.nq + b);
+          }
+      }
+  if (nodes.empty() || nsteps == 0) return sg_set_source(h, 0, nullptr, 0, nullptr);
+  std::vector<double> pattern(nodes.size() * (size_t)d * d, 0.0), w((size_t)nsteps);
+  for (size_t j = 0; j < nodes.size(); ++j)
+    for (int i = 0; i < d; ++i) pattern[(j * d + i) * d + i] = 1.0;
+  for (int64_t k = 0; k < nsteps; ++k) {
+    const double t = t_first + (double)k * dt_step, q = (t - t0) * (t - t0);
+    w[(size_t)k] = (-1.0 + 2.0 * a * q) * std::exp(-a * q);
+  }
+  return sg_set_source_separable(h, (int64_t)nodes.size(), nodes.data(), pattern.data(), nsteps, w.data());
 }
 
 int sg_get_sym(const sg_handle* h, int* sym) {

@@ -621,3 +621,55 @@ def test_separable_source(gpu):
     el.SOURCE_TABLE_MAX_BYTES = 0
     with pytest.raises(MemoryError):
         el.run(30 * el.dt)
+
+
+@pytest.mark.parametrize("case", ["tri", "quad", "tet"])
+def test_box_ricker_source_from_its_parameters(gpu, case):
+    """sg_set_source_box_ricker (the reference's source, explosive_source_lf4.py:36-40, from box and wavelet parameters)
+    against the same source handed over as nodes + Expression values by the host layer: same node set, weights equal
+    to the last bit or two of exp(), fields to 1e-13; boxes that contain no node / reach outside the block."""
+    import math
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    a, t0 = 159.42, 0.03
+    if case == "tet":
+        dim, P, n, h, diag = 3, 3, (6, 5, 4), [2.5, 2.5, 2.5], "left"
+        lo, hi = (4.5, 4.5, 4.5), (8.0, 8.0, 8.0)
+    else:
+        dim, P, n, h, diag = 2, 2, (24, 10), [2.5, 2.5], "quadrilateral" if case == "quad" else "left"
+        lo, hi = (14.5, 18.5), (15.5, 19.5)          # the reference's 1 m box: a node on the box line counts (closed box)
+    dt, nsteps = 1e-3, 40
+    res = []
+    for mode in ("host", "abi"):
+        blk = HipBlock(dim, P, n, h, [0.0] * dim, diag)
+        blk.set_params(1.0, dt, 3599.3664, 3600.0)
+        if mode == "host":
+            X = blk.node_coords().reshape(-1, dim)
+            inside = np.all((X >= np.asarray(lo)) & (X <= np.asarray(hi)), axis=1)
+            nodes = np.nonzero(inside)[0]
+            assert len(nodes) > 0
+            pat = np.zeros((len(nodes), dim, dim))
+            for i in range(dim):
+                pat[:, i, i] = 1.0
+            w = np.array([(-1.0 + 2 * a * (dt * (k + 1) - t0) ** 2) * math.exp(-a * (dt * (k + 1) - t0) ** 2) for k in range(nsteps)])
+            blk.set_source_separable(nodes, pat, w)
+        else:
+            blk.set_source_box_ricker(lo, hi, a, t0, dt, dt, nsteps)
+        blk.step(nsteps + 3)
+        res.append((blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S)))
+        blk.close()
+    scale = np.abs(res[0][1]).max()
+    assert scale > 0
+    assert np.abs(res[0][1] - res[1][1]).max() < 1e-13 * scale
+    assert np.abs(res[0][0] - res[1][0]).max() < 1e-13 * np.abs(res[0][0]).max()
+    # a box between the nodes: no source; a box that sticks out of the block: clipped; lo > hi: an error
+    blk = HipBlock(dim, P, n, h, [0.0] * dim, diag)
+    blk.set_params(1.0, dt, 0.5, 0.25)
+    blk.set_source_box_ricker([0.3] * dim, [0.4] * dim, a, t0, dt, dt, nsteps)
+    blk.step(3)
+    assert np.abs(blk.get_field(_lib.FIELD_S)).max() == 0.0
+    blk.set_source_box_ricker([-50.0] * dim, [1.0] * dim, a, t0, dt, dt, nsteps)
+    blk.step(3)
+    assert np.abs(blk.get_field(_lib.FIELD_S)).max() > 0.0
+    with pytest.raises(_lib.SeigenHipError):
+        blk.set_source_box_ricker([1.0] * dim, [0.5] * dim, a, t0, dt, dt, nsteps)
