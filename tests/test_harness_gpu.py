@@ -673,3 +673,36 @@ def test_box_ricker_source_from_its_parameters(gpu, case):
     assert np.abs(blk.get_field(_lib.FIELD_S)).max() > 0.0
     with pytest.raises(_lib.SeigenHipError):
         blk.set_source_box_ricker([1.0] * dim, [0.5] * dim, a, t0, dt, dt, nsteps)
+
+
+@pytest.mark.parametrize("quad", [0, 1])
+def test_plain_c_host_through_the_c_abi(gpu, tmp_path, quad):
+    """examples/explosive_source_c_abi.c: the explosive-source set-up (sponge, box-Ricker source, run, download) from a
+    C99 program that links libseigen_hip.so and nothing else - the drop-in boundary without the Python host layer.
+    Its final velocity field equals the same run through HipBlock bit for bit."""
+    import subprocess
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "explosive_source_c_abi")
+    libdir = os.path.join(root, "seigen_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                         os.path.join(root, "examples", "explosive_source_c_abi.c"), "-o", exe,
+                         "-L" + libdir, "-lseigen_hip", "-Wl,-rpath," + libdir, "-lm"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    nx, ny, P, nsteps = 40, 24, 2, 60
+    out = str(tmp_path / "u.bin")
+    run = subprocess.run([exe, str(nx), str(ny), str(P), str(nsteps), str(quad), out], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "device_ms_per_step" in run.stdout
+    u_c = np.fromfile(out)
+    blk = HipBlock(2, P, (nx, ny), [2.5, 2.5], [0.0, 0.0], "quadrilateral" if quad else "left")
+    blk.set_params(1.0, 1e-3, 3599.3664, 3600.0)
+    X = blk.node_coords(4)
+    Lx, Ly = nx * 2.5, ny * 2.5
+    blk.set_absorption(np.where((X[..., 0] <= 20.0) | (X[..., 0] >= Lx - 20.0) | (X[..., 1] <= 20.0), 1000.0, 0.0), 4)
+    blk.set_source_box_ricker((44.5, Ly - 1.5), (45.5, Ly - 0.5), 159.42, 0.03, 1e-3, 1e-3, nsteps)
+    blk.step(nsteps)
+    u_py = blk.get_field(_lib.FIELD_U)
+    assert np.abs(u_py).max() > 0
+    assert np.array_equal(u_c, u_py.ravel())
