@@ -149,8 +149,9 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->use_tile = kp.tile;
   if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
   h->f32 = cfg->dtype;
-  if (h->f32 && !h->use_mfma)
-    return fail(h, SG_ERR_ARG, "dtype f32 is implemented on the MFMA path (3-D blocks; degree 1 from 65536 cells)");
+  if (h->f32 && !h->use_mfma && !h->use_tile)
+    return fail(h, SG_ERR_ARG, "dtype f32 is implemented on the MFMA paths (3-D blocks: degree 1 from 65536 cells; 2-D "
+                               "blocks on the tile kernels: triangles P1-P4, quadrilaterals P1-P3)");
   h->md.gw = kp.gw;
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;
@@ -215,8 +216,17 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
       return fail(h, SG_ERR_NOMEM, "hipMalloc of a field buffer failed");
     HIPCHECK(h, hipMemset(h->field[f], 0, h->field_alloc[f] * es));
   }
-  if (h->use_mfma && h->f32) {
-    std::vector<float> fF = mfma32_frags_F(h->re), fG = mfma32_frags_G(h->re), fL = mfma32_frags_L(h->re);
+  if ((h->use_mfma || h->use_tile) && h->f32) {
+    std::vector<float> fF, fG, fL;
+    if (h->use_tile) {
+      fF = tile2d_frags32_V(h->re, -1.0);
+      fG = tile2d_frags32_V(h->re, 1.0);
+      fL = tile2d_frags32_L(h->re);
+    } else {
+      fF = mfma32_frags_F(h->re);
+      fG = mfma32_frags_G(h->re);
+      fL = mfma32_frags_L(h->re);
+    }
     HIPCHECK(h, hipMalloc((void**)&h->fragF, fF.size() * sizeof(float)));
     HIPCHECK(h, hipMalloc((void**)&h->fragG, fG.size() * sizeof(float)));
     HIPCHECK(h, hipMalloc((void**)&h->fragL, fL.size() * sizeof(float)));

@@ -37,7 +37,11 @@ namespace sg {
 
 // TP = 1: quadrilateral cells, tensor-product element DQ_P (one class per square, four facets; P <= 3: at most
 // one 16-row tile)
-template <int P, int TP = 0>
+// R = float (sg_config::dtype = 1, the second mode of SURVEY 8d): v_mfma_f32_16x16x4_f32 for every degree (gfx950 has
+// no 4-row f32 shape with K = 4), one zero-padded 16-row tile; its C/D rows are 4 (lane >> 4) + reg, so the float
+// operator tiles hold node 4 (i & 3) + (i >> 2) in MFMA row i (mfma_tables.cpp tile2d_frags32_*) and accumulator
+// register m of lane group q is node row 4 m + q, as in double.
+template <int P, int TP = 0, typename R = double>
 struct TG : ElemDims<2, P, TP> {
   using ElemDims<2, P, TP>::ND;
   using ElemDims<2, P, TP>::NF;
@@ -46,13 +50,16 @@ struct TG : ElemDims<2, P, TP> {
   static constexpr int KS = (ND + 3) / 4;    // k-steps over the element nodes
   static constexpr int KSF = (NF + 3) / 4;   // k-steps over the facet nodes
   static constexpr int S4 = (ND + 3) / 4;    // row-quads of the result
-  static constexpr bool LARGE = ND > SG_T2_LARGE_FROM;     // one 16-row tile (P3, P4) or S4 4-row tiles (P1, P2)
+  static constexpr bool LARGE = sizeof(R) == 4 || ND > SG_T2_LARGE_FROM;     // one 16-row tile (P3, P4; float) or S4 4-row tiles (P1, P2)
   static constexpr int RT = LARGE ? 1 : S4;  // A fragments per (operator, k-step)
   static constexpr int NFRAG_V = 2 * KS * RT;
   static constexpr int NFRAG_L = NFACES * KSF * RT;
 };
 
 typedef double t2d4 __attribute__((ext_vector_type(4)));
+typedef float t2f4 __attribute__((ext_vector_type(4)));
+template <typename R> struct T2V { typedef t2d4 v4; };
+template <> struct T2V<float> { typedef t2f4 v4; };
 
 // acc (rows 4 reg + q of the 16 cells) += A x B.  LARGE: a[0] is the 16-row fragment; else a[t] is the
 // 4-row fragment of row-quad t (lane l of its result holds row l >> 4 of cell l & 15).
@@ -65,22 +72,31 @@ __device__ __forceinline__ void t2_mma(const double* a, double b, t2d4& acc) {
     for (int t = 0; t < S4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t], b, acc[t], 0, 0, 0);
   }
 }
+template <bool LARGE, int S4>
+__device__ __forceinline__ void t2_mma(const float* a, float b, t2f4& acc) {
+  static_assert(LARGE, "float kernels use the 16-row tile at every degree");
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b, acc, 0, 0, 0);
+}
 
 // Access through a wave-uniform base and a 32-bit lane offset in bytes: global_load/store with an SGPR base,
 // no 64-bit lane arithmetic (each 64-bit lane pointer costs two VALU adds and two registers).
-__device__ __forceinline__ double t2_ld(const double* ubase, unsigned boff) {
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ubase) + boff);
+template <typename R>
+__device__ __forceinline__ R t2_ld(const R* ubase, unsigned boff) {
+  return *reinterpret_cast<const R*>(reinterpret_cast<const char*>(ubase) + boff);
 }
-__device__ __forceinline__ void t2_st(double* ubase, unsigned boff, double v) {
-  *reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + boff) = v;
+template <typename R>
+__device__ __forceinline__ void t2_st(R* ubase, unsigned boff, R v) {
+  *reinterpret_cast<R*>(reinterpret_cast<char*>(ubase) + boff) = v;
 }
 
 // row q of a packed table word (four byte entries: the rows 4 ks + q, q = 0..3, of one k-step)
 __device__ __forceinline__ int t2_row(uint32_t word, int q) { return (int)((word >> (8 * q)) & 0xffu); }
 
-template <int P, int KIND, int MODE, int SYM, int GHOST, int TP = 0>
+template <int P, int KIND, int MODE, int SYM, int GHOST, int TP = 0, typename R = double>
 __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2Const C) {
-  using G = TG<P, TP>;
+  using G = TG<P, TP, R>;
+  typedef typename T2V<R>::v4 v4;
+  constexpr unsigned EBY = sizeof(R), LB = 16 * sizeof(R);   // bytes per value / per 16-cell line
   constexpr int ND = G::ND, NF = G::NF, KS = G::KS, KSF = G::KSF, S4 = G::S4, RT = G::RT;
   constexpr int NFC = G::NFACES, NCLS = G::NCLS;
   constexpr bool LARGE = G::LARGE;
@@ -88,9 +104,9 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, w = lane & 15;
-  const double* __restrict__ in = A.in;
-  const double* aux = A.aux;
-  double* out = A.out;
+  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
+  const R* aux = reinterpret_cast<const R*>(A.aux);
+  R* out = reinterpret_cast<R*>(A.out);
 
   const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (stages.cpp)
   const int nitems = listed ? A.nlist : C.ngroups * NCLS;
@@ -106,22 +122,22 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   const T2Class& K = C.cls[k];
 
   // ---- operator fragments: registers, once per wave -----------------------------------------
-  double Av[G::NFRAG_V], Al[G::NFRAG_L];
+  R Av[G::NFRAG_V], Al[G::NFRAG_L];
 #pragma unroll
-  for (int j = 0; j < G::NFRAG_V; ++j) Av[j] = A.fragV[j * 64 + lane];
+  for (int j = 0; j < G::NFRAG_V; ++j) Av[j] = reinterpret_cast<const R*>(A.fragV)[j * 64 + lane];
 #pragma unroll
-  for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = A.fragL[j * 64 + lane];
+  for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = reinterpret_cast<const R*>(A.fragL)[j * 64 + lane];
 
   // ---- class constants: one batch of scalar loads from the kernarg segment at an offset that depends on k only
-  double Jv[2][2], cnv[NFC][2];
+  R Jv[2][2], cnv[NFC][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) Jv[r][j] = K.Jinv[r][j];
+    for (int j = 0; j < 2; ++j) Jv[r][j] = (R)K.Jinv[r][j];
 #pragma unroll
   for (int f = 0; f < NFC; ++f)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) cnv[f][j] = K.cn[f][j];
+    for (int j = 0; j < 2; ++j) cnv[f][j] = (R)K.cn[f][j];
   int f_axis[NFC], f_dir[NFC], f_kn[NFC], f_ord[NFC];
   uint32_t f_tf[NFC][KSF], f_tg[NFC][KSF];
 #pragma unroll
@@ -165,25 +181,25 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       active = valid && inbox;
       if (!__any(active)) continue;
     }
-    const double* ownb = in + ((long)item * ND) * NC * 16;   // wave-uniform
+    const R* ownb = in + ((long)item * ND) * NC * 16;   // wave-uniform
     const int e = (int)cl * NCLS + k;  // cell index in the host numbering
     // G: does this item hold source nodes?  (a scalar load that is consumed only in the epilogue)
     const int sslot_src = (KIND == 1 && A.src_slot != nullptr) ? A.src_slot[item] : -1;
 
     // ---- own rows: requested first.  B row of this lane at k-step ks = node 4 ks + q; rows past ND meet
     //      all-zero operator columns, so any finite value will do: clamp to node 0
-    double ub[KS][NC];
+    R ub[KS][NC];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const unsigned orow = (unsigned)((((4 * ks + q < ND) ? 4 * ks + q : 0) * NC * 16 + w) * 8);
+      const unsigned orow = (unsigned)((((4 * ks + q < ND) ? 4 * ks + q : 0) * NC * 16 + w) * EBY);
       if (KIND == 0) {
-        ub[ks][0] = t2_ld(ownb, orow + 0 * 128);
-        ub[ks][1] = t2_ld(ownb, orow + 1 * 128);
-        ub[ks][3] = t2_ld(ownb, orow + 3 * 128);
-        ub[ks][2] = SYM ? ub[ks][1] : t2_ld(ownb, orow + 2 * 128);
+        ub[ks][0] = t2_ld(ownb, orow + 0 * LB);
+        ub[ks][1] = t2_ld(ownb, orow + 1 * LB);
+        ub[ks][3] = t2_ld(ownb, orow + 3 * LB);
+        ub[ks][2] = SYM ? ub[ks][1] : t2_ld(ownb, orow + 2 * LB);
       } else {
         ub[ks][0] = t2_ld(ownb, orow);
-        ub[ks][1] = t2_ld(ownb, orow + 128);
+        ub[ks][1] = t2_ld(ownb, orow + LB);
       }
     }
 
@@ -192,28 +208,28 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
     //      they are small and non-negative.  GHOST = 1 lanes may read a packed remote trace instead:
     //      a lane pointer then.
     const int g0 = (g > C.gpr) ? g - C.gpr : 0;
-    const double* nbb = in + ((long)g0 * NCLS * ND) * NC * 16;  // wave-uniform
-    double tn[NFC][KSF][NC];
-    double wf[NFC];
+    const R* nbb = in + ((long)g0 * NCLS * ND) * NC * 16;  // wave-uniform
+    R tn[NFC][KSF][NC];
+    R wf[NFC];
 #pragma unroll
     for (int f = 0; f < NFC; ++f) {
       const int axis = f_axis[f], kn = f_kn[f], dir = f_dir[f];
       unsigned noff;  // bytes from nbb to the neighbour cell (component 0 of node 0, this lane's column)
-      const double* gp = nullptr;
+      const R* gp = nullptr;
       bool ghost = false, physical = false;
       if (axis < 0) {
-        noff = (unsigned)(((((g - g0) * NCLS + kn) * ND) * NC * 16 + w) * 8);
+        noff = (unsigned)(((((g - g0) * NCLS + kn) * ND) * NC * 16 + w) * EBY);
       } else {
         const int cn = cc[axis] + dir;
         const bool inside = cn >= 0 && cn < (axis == 0 ? n0 : n1);
         const int nc = inside ? (int)cl + dir * (axis == 0 ? 1 : n0) : (int)cl;
-        noff = (unsigned)((((((nc >> 4) - g0) * NCLS + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15)) * 8);
+        noff = (unsigned)((((((nc >> 4) - g0) * NCLS + (inside ? kn : k)) * ND) * NC * 16 + (nc & 15)) * EBY);
         physical = !inside;
         if (GHOST) {
           const int side = 2 * axis + (dir > 0 ? 1 : 0);
           if (!inside && C.has_nbr[side]) {
             const long slot2 = (long)(axis == 0 ? cc[1] : cc[0]) * C.halo_per_cube + f_ord[f];
-            gp = A.ghost[side] + slot2 * NF * 2;  // packed trace: 2 comps per facet node (velocity, or T_i,axis)
+            gp = reinterpret_cast<const R*>(A.ghost[side]) + slot2 * NF * 2;  // packed trace: 2 comps per facet node (velocity, or T_i,axis)
             ghost = true;
             physical = false;
           }
@@ -221,20 +237,20 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       }
       // F: +1/2 neighbour flux inside, -1/2 own flux on the boundary (cancels the folded half: T.n = 0);
       // G: 1/2 of the neighbour, or the missing 1/2 of the own trace; the 1/2 is part of the lift tiles
-      wf[f] = (KIND == 0 && physical) ? -1.0 : 1.0;
+      wf[f] = (KIND == 0 && physical) ? (R)-1 : (R)1;
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
         // facet-trace row: the neighbour's node inside the block's field, the own node on the domain
         // boundary, the position in the neighbour's facet list in a packed remote trace
-        const unsigned roff = noff + (unsigned)(t2_row(physical ? C.tpw[f][ks] : f_tf[f][ks], q) * NC * 128);
+        const unsigned roff = noff + (unsigned)(t2_row(physical ? C.tpw[f][ks] : f_tf[f][ks], q) * NC * LB);
         const int grow = GHOST ? t2_row(f_tg[f][ks], q) * 2 : 0;
-        const double* fp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(nbb) + roff);
+        const R* fp = reinterpret_cast<const R*>(reinterpret_cast<const char*>(nbb) + roff);
         if (KIND == 0) {
           // a packed remote trace holds g_i = T_i,axis only; the columns j != axis meet (c n)_j = 0 there,
           // so any finite value serves: pairs (i <= j): axis 0 -> g_j, axis 1 -> g_i; full tensor: g_i
           auto at = [&](int i, int j) {
             const int cidx = (SYM && i > j) ? j * 2 + i : i * 2 + j;
-            if (!GHOST) return t2_ld(nbb, roff + cidx * 128);
+            if (!GHOST) return t2_ld(nbb, roff + cidx * LB);
             const int og = SYM ? (axis == 0 ? j : i) : i;
             return ghost ? gp[grow + og] : fp[cidx * 16];
           };
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         } else {
           if (!GHOST) {
             tn[f][ks][0] = t2_ld(nbb, roff);
-            tn[f][ks][1] = t2_ld(nbb, roff + 128);
+            tn[f][ks][1] = t2_ld(nbb, roff + LB);
           } else {
             tn[f][ks][0] = ghost ? gp[grow] : fp[0];
             tn[f][ks][1] = ghost ? gp[grow + 1] : fp[16];
@@ -257,31 +273,31 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
     if (KIND == 0) {
       // ---- F ---------------------------------------------------------------------------------
       const long ubase = ((long)item * ND) * 2 * 16;
-      double* outb = out + ubase;            // wave-uniform
-      const double* auxb = aux + ubase;
+      R* outb = out + ubase;            // wave-uniform
+      const R* auxb = aux + ubase;
       int sslot = -1;
       if (A.sponge_slot != nullptr && active) sslot = A.sponge_slot[e];
-      double cs = A.c_self, ca = A.c_aux, cnw = A.c_new;
+      R cs = (R)A.c_self, ca = (R)A.c_aux, cnw = (R)A.c_new;
       if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
-        const double r0 = A.rho2[2 * e], r1 = A.rho2[2 * e + 1];
+        const R r0 = (R)A.rho2[2 * e], r1 = (R)A.rho2[2 * e + 1];
         cs = r0;
         ca *= r1;
         cnw *= r1;
       }
       // in-place combine operands, requested before the arithmetic
-      double po[S4][2], pa[S4][2];
+      R po[S4][2], pa[S4][2];
       if (MODE == 1) {
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
-          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 2 * 16 + w) * 8);
+          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 2 * 16 + w) * EBY);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            po[m][i] = t2_ld(outb, ro + i * 128);
-            pa[m][i] = t2_ld(auxb, ro + i * 128);
+            po[m][i] = t2_ld(outb, ro + i * LB);
+            pa[m][i] = t2_ld(auxb, ro + i * LB);
           }
         }
       }
-      t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
+      v4 acc[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
       // volume: B = T~_ir = Jinv_rj T_ij (the fragments hold -E_r)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const double tt = Jv[r][0] * ub[ks][i * 2 + 0] + Jv[r][1] * ub[ks][i * 2 + 1];
+            const R tt = Jv[r][0] * ub[ks][i * 2 + 0] + Jv[r][1] * ub[ks][i * 2 + 1];
             t2_mma<LARGE, S4>(&Av[(r * KS + ks) * RT], tt, acc[i]);
           }
       // lifts of w_f (c n)_j T(nbr)_ij
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const double fl = wf[f] * (cnv[f][0] * tn[f][ks][i * 2 + 0] + cnv[f][1] * tn[f][ks][i * 2 + 1]);
+            const R fl = wf[f] * (cnv[f][0] * tn[f][ks][i * 2 + 0] + cnv[f][1] * tn[f][ks][i * 2 + 1]);
             t2_mma<LARGE, S4>(&Al[(f * KSF + ks) * RT], fl, acc[i]);
           }
       // sponge (elastic.py:207-208): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
@@ -307,23 +323,23 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       // wave runs in program order, so these reads precede the stores below.
       if (__any(sslot >= 0)) {
         if (sslot >= 0) {
-          const double* ua = A.uabs + ubase + w;
-          const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND
-          double s[S4][2];
+          const R* ua = reinterpret_cast<const R*>(A.uabs) + ubase + w;
+          const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND (double in both modes)
+          R s[S4][2];
 #pragma unroll
-          for (int m = 0; m < S4; ++m) s[m][0] = s[m][1] = 0.0;
+          for (int m = 0; m < S4; ++m) s[m][0] = s[m][1] = (R)0;
           // chunks of CH columns: all of a chunk's loads are in flight together (one round trip per chunk)
           constexpr int CH = ND <= 6 ? ND : (ND % 5 == 0 ? 5 : (ND % 4 == 0 ? 4 : 3));
           static_assert(ND % CH == 0, "the sponge column chunks must tile the element's nodes");
 #pragma nounroll
           for (int b0 = 0; b0 < ND; b0 += CH) {
-            double uu[CH][2], bb[S4][CH];
+            R uu[CH][2], bb[S4][CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
               uu[j][0] = ua[((b0 + j) * 2 + 0) * 16];
               uu[j][1] = ua[((b0 + j) * 2 + 1) * 16];
 #pragma unroll
-              for (int m = 0; m < S4; ++m) bb[m][j] = B[((4 * m + q < ND) ? m * 4 * ND : 0) + b0 + j];
+              for (int m = 0; m < S4; ++m) bb[m][j] = (R)B[((4 * m + q < ND) ? m * 4 * ND : 0) + b0 + j];
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j)
@@ -343,41 +359,42 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
       for (int m = 0; m < S4; ++m) {
         const int a = 4 * m + q;
-        const unsigned ro = (unsigned)((a * 2 * 16 + w) * 8);
+        const unsigned ro = (unsigned)((a * 2 * 16 + w) * EBY);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          double v = acc[i][m];
+          R v = acc[i][m];
           if (MODE == 1) v = cs * po[m][i] + ca * pa[m][i] + cnw * v;
-          if (active && a < ND) t2_st(outb, ro + i * 128, v);
+          if (active && a < ND) t2_st(outb, ro + i * LB, v);
         }
       }
     } else {
       // ---- G ---------------------------------------------------------------------------------
-      const double lam = A.per_cell ? A.lam[e] : A.lam0;
-      const double mu = A.per_cell ? A.mu[e] : A.mu0;
+      const R lam = (R)(A.per_cell ? A.lam[e] : A.lam0);
+      const R mu = (R)(A.per_cell ? A.mu[e] : A.mu0);
+      const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
       const long sbase = ((long)item * ND) * 4 * 16;
-      double* outb = out + sbase;            // wave-uniform
-      const double* auxb = aux + sbase;
-      double po[S4][3], pa[S4][3], pl[S4], pal[S4];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
+      R* outb = out + sbase;            // wave-uniform
+      const R* auxb = aux + sbase;
+      R po[S4][3], pa[S4][3], pl[S4], pal[S4];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
       if (MODE == 1) {
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
-          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 4 * 16 + w) * 8);
-          po[m][0] = t2_ld(outb, ro + 0 * 128);
-          po[m][1] = t2_ld(outb, ro + 1 * 128);
-          po[m][2] = t2_ld(outb, ro + 3 * 128);
-          pa[m][0] = t2_ld(auxb, ro + 0 * 128);
-          pa[m][1] = t2_ld(auxb, ro + 1 * 128);
-          pa[m][2] = t2_ld(auxb, ro + 3 * 128);
+          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 4 * 16 + w) * EBY);
+          po[m][0] = t2_ld(outb, ro + 0 * LB);
+          po[m][1] = t2_ld(outb, ro + 1 * LB);
+          po[m][2] = t2_ld(outb, ro + 3 * LB);
+          pa[m][0] = t2_ld(auxb, ro + 0 * LB);
+          pa[m][1] = t2_ld(auxb, ro + 1 * LB);
+          pa[m][2] = t2_ld(auxb, ro + 3 * LB);
           if (!SYM) {
-            pl[m] = t2_ld(outb, ro + 2 * 128);
-            pal[m] = t2_ld(auxb, ro + 2 * 128);
+            pl[m] = t2_ld(outb, ro + 2 * LB);
+            pal[m] = t2_ld(auxb, ro + 2 * LB);
           }
         }
       }
       // W_00, W_11 and W_01 + W_10 per row-quad
-      t2d4 Sd[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}}, So = t2d4{0, 0, 0, 0};
-      auto fold = [&](const double c0, const double c1, const t2d4 (&v)[2]) {
+      v4 Sd[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}}, So = v4{0, 0, 0, 0};
+      auto fold = [&](const R c0, const R c1, const v4 (&v)[2]) {
         // W_ik += c_k v_i
 #pragma unroll
         for (int m = 0; m < S4; ++m) {
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       };
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
+        v4 acc[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       }
 #pragma unroll
       for (int f = 0; f < NFC; ++f) {
-        t2d4 acc[2] = {t2d4{0, 0, 0, 0}, t2d4{0, 0, 0, 0}};
+        v4 acc[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
 #pragma unroll
         for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
@@ -407,30 +424,30 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
       for (int m = 0; m < S4; ++m) {
         const int a = 4 * m + q;
-        const unsigned ro = (unsigned)((a * 4 * 16 + w) * 8);
-        const double tr = lam * (Sd[0][m] + Sd[1][m]);
-        double v00 = 2.0 * mu * Sd[0][m] + tr, v11 = 2.0 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
+        const unsigned ro = (unsigned)((a * 4 * 16 + w) * EBY);
+        const R tr = lam * (Sd[0][m] + Sd[1][m]);
+        R v00 = (R)2 * mu * Sd[0][m] + tr, v11 = (R)2 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
         if (sslot_src >= 0) {  // wave-uniform, a handful of items: + S_ij at the source nodes (elastic.py:217-218)
           const int ix = (a < ND) ? A.src_idx[(sslot_src * ND + a) * 16 + w] : -1;
           if (ix >= 0) {
             const double* sv = A.src_vals + (long)ix * 4;
-            v00 += __dmul_rn(A.src_scale, sv[0]);   // rounded product first: bitwise = a table of the products
-            v01 += __dmul_rn(A.src_scale, sv[1]);
-            v10 += __dmul_rn(A.src_scale, sv[2]);
-            v11 += __dmul_rn(A.src_scale, sv[3]);
+            v00 += (R)__dmul_rn(A.src_scale, sv[0]);   // rounded product first: bitwise = a table of the products
+            v01 += (R)__dmul_rn(A.src_scale, sv[1]);
+            v10 += (R)__dmul_rn(A.src_scale, sv[2]);
+            v11 += (R)__dmul_rn(A.src_scale, sv[3]);
           }
         }
         if (MODE == 1) {
-          v00 = A.c_self * po[m][0] + A.c_aux * pa[m][0] + A.c_new * v00;
-          v11 = A.c_self * po[m][2] + A.c_aux * pa[m][2] + A.c_new * v11;
-          if (!SYM) v10 = A.c_self * pl[m] + A.c_aux * pal[m] + A.c_new * v10;
-          v01 = A.c_self * po[m][1] + A.c_aux * pa[m][1] + A.c_new * v01;
+          v00 = c_self * po[m][0] + c_aux * pa[m][0] + c_new * v00;
+          v11 = c_self * po[m][2] + c_aux * pa[m][2] + c_new * v11;
+          if (!SYM) v10 = c_self * pl[m] + c_aux * pal[m] + c_new * v10;
+          v01 = c_self * po[m][1] + c_aux * pa[m][1] + c_new * v01;
         }
         if (active && a < ND) {
-          t2_st(outb, ro + 0 * 128, v00);
-          t2_st(outb, ro + 1 * 128, v01);
-          if (!SYM) t2_st(outb, ro + 2 * 128, v10);
-          t2_st(outb, ro + 3 * 128, v11);
+          t2_st(outb, ro + 0 * LB, v00);
+          t2_st(outb, ro + 1 * LB, v01);
+          if (!SYM) t2_st(outb, ro + 2 * LB, v10);
+          t2_st(outb, ro + 3 * LB, v11);
         }
       }
     }
@@ -481,7 +498,7 @@ T2Const tile2d_const(const MeshDev& md) {
   return C;
 }
 
-template <int P, int SYM, int GHOST, int TP = 0>
+template <int P, int SYM, int GHOST, int TP = 0, typename R = double>
 static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
   long blocks = (nitems + 3) / 4;
   const long cap = a.grid_blocks > 0 ? a.grid_blocks : 2048;
@@ -490,24 +507,28 @@ static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems
   const dim3 grid((unsigned)blocks), block(256);
   if (kind == 0) {
     if (a.mode == 0)
-      hipLaunchKernelGGL((tile2d_stage<P, 0, 0, SYM, GHOST, TP>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 0, 0, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
     else
-      hipLaunchKernelGGL((tile2d_stage<P, 0, 1, SYM, GHOST, TP>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 0, 1, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
   } else {
     if (a.mode == 0)
-      hipLaunchKernelGGL((tile2d_stage<P, 1, 0, SYM, GHOST, TP>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 1, 0, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
     else
-      hipLaunchKernelGGL((tile2d_stage<P, 1, 1, SYM, GHOST, TP>), grid, block, 0, s, a, c);
+      hipLaunchKernelGGL((tile2d_stage<P, 1, 1, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
   }
   return (int)hipGetLastError();
 }
 
-template <int P, int TP = 0>
-static int launch_t2p(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
+template <int P, int TP, typename R>
+static int launch_t2r(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
   bool ghosts = false;
   for (int sd = 0; sd < 4; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
-  if (a.sym) return ghosts ? launch_t2<P, 1, 1, TP>(kind, a, c, nitems, s) : launch_t2<P, 1, 0, TP>(kind, a, c, nitems, s);
-  return ghosts ? launch_t2<P, 0, 1, TP>(kind, a, c, nitems, s) : launch_t2<P, 0, 0, TP>(kind, a, c, nitems, s);
+  if (a.sym) return ghosts ? launch_t2<P, 1, 1, TP, R>(kind, a, c, nitems, s) : launch_t2<P, 1, 0, TP, R>(kind, a, c, nitems, s);
+  return ghosts ? launch_t2<P, 0, 1, TP, R>(kind, a, c, nitems, s) : launch_t2<P, 0, 0, TP, R>(kind, a, c, nitems, s);
+}
+template <int P, int TP = 0>
+static int launch_t2p(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
+  return a.f32 ? launch_t2r<P, TP, float>(kind, a, c, nitems, s) : launch_t2r<P, TP, double>(kind, a, c, nitems, s);
 }
 
 bool tile2d_supported(int dim, int P) { return dim == 2 && P >= 1 && P <= 4; }

@@ -172,6 +172,33 @@ std::vector<double> tile2d_frags_L(const RefElem& re) {
 }
 
 
+// The same two tables for the float tile kernels: always ONE zero-padded 16-row tile per (operator, k-step), and MFMA
+// row i holds node 4 (i & 3) + (i >> 2) - v_mfma_f32_16x16x4_f32 returns row 4 (lane >> 4) + reg, and the kernels
+// keep "accumulator register m of lane group q = node row 4 m + q" in both precisions.
+static inline int tile2d_row32(int l) { return 4 * (l & 3) + ((l & 15) >> 2); }
+
+std::vector<float> tile2d_frags32_V(const RefElem& re, double sign) {
+  const int ks = (re.nd + 3) / 4;
+  std::vector<float> out((size_t)2 * ks * 64, 0.0f);
+  for (int r = 0; r < 2; ++r)
+    for (int k0 = 0; k0 < ks; ++k0)
+      for (int l = 0; l < 64; ++l)
+        out[((size_t)r * ks + k0) * 64 + l] = (float)(sign * Eval(re, r, tile2d_row32(l), 4 * k0 + (l >> 4)));
+  return out;
+}
+
+std::vector<float> tile2d_frags32_L(const RefElem& re) {
+  const int ksf = (re.nf + 3) / 4;
+  std::vector<float> out((size_t)re.nfaces * ksf * 64, 0.0f);
+  for (int f = 0; f < re.nfaces; ++f)
+    for (int k0 = 0; k0 < ksf; ++k0)
+      for (int l = 0; l < 64; ++l) {
+        const int a = tile2d_row32(l), b = 4 * k0 + (l >> 4);
+        out[((size_t)f * ksf + k0) * 64 + l] = (a < re.nd && b < re.nf) ? (float)(0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b]) : 0.0f;
+      }
+  return out;
+}
+
 MfmaConst mfma_const(const MeshDev& md) {
   MfmaConst c;
   std::memset(&c, 0, sizeof(c));

@@ -68,5 +68,9 @@ std::vector<float> mfma32_frags_L(const RefElem& re);
 // with E_r = D_r - 1/2 (L_0 R_0 - L_{r+1} R_{r+1}) (the fold of mfma_tables.cpp with the 2-D normal scale).
 std::vector<double> tile2d_frags_V(const RefElem& re, double sign);
 std::vector<double> tile2d_frags_L(const RefElem& re);
+// float kernels (sg_config::dtype = 1): one zero-padded 16-row tile per (operator, k-step), rows permuted for the
+// C/D layout of v_mfma_f32_16x16x4_f32 (mfma_tables.cpp)
+std::vector<float> tile2d_frags32_V(const RefElem& re, double sign);
+std::vector<float> tile2d_frags32_L(const RefElem& re);
 
 }  // namespace sg

@@ -11,7 +11,7 @@ class ExplosiveSourceLF4():
 
     def setup(self, Lx=300.0, Ly=150.0, h=2.5, degree=2, solver="explicit", output=False,
               courant_number=0.5, dt=None, source_x=45.0, source_mode="interpolate", source_y=None,
-              quadrilateral=False):
+              quadrilateral=False, dtype="f64"):
         """source_mode: 'interpolate' - the reference's nodal interpolation of the box indicator
         (explosive_source_lf4.py:36-40; its integral depends on the mesh: 2.08 m^2 at h = 2.5, P2);
         'unit_integral' - the same interpolant scaled so that its integral is the box's 1 m^2;
@@ -19,7 +19,7 @@ class ExplosiveSourceLF4():
         with timed_region('mesh generation'):
             mesh = self.generate_mesh(Lx, Ly, h, quadrilateral)
             self.elastic = ElasticLF4.create(mesh, "DG", degree, dimension=2,
-                                             solver=solver, output=output)
+                                             solver=solver, output=output, dtype=dtype)
 
         # Constants (explosive_source_lf4.py:21-23)
         self.elastic.density = 1.0

@@ -1,5 +1,6 @@
 """The FP32 second mode (sg_config.dtype = 1; SURVEY 8b `dtype`, 8d "optional second mode, 32 B per
-DoF-update"): float storage and arithmetic on the 3-D MFMA path (v_mfma_f32_16x16x4_f32).
+DoF-update"): float storage and arithmetic on the 3-D MFMA path and on the 2-D MFMA tile kernels - triangles P1-P4,
+quadrilaterals DQ_1-3 - (v_mfma_f32_16x16x4_f32).
 The reference is FP64 throughout (seigen/elastic.py:442), so this mode is checked against the same
 FP64 oracle with float tolerances, stated here:
 
@@ -97,8 +98,104 @@ def test_fp32_multiblock_equals_single_block_bitwise(gpu, degree, n, grid):
     _multiblock_case(3, degree, n, grid, True, extras=True, dtype="f32")
 
 
-def test_fp32_needs_the_mfma_path(gpu):
+def test_fp32_needs_an_mfma_path(gpu, monkeypatch):
     from seigen_amd import _lib
     from seigen_amd.backend import HipBlock
     with pytest.raises(_lib.SeigenHipError, match="f32"):
+        HipBlock(1, 2, (8,), (0.25,), (0.0,), dtype="f32")                                      # 1-D: lane / generic kernels
+    with pytest.raises(_lib.SeigenHipError, match="f32"):
+        HipBlock(2, 4, (4, 4), (0.25, 0.25), (0.0, 0.0), "quadrilateral", dtype="f32")          # DQ_4: generic kernels
+    monkeypatch.setenv("SEIGEN_HIP_PATH", "generic")
+    with pytest.raises(_lib.SeigenHipError, match="f32"):
         HipBlock(2, 2, (4, 4), (0.25, 0.25), (0.0, 0.0), dtype="f32")
+
+
+CASES_2D = [(1, (9, 7), "left"), (2, (8, 5), "right"), (3, (17, 3), "left"), (4, (6, 6), "left"),
+            (1, (7, 9), "quadrilateral"), (2, (8, 5), "quadrilateral"), (3, (17, 3), "quadrilateral")]
+
+
+@pytest.mark.parametrize("degree,n,diagonal", CASES_2D)
+def test_fp32_2d_operators_and_steps_against_the_fp64_oracle(gpu, degree, n, diagonal):
+    """2-D tile kernels in float: one application of F and G (symmetric and full-tensor storage), and five whole
+    steps with sponge, source, per-cell material and density, against the FP64 oracle at float tolerances."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    L = (1.7, 1.1)
+    h = [L[a] / n[a] for a in range(2)]
+    blk = HipBlock(2, degree, n, h, [0.0, 0.0], diagonal, dtype="f32")
+    m = oracle_mesh(2, n, L, diagonal)
+    E = ElasticOperators(m, degree)
+    T = seeded(blk.field_shape(_lib.FIELD_S), 0)
+    Ts = 0.5 * (T + np.swapaxes(T, -1, -2))
+    u = seeded(blk.field_shape(_lib.FIELD_U), 1)
+    blk.set_params(1.0, 0.01, 0.7, 0.3)
+    blk.set_field(_lib.FIELD_S, Ts)
+    blk.set_field(_lib.FIELD_U, u)
+    assert blk.is_sym()
+    assert rel_err(blk.get_field(_lib.FIELD_S), Ts.astype(np.float32).astype(np.float64)) == 0.0
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    assert rel_err(blk.get_field(_lib.FIELD_UH), E.apply_F(Ts, u)) < 2e-5
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, 0.7, 0.3)) < 2e-5
+    blk.set_field(_lib.FIELD_S, T)
+    assert not blk.is_sym()
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    assert rel_err(blk.get_field(_lib.FIELD_UH), E.apply_F(T, u)) < 2e-5
+    blk.close()
+    # whole steps with every extra
+    blk = HipBlock(2, degree, n, h, [0.0, 0.0], diagonal, dtype="f32")
+    orc = OracleLF4(m, degree)
+    nc, nd = m.ncells, blk.nd
+    rng = np.random.default_rng(8)
+    lam, mu, rho = rng.uniform(0.4, 0.8, nc), rng.uniform(0.2, 0.4, nc), rng.uniform(0.8, 1.5, nc)
+    orc.dt, orc.l, orc.mu = 0.03 * min(h) / degree ** 2, lam, mu
+    orc.density, orc.density_physical = rho, True
+    nq = 25 if diagonal == "quadrilateral" else 15
+    sigma = np.where(rng.uniform(size=(nc, nq)) > 0.6, 5.0, 0.0)
+    orc.E.set_absorption(sigma, 4)
+    nodes = np.unique(rng.integers(0, nc * nd, size=12))
+    vals = rng.uniform(-1, 1, (5, len(nodes), 2, 2))
+    vals = 0.5 * (vals + np.swapaxes(vals, -1, -2))
+
+    def source(k):
+        S = np.zeros((nc * nd, 2, 2))
+        S[nodes] = vals[k]
+        return S.reshape(nc, nd, 2, 2)
+
+    orc.u0, orc.s0 = u.copy(), Ts.copy()
+    blk.set_params(1.0, orc.dt, lam, mu)
+    blk.set_density(rho, physical=True)
+    blk.set_absorption(sigma, 4)
+    blk.set_source(nodes, vals)
+    blk.set_field(_lib.FIELD_U, u)
+    blk.set_field(_lib.FIELD_S, Ts)
+    blk.step(5)
+    for k in range(5):
+        orc.source = lambda t, k=k: source(k)
+        orc.step((k + 1) * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 5e-5
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 5e-5
+
+
+@pytest.mark.parametrize("degree,n,grid,diagonal", [(3, (72, 6), (2, 2), "left"), (2, (8, 6), (2, 2), "quadrilateral")])
+def test_fp32_2d_multiblock_equals_single_block_bitwise(gpu, degree, n, grid, diagonal):
+    from tests.test_harness_gpu import _multiblock_case
+    _multiblock_case(2, degree, n, grid, True, extras=True, dtype="f32", diagonal=diagonal)
+
+
+def test_fp32_2d_eigenmode_error_close_to_fp64(gpu):
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    import seigen_amd.harness.eigenmode as he
+    helpers.log = seigen_amd.elastic.log = he.log = lambda s: None
+    N, P = 8, 2
+    dt = 0.5 * (1.0 / N) / 2 ** (P - 1)
+    for quad in (False, True):
+        errs = {}
+        for dtype in ("f64", "f32"):
+            em = he.Eigenmode2DLF4(N, P, dt, output=False, quadrilateral=quad)
+            em.elastic = seigen_amd.ElasticLF4.create(em.mesh, "DG", P, dimension=2, solver="explicit", output=False, dtype=dtype)
+            em.elastic.density, em.elastic.dt, em.elastic.mu, em.elastic.l = 1.0, dt, 0.25, 0.5
+            u1, s1 = em.eigenmode2d(T=5.0)
+            errs[dtype] = em.eigenmode_error(u1, s1)
+        assert abs(errs["f32"][0] - errs["f64"][0]) < 2e-5 and abs(errs["f32"][1] - errs["f64"][1]) < 2e-5, (quad, errs)

@@ -64,14 +64,17 @@ def timed(elastic, steps, warmup):
                 value=dofs * steps / (dev_ms * 1e-3) / 1e6, finite=bool(np.isfinite(u).all()))
 
 
-def config2(steps, warmup, n=512, quadrilateral=False):
+def config2(steps, warmup, n=512, quadrilateral=False, dtype="f64"):
     h = 2.5
     ex = ExplosiveSourceLF4()
     # Courant number 0.05 (default of the reference's tiling harness, tests/tiling/utils.py:51-52):
     # the 0.5 of explosive_source_lf4.py:31 is unstable with the explicit sponge
-    el = ex.setup(Lx=n * h, Ly=n * h, h=h, degree=2, courant_number=0.05, quadrilateral=quadrilateral)
+    el = ex.setup(Lx=n * h, Ly=n * h, h=h, degree=2, courant_number=0.05, quadrilateral=quadrilateral, dtype=dtype)
     r = timed(el, steps, warmup)
     r["config"] = "c2: 2D explosive source %dx%d squares, P2, sponge+source" % (n, n)
+    if dtype == "f32":
+        r["config"] += " [FP32 second mode: 32 B per DoF-update]"
+        r["bytes_per_dof_update"] = 32
     return r
 
 
@@ -149,7 +152,9 @@ if __name__ == "__main__":
     STAGES = args.stages
     for c in args.configs:
         r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share,
-             "c2q": config2_quad}[c](args.steps, args.warmup)
-        r["algorithmic_GBps"] = r["value"] * 1e6 * 64 / 1e9
+             "c2q": config2_quad,
+             "c2f32": lambda st, w: config2(st, w, dtype="f32"),
+             "c2qf32": lambda st, w: config2(st, w, quadrilateral=True, dtype="f32")}[c](args.steps, args.warmup)
+        r["algorithmic_GBps"] = r["value"] * 1e6 * r.get("bytes_per_dof_update", 64) / 1e9
         r["hbm_frac"] = r["algorithmic_GBps"] / 8000.0
         print(json.dumps(r))
