@@ -120,13 +120,31 @@ def probe(path, name, xs):
     pts, data = read_vtu(path)
     xs = np.atleast_2d(np.asarray(xs, dtype=np.float64))
     dim = xs.shape[1]
-    nv = dim + 1
+    import xml.etree.ElementTree as ET
+    piece = ET.parse(path).getroot().find("UnstructuredGrid").find("Piece")
+    types = [da for da in piece.find("Cells").findall("DataArray") if da.get("Name") == "types"][0].text.split()
+    quad = dim == 2 and len(types) > 0 and types[0] == "9"           # VTK_QUAD: vertices counter-clockwise from the low corner
+    nv = 4 if quad else dim + 1
     P = pts[:, :dim].reshape(-1, nv, dim)
     V = data[name].reshape(P.shape[0], nv, -1)
+    out = np.empty((xs.shape[0], V.shape[2]))
+    if quad:
+        # affine quadrilaterals: reference coordinates from the edges 0-1 and 0-3, bilinear interpolation of the corners
+        T = np.stack([P[:, 1, :] - P[:, 0, :], P[:, 3, :] - P[:, 0, :]], axis=2)      # [cells, dim, 2]
+        Tinv = np.linalg.inv(T)
+        for k, x in enumerate(xs):
+            st = np.einsum("cij,cj->ci", Tinv, x[None, :] - P[:, 0, :])
+            inside = (st.min(axis=1) >= -1e-12) & (st.max(axis=1) <= 1.0 + 1e-12)
+            if not inside.any():
+                raise ValueError("point %r is outside the mesh" % (tuple(x),))
+            c = int(np.nonzero(inside)[0][0])
+            a, b = st[c]
+            w = np.array([(1 - a) * (1 - b), a * (1 - b), a * b, (1 - a) * b])
+            out[k] = w @ V[c]
+        return out
     # barycentric coordinates of every query point in every cell
     T = np.transpose(P[:, 1:, :] - P[:, :1, :], (0, 2, 1))          # [cells, dim, dim]
     Tinv = np.linalg.inv(T)
-    out = np.empty((xs.shape[0], V.shape[2]))
     for k, x in enumerate(xs):
         lam = np.einsum("cij,cj->ci", Tinv, x[None, :] - P[:, 0, :])
         lam0 = 1.0 - lam.sum(axis=1)

@@ -167,3 +167,32 @@ def test_function_evaluation_and_integral_on_quadrilaterals():
         v = evaluate_at(f, p)
         np.testing.assert_allclose(v, [p[0] ** 2 * p[1], 1 + p[0] - 2 * p[1] ** 3], atol=1e-13)
     np.testing.assert_allclose(integral(f), [1.0 / 6.0, 1.0], atol=1e-13)
+
+
+def test_vtu_output_of_a_quadrilateral_mesh(tmp_path):
+    """Output path (seigen/elastic.py:221-232) on quadrilateral cells: VTK_QUAD cells with their own four vertices,
+    counter-clockwise; the probe of uy.py:36-43 interpolates bilinearly."""
+    from seigen_amd import Function, UnitSquareMesh, VectorFunctionSpace
+    from seigen_amd.vtu import VtuStream, probe, read_vtu, vertex_nodes
+    mesh = UnitSquareMesh(3, 2, quadrilateral=True)
+    U = VectorFunctionSpace(mesh, "DG", 3)
+    u = Function(U, name="VelocityNew")
+    X = U.node_coords()
+    vals = np.stack([X[..., 0] + 2 * X[..., 1], X[..., 0] * X[..., 1]], axis=-1)      # linear and bilinear
+    u.dat.data = vals.reshape(-1, 2)
+    st = VtuStream("velocity", directory=str(tmp_path))
+    f = st.write(u, 0.25)
+    text = (tmp_path / f).read_text()
+    assert text.count(" 9") >= 6 or "9 9 9 9 9 9" in text
+    pts, data = read_vtu(str(tmp_path / f))
+    vn = vertex_nodes(2, 3, True)
+    assert pts.shape == (6 * 4, 3)
+    np.testing.assert_allclose(pts[:, :2], X[:, vn, :].reshape(-1, 2), atol=1e-15)
+    corners = X[:, vn, :]
+    e1, e2 = corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 1]
+    cross = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    assert (cross > 0).all()                                                         # counter-clockwise
+    xq = np.array([[0.31, 0.47], [0.5, 0.5], [1.0, 1.0], [0.0, 0.9]])
+    got = probe(str(tmp_path / f), "VelocityNew", xq)
+    np.testing.assert_allclose(got[:, 0], xq[:, 0] + 2 * xq[:, 1], atol=1e-13)
+    np.testing.assert_allclose(got[:, 1], xq[:, 0] * xq[:, 1], atol=1e-13)           # bilinear: exact too
