@@ -102,12 +102,16 @@ static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, doub
       HIPCHECK(h, hipMemcpy(host, dev, nb, hipMemcpyDeviceToHost));
     return SG_OK;
   }
-  const size_t cap_cells = std::max<size_t>(1, ((size_t)32 << 20) / per_cell);  // 256 MB staging
+  // The staging buffer is allocated once, by whichever field is moved first: size it for the widest field (stress),
+  // or a velocity-sized buffer of a one-cell block holds no whole cell of a stress field (chunk = 0: no progress).
+  const size_t per_cell_max = (size_t)h->re.nd * h->cfg.dim * h->cfg.dim;
+  const size_t cap_cells = std::max<size_t>(1, ((size_t)32 << 20) / per_cell_max);  // 256 MB staging
   if (!h->staging) {
-    h->staging_len = std::min(cap_cells, (size_t)h->ncells) * per_cell;
+    h->staging_len = std::min(cap_cells, (size_t)h->ncells) * per_cell_max;
     HIPCHECK(h, hipMalloc((void**)&h->staging, h->staging_len * sizeof(double)));
   }
   const size_t chunk = h->staging_len / per_cell;
+  if (chunk == 0) return fail(h, SG_ERR_STATE, "staging buffer smaller than one cell");
   const int comps = (int)(per_cell / h->re.nd);
   for (int64_t done = 0; done < ncells; done += (int64_t)chunk) {
     int64_t n = std::min<int64_t>((int64_t)chunk, ncells - done);

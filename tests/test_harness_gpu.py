@@ -341,7 +341,8 @@ def test_multiblock_random_grids(gpu, seed):
     if int(np.prod(grid)) == 1:
         grid = grid[:-1] + (2,)
     n = tuple(int(g * rng.integers(1, 4) + rng.integers(0, 2)) for g in grid)
-    _multiblock_case(dim, degree, n, grid, bool(seed % 2 == 0), extras=(seed % 3 != 1))
+    diagonal = "quadrilateral" if (dim == 2 and seed % 4 == 3) else "left"
+    _multiblock_case(dim, degree, n, grid, bool(seed % 2 == 0), extras=(seed % 3 != 1), diagonal=diagonal)
 
 
 def test_receiver_traces_full_run_vs_oracle(gpu):

@@ -302,15 +302,16 @@ def test_kernel_families_agree_on_random_blocks(gpu, monkeypatch, seed):
     degree = int(rng.integers(1, 5))
     n = tuple(int(x) for x in (rng.integers(1, 20, size=dim) if dim == 3 else rng.integers(1, 40, size=dim)))
     h = tuple(float(x) for x in rng.uniform(0.2, 1.5, size=dim))
-    diagonal = "right" if (dim == 2 and rng.integers(0, 2)) else "left"
+    diagonal = ("left", "right", "quadrilateral")[int(rng.integers(0, 3))] if dim == 2 else "left"
+    quad = diagonal == "quadrilateral"
     dt = 0.05 * min(h) / degree ** 2
     results = {}
     for path in ("generic", "lane", "mfma", "tile"):
         if path == "mfma" and dim != 3:
             continue
-        if path == "tile" and dim != 2:
+        if path == "tile" and (dim != 2 or (quad and degree == 4)):
             continue
-        if path == "lane" and dim == 3 and degree > 2:
+        if path == "lane" and ((dim == 3 and degree > 2) or quad):
             continue
         monkeypatch.setenv("SEIGEN_HIP_PATH", path)
         blk = HipBlock(dim, degree, n, h, (0.0,) * dim, diagonal)
@@ -319,7 +320,7 @@ def test_kernel_families_agree_on_random_blocks(gpu, monkeypatch, seed):
         mu = r2.uniform(0.2, 0.5, blk.ncells) if seed % 2 else 0.25
         blk.set_params(1.0, dt, lam, mu)
         if seed % 3 == 0:
-            nq = {2: 15, 3: 35}[dim]
+            nq = 25 if quad else {2: 15, 3: 35}[dim]
             blk.set_absorption(np.where(r2.uniform(size=(blk.ncells, nq)) > 0.7, 5.0, 0.0), 4)
         u0 = r2.uniform(-1, 1, blk.field_shape(_lib.FIELD_U))
         s0 = r2.uniform(-1, 1, blk.field_shape(_lib.FIELD_S))

@@ -218,3 +218,22 @@ def test_config2_setup_on_quadrilaterals_full_size_tile_vs_generic(gpu, monkeypa
     assert np.abs(res["tile"][1] - res["generic"][1]).max() < 1e-11 * scale_s
     assert np.abs(res["tile32"][0] - res["generic"][0]).max() < 2e-4 * scale_u
     assert np.abs(res["tile32"][1] - res["generic"][1]).max() < 2e-4 * scale_s
+
+
+def test_one_cell_block_moves_every_field(gpu):
+    """A block of a single quadrilateral: the staging buffer of the interleaved layouts is allocated by the first
+    transfer (a velocity field here) and must still hold a cell of the stress field (it was sized by the first field:
+    sg_set_field of the stress then made no progress)."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    for P in (1, 2, 3):
+        blk = HipBlock(2, P, (1, 1), [1.0, 1.0], [0.0, 0.0], "quadrilateral")
+        u = seeded(blk.field_shape(_lib.FIELD_U), 1)
+        s = seeded(blk.field_shape(_lib.FIELD_S), 2)
+        blk.set_field(_lib.FIELD_U, u)
+        blk.set_field(_lib.FIELD_S, s)
+        assert np.array_equal(blk.get_field(_lib.FIELD_U), u) and np.array_equal(blk.get_field(_lib.FIELD_S), s)
+        blk.set_params(1.0, 1e-3, 0.5, 0.25)
+        blk.step(2)
+        assert np.isfinite(blk.get_field(_lib.FIELD_S)).all()
+        blk.close()
