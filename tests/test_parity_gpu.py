@@ -398,3 +398,56 @@ def test_random_cases_against_the_oracle(gpu, seed):
     tol = 20 * tol_of(degree, diagonal)
     assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < tol, (dim, degree, n, diagonal)
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < tol, (dim, degree, n, diagonal)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEIGEN_TEST_TRANSFER_FUZZ", "6"))))
+def test_random_field_ranges_round_trip(gpu, monkeypatch, seed):
+    """Transfer fuzz: random block, kernel family (i.e. device layout: host order, 16- or 64-cell interleaved), FP64 or
+    float storage, symmetric or full stress; whole fields and random cell ranges written and read back in any order
+    must agree with a host-side copy (float mode: with what float holds)."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(9000 + seed)
+    dim = int(rng.integers(1, 4))
+    degree = int(rng.integers(1, 5))
+    n = tuple(int(x) for x in rng.integers(1, {1: 40, 2: 24, 3: 7}[dim], size=dim))
+    diagonal = ("left", "right", "quadrilateral")[int(rng.integers(0, 3))] if dim == 2 else "left"
+    path = ("", "generic", "lane")[int(rng.integers(0, 3))]
+    quad = diagonal == "quadrilateral"
+    if path == "lane" and (quad or (dim == 3 and degree > 2)):
+        path = ""
+    if path:
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+    f32_ok = not path and ((dim == 3 and degree >= 2) or (dim == 2 and not (quad and degree == 4)))
+    dtype = "f32" if (f32_ok and rng.integers(0, 2)) else "f64"
+    blk = HipBlock(dim, degree, n, [0.5] * dim, [0.0] * dim, diagonal, dtype=dtype)
+    hold = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype == "f32" else (lambda a: a)
+    host = {}
+    for field in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH):
+        host[field] = np.zeros(blk.field_shape(field))
+    order = [int(f) for f in rng.permutation(4)]
+    for it in range(10):
+        field = order[it % 4]
+        shape = blk.field_shape(field)
+        if rng.integers(0, 3) == 0:
+            a = rng.uniform(-1, 1, shape)
+            if field in (_lib.FIELD_S, _lib.FIELD_SH) and rng.integers(0, 2):
+                a = 0.5 * (a + np.swapaxes(a, -1, -2))
+            blk.set_field(field, a)
+            host[field] = hold(a)
+        else:
+            c0 = int(rng.integers(0, blk.ncells))
+            nc = int(rng.integers(1, blk.ncells - c0 + 1))
+            a = rng.uniform(-1, 1, (nc,) + shape[1:])
+            if field in (_lib.FIELD_S, _lib.FIELD_SH) and rng.integers(0, 2):
+                a = 0.5 * (a + np.swapaxes(a, -1, -2))
+            blk.set_field_range(field, c0, a)
+            host[field][c0:c0 + nc] = hold(a)
+        f2 = int(rng.integers(0, 4))
+        if rng.integers(0, 2):
+            assert np.array_equal(blk.get_field(f2), host[f2]), (dim, degree, n, diagonal, path, dtype, it)
+        else:
+            c0 = int(rng.integers(0, blk.ncells))
+            nc = int(rng.integers(1, blk.ncells - c0 + 1))
+            assert np.array_equal(blk.get_field_range(f2, c0, nc), host[f2][c0:c0 + nc]), (dim, degree, n, diagonal, path, dtype, it)
+    blk.close()
