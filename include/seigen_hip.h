@@ -174,14 +174,16 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
  * (k = 0 .. nsteps-1 counted from this call; no source afterwards).  This is the
  * re-interpolated `source_function` of elastic.py:285-288 restricted to its
  * support.  nsteps = -1: a time-independent source, values[0][i][dim*dim] holds at
- * every step.  nnz = 0 disables. */
+ * every step.  nnz = 0 disables.  A node listed more than once receives the SUM of its
+ * entries (added up in the order listed, once, on the host: deterministic). */
 int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nsteps, const double* values);
 /* The same for a SEPARABLE source S_ij(node, step k) = weights[k] * pattern[node][dim*dim] - what every source of
  * the reference's tests is (the indicator of a box times a Ricker wavelet re-interpolated at every step,
  * tests/explosive_source/explosive_source_lf4.py:36-40 with elastic.py:285-288): one slice of nodal values and
  * one factor per step (k = 0 .. nsteps-1 counted from this call; no source afterwards) instead of a table of
  * nsteps * nnz * dim^2 values.  The product weights[k] * pattern is rounded before it is added, so the result is
- * bitwise what sg_set_source gives for the table of those products. */
+ * bitwise what sg_set_source gives for the table of those products (node lists without repeated nodes; the entries
+ * of a repeated node are summed first, here of the pattern, there of the products). */
 int sg_set_source_separable(sg_handle* h, int64_t nnz, const int64_t* nodes, const double* pattern, int64_t nsteps,
                             const double* weights);
 /* The reference's explosive source itself, from its parameters (tests/explosive_source/explosive_source_lf4.py:36-40):

@@ -591,6 +591,34 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   int64_t nscalar = h->ncells * h->re.nd;
   for (int64_t k = 0; k < nnz; ++k)
     if (nodes[k] < 0 || nodes[k] >= nscalar) return fail(h, SG_ERR_ARG, "sg_set_source: node index out of range");
+  // A node listed more than once: its entries add up (in the order listed), merged here once so that every node is
+  // written by one thread - the sum is then the same on every run and on every partition of the mesh (an atomic add
+  // per entry gave the right sum in an arbitrary order, i.e. results that differed in the last bit from run to run).
+  std::vector<int64_t> merged_nodes;
+  std::vector<double> merged_values;
+  {
+    std::unordered_map<int64_t, int64_t> slot_of;
+    slot_of.reserve((size_t)nnz * 2);
+    std::vector<int64_t> to((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+      auto it = slot_of.find(nodes[k]);
+      if (it == slot_of.end()) {
+        it = slot_of.emplace(nodes[k], (int64_t)merged_nodes.size()).first;
+        merged_nodes.push_back(nodes[k]);
+      }
+      to[(size_t)k] = it->second;
+    }
+    if ((int64_t)merged_nodes.size() != nnz) {
+      const int64_t nm = (int64_t)merged_nodes.size(), dd = (int64_t)d * d;
+      merged_values.assign((size_t)(nsteps * nm * dd), 0.0);
+      for (int64_t s = 0; s < nsteps; ++s)
+        for (int64_t k = 0; k < nnz; ++k)
+          for (int64_t c = 0; c < dd; ++c) merged_values[(size_t)((s * nm + to[(size_t)k]) * dd + c)] += values[(s * nnz + k) * dd + c];
+      nodes = merged_nodes.data();
+      values = merged_values.data();
+      nnz = nm;
+    }
+  }
   if (h->sym) {
     bool symmetric = true;
     for (int64_t i = 0; i < nsteps * nnz && symmetric; ++i)
@@ -643,8 +671,8 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
   HIPCHECK(h, hipMemcpy(h->src_values, vals.data(), vbytes, hipMemcpyHostToDevice));
   if (h->use_tile && !std::getenv("SEIGEN_HIP_SOURCE_LAUNCH")) {
     // tile kernels: item (16 squares of one class) -> slot, and per slot a dense (node, cell) -> value-row table, so
-    // that the G stages add the source themselves (one launch less per G stage).  A node listed twice keeps the
-    // separate launch (which adds both entries).
+    // that the G stages add the source themselves (one launch less per G stage).  (Nodes are unique here: entries of a
+    // node listed twice were merged above.)
     const int64_t nd = h->re.nd, ncl = h->ncls, nitems = h->md.ncube_pad / 16 * ncl;
     std::vector<int32_t> slot((size_t)nitems, -1), idx;
     bool dup = false;

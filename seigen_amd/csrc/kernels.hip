@@ -454,8 +454,9 @@ __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64
   if (idx >= nnz * ncomp) return;
   long k = idx / ncomp;
   int c = (int)(idx - k * ncomp);
-  // a node may be listed more than once (its entries add up): atomic, the table is tiny
-  atomicAdd(&field[offs[k] + (long)c * gw], (T)(coef * __dmul_rn(scale, values[idx])));
+  // every node appears once (sg_set_source merges the entries of a node listed twice): a plain read-modify-write
+  T* p = &field[offs[k] + (long)c * gw];
+  *p = *p + (T)(coef * sg_mul_rounded(scale, values[idx]));
 }
 
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,

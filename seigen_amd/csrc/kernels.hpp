@@ -48,6 +48,21 @@ MfmaConst mfma_const(const MeshDev& md_host);
 // [item = cell group * 6 + class][lane 0..15][facet 0..3] (see StageArgs::nbr_tab); (ncube_pad / 16) * 6 * 64 entries
 void build_nbr_table(const MeshDev& md_host, std::vector<int32_t>& tab);
 
+// scale * value rounded to double BEFORE anything is added to it: a separable source (weight x pattern) then gives
+// bit for bit what a table of the products gives.  (HIP's __dmul_rn is a plain `x * y`, which hipcc contracts with
+// a following add into one FMA; an instruction the optimiser cannot see into is not contracted.)
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__ double sg_mul_rounded(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double p;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+  return p;
+#else
+  return a * b;   // host pass of the compiler only; never executed
+#endif
+}
+#endif
+
 struct StageArgs {
   const double* in;    // stress for F, velocity for G           [cell][node][comp]
   double* out;         // result, or in-place target of a fused combine

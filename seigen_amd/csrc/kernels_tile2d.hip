@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const unsigned orow = (unsigned)((((4 * ks + q < ND) ? 4 * ks + q : 0) * NC * 16 + w) * EBY);
-      if (KIND == 0) {
+      if constexpr (KIND == 0) {
         ub[ks][0] = t2_ld(ownb, orow + 0 * LB);
         ub[ks][1] = t2_ld(ownb, orow + 1 * LB);
         ub[ks][3] = t2_ld(ownb, orow + 3 * LB);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         const unsigned roff = noff + (unsigned)(t2_row(physical ? C.tpw[f][ks] : f_tf[f][ks], q) * NC * LB);
         const int grow = GHOST ? t2_row(f_tg[f][ks], q) * 2 : 0;
         const R* fp = reinterpret_cast<const R*>(reinterpret_cast<const char*>(nbb) + roff);
-        if (KIND == 0) {
+        if constexpr (KIND == 0) {
           // a packed remote trace holds g_i = T_i,axis only; the columns j != axis meet (c n)_j = 0 there,
           // so any finite value serves: pairs (i <= j): axis 0 -> g_j, axis 1 -> g_i; full tensor: g_i
           auto at = [&](int i, int j) {
@@ -431,10 +431,10 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           const int ix = (a < ND) ? A.src_idx[(sslot_src * ND + a) * 16 + w] : -1;
           if (ix >= 0) {
             const double* sv = A.src_vals + (long)ix * 4;
-            v00 += (R)__dmul_rn(A.src_scale, sv[0]);   // rounded product first: bitwise = a table of the products
-            v01 += (R)__dmul_rn(A.src_scale, sv[1]);
-            v10 += (R)__dmul_rn(A.src_scale, sv[2]);
-            v11 += (R)__dmul_rn(A.src_scale, sv[3]);
+            v00 += (R)sg_mul_rounded(A.src_scale, sv[0]);   // rounded product first: bitwise = a table of the products
+            v01 += (R)sg_mul_rounded(A.src_scale, sv[1]);
+            v10 += (R)sg_mul_rounded(A.src_scale, sv[2]);
+            v11 += (R)sg_mul_rounded(A.src_scale, sv[3]);
           }
         }
         if (MODE == 1) {

@@ -451,3 +451,59 @@ def test_random_field_ranges_round_trip(gpu, monkeypatch, seed):
             nc = int(rng.integers(1, blk.ncells - c0 + 1))
             assert np.array_equal(blk.get_field_range(f2, c0, nc), host[f2][c0:c0 + nc]), (dim, degree, n, diagonal, path, dtype, it)
     blk.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEIGEN_TEST_SOURCE_FUZZ", "6"))))
+def test_random_sources_agree_across_kernel_families(gpu, monkeypatch, seed):
+    """Source fuzz: a random node list (possibly with a node listed twice - both entries count -, possibly all in one
+    cell), as a table per step, one static slice, or a separable pattern x weights; shorter than, equal to or longer
+    than the run; symmetric or not.  The default kernel family (fused source on the 2-D tile path, source launches
+    elsewhere) against the generic kernels, and the separable form against its table."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(11000 + seed)
+    dim = int(rng.integers(1, 4))
+    degree = int(rng.integers(1, 5))
+    n = tuple(int(x) for x in rng.integers(1, {1: 30, 2: 20, 3: 6}[dim], size=dim))
+    diagonal = ("left", "right", "quadrilateral")[int(rng.integers(0, 3))] if dim == 2 else "left"
+    nrun = int(rng.integers(2, 7))
+    results = {}
+    for variant in ("generic", "default", "default-separable"):
+        monkeypatch.setenv("SEIGEN_HIP_PATH", "generic" if variant == "generic" else "")
+        if variant != "generic":
+            monkeypatch.delenv("SEIGEN_HIP_PATH")
+        blk = HipBlock(dim, degree, n, [0.7] * dim, [0.0] * dim, diagonal)
+        r2 = np.random.default_rng(12000 + seed)
+        nn = blk.ncells * blk.nd
+        k = int(r2.integers(1, min(12, nn) + 1))
+        nodes = r2.integers(0, nn, size=k) if r2.integers(0, 2) else r2.integers(0, min(nn, blk.nd), size=k)
+        if r2.integers(0, 3):
+            nodes = np.unique(nodes)                       # otherwise duplicates may stay in
+        mode = ("table", "static", "separable")[int(r2.integers(0, 3))]
+        nsrc = int(r2.integers(1, nrun + 3))
+        pat = r2.uniform(-1, 1, (len(nodes), dim, dim))
+        if r2.integers(0, 2):
+            pat = 0.5 * (pat + np.swapaxes(pat, -1, -2))
+        w = r2.uniform(-2, 2, nsrc)
+        blk.set_params(1.0, 0.01, 0.5, 0.25)
+        blk.set_field(_lib.FIELD_U, r2.uniform(-1, 1, blk.field_shape(_lib.FIELD_U)))
+        if mode == "static":
+            blk.set_source(nodes, pat[None], static=True)
+        elif mode == "separable" and variant == "default-separable":
+            blk.set_source_separable(nodes, pat, w)
+        else:
+            table = w[:, None, None, None] * pat[None] if mode == "separable" else r2.uniform(-1, 1, (nsrc, len(nodes), dim, dim))
+            blk.set_source(nodes, table)
+        blk.step(nrun)
+        results[variant] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    ref = results["generic"]
+    assert np.abs(ref[1]).max() > 0
+    for variant in ("default", "default-separable"):
+        assert rel_err(results[variant][0], ref[0]) < 1e-11 and rel_err(results[variant][1], ref[1]) < 1e-11, (variant, dim, degree, n, diagonal)
+    # one handle, same calls: bitwise; the separable form against its table of products: bitwise too, unless a node is
+    # listed twice (then the pattern entries are summed before the weight is applied, the table entries after)
+    if len(np.unique(nodes)) == len(nodes) or mode != "separable":
+        assert np.array_equal(results["default"][1], results["default-separable"][1])
+    else:
+        assert rel_err(results["default-separable"][1], results["default"][1]) < 1e-13
