@@ -318,7 +318,9 @@ def test_kernel_families_agree_on_random_blocks(gpu, monkeypatch, seed):
         r2 = np.random.default_rng(2000 + seed)
         lam = r2.uniform(0.4, 0.9, blk.ncells) if seed % 2 else 0.5
         mu = r2.uniform(0.2, 0.5, blk.ncells) if seed % 2 else 0.25
-        blk.set_params(1.0, dt, lam, mu)
+        blk.set_params(1.0 if seed % 5 else 1.3, dt, lam, mu)
+        if seed % 5 in (1, 2):                 # per-cell density, either convention
+            blk.set_density(r2.uniform(0.7, 1.6, blk.ncells), physical=(seed % 5 == 2))
         if seed % 3 == 0:
             nq = 25 if quad else {2: 15, 3: 35}[dim]
             blk.set_absorption(np.where(r2.uniform(size=(blk.ncells, nq)) > 0.7, 5.0, 0.0), 4)
@@ -368,7 +370,7 @@ def test_random_cases_against_the_oracle(gpu, seed):
     if rho_mode:
         blk.set_density(rho, physical=(rho_mode == 2))
     if rng.integers(0, 2):
-        q = int(rng.integers(1, 5))
+        q = int(rng.integers(1, 7))            # sg_set_absorption takes DG_1 .. DG_6
         nq = m.node_coords(q).shape[1]
         sigma = np.where(rng.uniform(size=(nc, nq)) > 0.5, rng.uniform(1.0, 20.0), 0.0)
         orc.E.set_absorption(sigma, q)
