@@ -355,7 +355,7 @@ class ElasticLF4(object):
             nz = np.nonzero(np.abs(vals).reshape(vals.shape[0] * vals.shape[1], -1).max(axis=1) > 0)[0]
             return nz, vals.reshape(-1, d, d)[nz], np.array([float(self.source_time_function(t)) for t in times])
         expr = self.source_expression
-        if expr is None or not hasattr(expr, "_params") or "t" not in expr._params or len(times) < 2:
+        if expr is None or not hasattr(expr, "_params") or "t" not in expr._params or len(times) < 1:
             return None
         t_keep = expr.t
         try:

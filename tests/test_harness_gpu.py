@@ -710,3 +710,93 @@ def test_plain_c_host_through_the_c_abi(gpu, tmp_path, quad):
     u_py = blk.get_field(_lib.FIELD_U)
     assert np.abs(u_py).max() > 0
     assert np.array_equal(u_c, u_py.ravel())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEIGEN_TEST_SOLVER_FUZZ", "6"))))
+def test_solver_class_random_setups_against_the_oracle(gpu, seed):
+    """Host-layer fuzz: the public solver class with a random mesh (interval / triangles / quadrilaterals /
+    tetrahedra), degree, material and density (floats or per-cell arrays, either density convention), Expression
+    initial conditions, an Expression sponge in a DG space of random degree, an Expression source `box ? f(t) : 0`
+    (table or factorised upload), run(T) with the reference's step rule - against the oracle fed with the same
+    Expressions evaluated at its own nodes."""
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    from seigen_amd import (BoxMesh, ElasticLF4, Expression, Function, FunctionSpace, IntervalMesh, RectangleMesh)
+    from tests.util import oracle_mesh
+    helpers.log = seigen_amd.elastic.log = lambda s: None
+    rng = np.random.default_rng(13000 + seed)
+    dim = int(rng.integers(1, 4))
+    P = int(rng.integers(1, 5))
+    n = tuple(int(x) for x in rng.integers(2, {1: 14, 2: 8, 3: 4}[dim], size=dim))
+    L = tuple(float(x) for x in rng.uniform(0.8, 2.2, size=dim))
+    quad = bool(dim == 2 and rng.integers(0, 2))
+    diagonal = "right" if (dim == 2 and not quad and rng.integers(0, 2)) else "left"
+    if dim == 1:
+        mesh, om = IntervalMesh(n[0], L[0]), oracle_mesh(1, n, L)
+    elif dim == 2:
+        mesh = RectangleMesh(n[0], n[1], L[0], L[1], diagonal=diagonal, quadrilateral=quad)
+        om = oracle_mesh(2, n, L, "quadrilateral" if quad else diagonal)
+    else:
+        mesh, om = BoxMesh(n[0], n[1], n[2], L[0], L[1], L[2]), oracle_mesh(3, n, L)
+    solver = ("explicit", "implicit", "tiling")[int(rng.integers(0, 3))]
+    el = ElasticLF4.create(mesh, "DG", P, dimension=dim, solver=solver, output=False)
+    orc = OracleLF4(om, P)
+    nc = om.ncells
+    assert el.U.ncells == nc
+    per_cell = bool(rng.integers(0, 2))
+    el.l = orc.l = rng.uniform(0.4, 0.9, nc) if per_cell else float(rng.uniform(0.4, 0.9))
+    el.mu = orc.mu = rng.uniform(0.2, 0.5, nc) if per_cell else float(rng.uniform(0.2, 0.5))
+    el.density = orc.density = rng.uniform(0.7, 1.5, nc) if rng.integers(0, 2) else float(rng.uniform(0.7, 1.5))
+    if solver == "implicit":
+        orc.density_physical = True                       # the implicit forms' convention (elastic.py:175-178)
+    elif rng.integers(0, 2):
+        el.density_physical = orc.density_physical = True
+    h = min(L[a] / n[a] for a in range(dim))
+    el.dt = orc.dt = 0.03 * h / P ** 2
+    nsteps = int(rng.integers(1, 6))
+    # initial conditions
+    k1, k2 = float(rng.uniform(1, 4)), float(rng.uniform(1, 4))
+    ucode = tuple("sin(%r*x[%d]) + 0.3*cos(%r*x[0])" % (k1 + i, i, k2) for i in range(dim))
+    scode = tuple(tuple("0.2*sin(%r*x[%d])*cos(%r*x[%d])" % (k1 + i + j, i, k2, j) for j in range(dim)) for i in range(dim))
+    uex, sex = Expression(ucode if dim > 1 else ucode[0]), Expression(scode if dim > 1 else scode[0][0])
+    if dim == 1:
+        uex, sex = Expression((ucode[0],)), Expression(((scode[0][0],),))
+    el.u0.assign(Function(el.U).interpolate(uex))
+    el.s0.assign(Function(el.S).interpolate(sex))
+    Xo = om.node_coords(P)
+    orc.u0 = uex.evaluate(Xo).reshape(nc, -1, dim)
+    orc.s0 = sex.evaluate(Xo).reshape(nc, -1, dim, dim)
+    # sponge
+    if rng.integers(0, 2):
+        q = int(rng.integers(1, 5))
+        cut = float(rng.uniform(0.2, 0.8)) * L[0]
+        aex = Expression("x[0] <= %r ? %r : 0.0" % (cut, float(rng.uniform(2.0, 30.0))))
+        el.absorption_function = Function(FunctionSpace(mesh, "DG", q))
+        el.absorption = aex
+        orc.E.set_absorption(aex.evaluate(om.node_coords(q)).reshape(nc, -1), q)
+    # source: indicator of a box (edges away from every node) times a function of t
+    if rng.integers(0, 2):
+        lo = [float(rng.uniform(0.1, 0.4)) * L[a] + 1.2345e-3 for a in range(dim)]
+        hi = [float(rng.uniform(0.6, 0.9)) * L[a] + 2.3456e-3 for a in range(dim)]
+        box = " && ".join("x[%d] >= %r && x[%d] <= %r" % (a, lo[a], a, hi[a]) for a in range(dim))
+        ft = "(1.0 + 0.5*x[0])*sin(%r*t)" % float(rng.uniform(20.0, 200.0))
+        code = "%s ? %s : 0.0" % (box, ft)
+        rows = tuple(tuple(code if i == j else "0.0" for j in range(dim)) for i in range(dim))
+        sx = Expression(rows, t=0)
+        el.source_expression = sx
+        el.source_function = Function(el.S)
+        el.source = el.source_expression
+        if rng.integers(0, 2):
+            el.SOURCE_TABLE_MAX_BYTES = 0                 # force the factorised (separable) upload
+
+        def osource(t, sx=sx):
+            sx.t = t
+            return sx.evaluate(Xo).reshape(nc, -1, dim, dim)
+        orc.source = osource
+    u1, s1 = el.run(nsteps * el.dt * (1 + 1e-9))
+    assert el.block.counters()["steps"] == nsteps
+    for k in range(nsteps):
+        orc.step((k + 1) * orc.dt)
+    tol = 1e-9
+    assert rel_err(u1.dat.data_cells, orc.u1) < tol, (seed, dim, P, n, quad, solver)
+    assert rel_err(s1.dat.data_cells, orc.s1) < tol, (seed, dim, P, n, quad, solver)
