@@ -452,7 +452,8 @@ def test_vtu_stream_round_trip(tmp_path):
         assert sd["StressNew"].shape == (ncells * (dim + 1), 9)
 
 
-@pytest.mark.parametrize("mesh,P", [(UnitSquareMesh(5, 4), 3), (UnitCubeMesh(2, 3, 2), 2), (IntervalMesh(7, 2.0), 4)])
+@pytest.mark.parametrize("mesh,P", [(UnitSquareMesh(5, 4), 3), (UnitCubeMesh(2, 3, 2), 2), (IntervalMesh(7, 2.0), 4),
+                                    (UnitSquareMesh(4, 5, quadrilateral=True), 3)])
 def test_interop_permutation_recovers_a_foreign_numbering(mesh, P):
     """binding from a host with another cell / node order (Firedrake: DMPlex cells, FIAT nodes)
     needs one permutation built from node coordinates; DG nodes coincide where cells touch, so it is built cell

@@ -196,3 +196,46 @@ def test_vtu_output_of_a_quadrilateral_mesh(tmp_path):
     got = probe(str(tmp_path / f), "VelocityNew", xq)
     np.testing.assert_allclose(got[:, 0], xq[:, 0] + 2 * xq[:, 1], atol=1e-13)
     np.testing.assert_allclose(got[:, 1], xq[:, 0] * xq[:, 1], atol=1e-13)           # bilinear: exact too
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_host_layer_point_evaluation_and_norms_on_random_meshes(seed):
+    """Host-layer fuzz without a GPU: point location and evaluation of an interpolated polynomial at random points
+    (cell edges and corners included) on triangles, quadrilaterals and tetrahedra; norm() and the projected-abs error
+    functional of eigenmode_2d.py:49-63 against the oracle's on a random field."""
+    from oracle.harness import l2_norm, projected_abs_norm
+    from seigen_amd import BoxMesh, Function, RectangleMesh, VectorFunctionSpace
+    from seigen_amd.expression import Expression
+    from seigen_amd.functionspace import evaluate_at
+    from seigen_amd.norms import norm, projected_abs_error_norm
+    rng = np.random.default_rng(seed)
+    dim = 2 if seed % 3 else 3
+    quad = dim == 2 and seed % 2 == 0
+    P = int(rng.integers(1, 5))
+    n = tuple(int(x) for x in rng.integers(1, 6 if dim == 2 else 4, size=dim))
+    L = tuple(float(x) for x in rng.uniform(0.5, 2.0, size=dim))
+    if dim == 2:
+        mesh = RectangleMesh(n[0], n[1], L[0], L[1], diagonal=("left", "right")[seed % 4 // 2], quadrilateral=quad)
+        om = omesh.structured(2, n, L, ("left", "right")[seed % 4 // 2], quadrilateral=quad)
+    else:
+        mesh, om = BoxMesh(n[0], n[1], n[2], L[0], L[1], L[2]), omesh.structured(3, n, L)
+    U = VectorFunctionSpace(mesh, "DG", P)
+    # a polynomial of total degree <= P in every cell type's space
+    c = rng.uniform(-1, 1, (dim, dim + 1))
+    poly = lambda X, i: (c[i, 0] + sum(c[i, a + 1] * X[..., a] for a in range(dim))) ** P
+    code = tuple("pow(%r + %s, %d)" % (float(c[i, 0]), " + ".join("%r*x[%d]" % (float(c[i, a + 1]), a) for a in range(dim)), P)
+                 for i in range(dim))
+    f = Function(U).interpolate(Expression(code))
+    pts = rng.uniform(0, 1, (12, dim)) * np.asarray(L)
+    grid = np.stack([rng.integers(0, n[a] + 1, 6) * (L[a] / n[a]) for a in range(dim)], axis=1)     # mesh vertices
+    mixed = pts[:6].copy()
+    mixed[:, 0] = grid[:, 0]                                                                        # points on grid lines
+    for p in np.concatenate([pts, grid, mixed]):
+        v = evaluate_at(f, p)
+        assert v is not None, p
+        np.testing.assert_allclose(v, [poly(p, i) for i in range(dim)], atol=1e-11)
+    g = Function(U).assign(rng.uniform(-1, 1, (U.ncells, U.nd, dim)))
+    z = Function(U).assign(np.zeros((U.ncells, U.nd, dim)))
+    assert abs(norm(g) - l2_norm(om, P, g.dat.data_cells)) < 1e-12 * max(1.0, norm(g))
+    q = 6 if dim == 2 else 3
+    assert abs(projected_abs_error_norm(g, z, q) - projected_abs_norm(om, P, g.dat.data_cells, q)) < 1e-11
