@@ -36,14 +36,15 @@ class FakeBlock(object):
         self.dim = dim = mesh.dim
         self.part = part
         self.n = part.n
-        self.ncls = {1: 1, 2: 2, 3: 6}[dim]
-        self.nfaces = dim + 1
+        quad = bool(getattr(mesh, "quadrilateral", False))
+        self.ncls = mesh.cells_per_block
+        self.nfaces = 2 * dim if quad else dim + 1
         fs = FunctionSpace(mesh, "DG", degree)
         self.X = fs.node_coords()
         self.nd = fs.nd
-        n4 = L.sg_reference_operator(dim, degree, 4, 0, None, 0)
+        n4 = L.sg_reference_operator_cell(int(quad), dim, degree, 4, 0, None, 0)
         fn = np.empty(n4)
-        L.sg_reference_operator(dim, degree, 4, 0, fn.ctypes.data, fn.nbytes)
+        L.sg_reference_operator_cell(int(quad), dim, degree, 4, 0, fn.ctypes.data, fn.nbytes)
         self.nf = n4 // self.nfaces
         self.fnode = fn.reshape(self.nfaces, self.nf).astype(int)
         self.nb = np.zeros((self.ncls, self.nfaces, 5), dtype=np.int32)
@@ -51,7 +52,7 @@ class FakeBlock(object):
         cn = np.zeros((self.ncls, self.nfaces, 3))
         ji = np.zeros((self.ncls, 3, 3))
         h = np.ascontiguousarray(mesh.h, dtype=np.float64)
-        assert L.sg_mesh_tables(dim, degree, 0, h.ctypes.data, self.nb.ctypes.data, self.nbn.ctypes.data,
+        assert L.sg_mesh_tables(dim, degree, 2 if quad else 0, h.ctypes.data, self.nb.ctypes.data, self.nbn.ctypes.data,
                                 cn.ctypes.data, ji.ctypes.data) == 0
         self.hpc = 2 if dim == 3 else 1
         self.ghost = {}
@@ -147,7 +148,7 @@ class FakeBlock(object):
         self.stages.append("end")
 
 
-def _worker(rank, world, port, dim, n, degree, grid):
+def _worker(rank, world, port, dim, n, degree, grid, quad=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -157,7 +158,7 @@ def _worker(rank, world, port, dim, n, degree, grid):
         from seigen_amd.mesh import Mesh, Partition
         from seigen_amd.parallel import HaloExchanger, world as world_fn
         assert world_fn() == (rank, world)
-        mesh = Mesh(n, tuple(1.0 + 0.5 * a for a in range(dim)))
+        mesh = Mesh(n, tuple(1.0 + 0.5 * a for a in range(dim)), quadrilateral=quad)
         part = Partition(n, rank, world, grid)
         mesh.set_partition(part)
         assert mesh.partition is part
@@ -196,6 +197,12 @@ def _worker(rank, world, port, dim, n, degree, grid):
 def test_halo_exchange_world2(dim, n, degree, grid):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), dim, n, degree, grid), nprocs=2, join=True)
+
+
+def test_halo_exchange_world4_quadrilaterals():
+    """The same on a 2 x 2 grid of blocks of quadrilateral cells (one class, four facets, sg_config::diagonal = 2)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(4, _free_port(), 2, (5, 4), 3, (2, 2), True), nprocs=4, join=True)
 
 
 def test_halo_exchange_world4_2d_grid():
