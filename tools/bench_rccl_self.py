@@ -37,7 +37,8 @@ def main():
     n, P, steps = (64, 64, 64), 4, int(os.environ.get("SEIGEN_BENCH_STEPS", "60"))
     h = [1.0 / 64] * 3
     rng = np.random.default_rng(0)
-    for grid_env in (None, "512", "496")[:int(os.environ.get("SEIGEN_BENCH_GRIDS", "3"))]:
+    grids = os.environ.get("SEIGEN_BENCH_GRID_LIST")
+    for grid_env in ((None, "512", "496")[:int(os.environ.get("SEIGEN_BENCH_GRIDS", "3"))] if not grids else tuple(grids.split(","))):
         if grid_env:
             os.environ["SEIGEN_HIP_GRID_BLOCKS"] = grid_env
         part = SelfNeighbour(n, 0, 1)
