@@ -86,7 +86,7 @@ typedef struct sg_config {
   int32_t dtype;     /* 0: FP64 storage and arithmetic - the reference's precision (elastic.py:442 'double'),
                         the parity and headline mode; 1: FP32 storage and arithmetic, the separately reported
                         second mode of SURVEY 8d (32 B per DoF-update; 3-D blocks on the MFMA path, 2-D blocks on the MFMA
-                        tile kernels: triangles P1-P4, quadrilaterals P1-P3; SG_ERR_ARG elsewhere).  The C-ABI
+                        tile kernels; SG_ERR_ARG elsewhere: 1-D blocks, forced generic / lane kernels).  The C-ABI
                         keeps double on the host side in both modes; halo buffers hold the device type. */
   void* stream;      /* hipStream_t to launch on, or NULL for the handle's own stream */
 } sg_config;

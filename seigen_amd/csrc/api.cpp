@@ -10,8 +10,8 @@ std::string g_create_err;
 KernelPath choose_kernel_path(const sg_config& cfg) {
   KernelPath kp;
   if (cfg.diagonal == SG_DIAGONAL_QUAD) {
-    // quadrilateral cells: the MFMA tile kernels for DQ_1..3 (at most one 16-row tile), else the table-driven
-    // generic kernels (host layout); same size threshold and SEIGEN_HIP_PATH overrides as for triangles
+    // quadrilateral cells: the MFMA tile kernels (DQ_4: two 16-row tiles), or on request the table-driven generic
+    // kernels (host layout); same size threshold and SEIGEN_HIP_PATH overrides as for triangles
     const char* pe = std::getenv("SEIGEN_HIP_PATH");
     const bool fg = pe && std::strcmp(pe, "generic") == 0, ft = pe && std::strcmp(pe, "tile") == 0;
     kp.tile = cfg.dim == 2 && tile2d_supported_quad(cfg.degree) && !fg &&
@@ -151,7 +151,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->f32 = cfg->dtype;
   if (h->f32 && !h->use_mfma && !h->use_tile)
     return fail(h, SG_ERR_ARG, "dtype f32 is implemented on the MFMA paths (3-D blocks: degree 1 from 65536 cells; 2-D "
-                               "blocks on the tile kernels: triangles P1-P4, quadrilaterals P1-P3)");
+                               "blocks on the tile kernels)");
   h->md.gw = kp.gw;
   h->md.ncube = (int64_t)h->cfg.n[0] * h->cfg.n[1] * h->cfg.n[2];
   h->md.ncube_pad = (h->md.ncube + h->md.gw - 1) / h->md.gw * h->md.gw;

@@ -51,8 +51,11 @@ struct TG : ElemDims<2, P, TP> {
   static constexpr int KSF = (NF + 3) / 4;   // k-steps over the facet nodes
   static constexpr int S4 = (ND + 3) / 4;    // row-quads of the result
   static constexpr bool LARGE = sizeof(R) == 4 || ND > SG_T2_LARGE_FROM;     // one 16-row tile (P3, P4; float) or S4 4-row tiles (P1, P2)
-  static constexpr int RT = LARGE ? 1 : S4;  // A fragments per (operator, k-step)
-  static constexpr int NFRAG_V = 2 * KS * RT;
+  static constexpr int RT = LARGE ? 1 : S4;  // A fragments per (operator, k-step) and row tile
+  static constexpr int MT = LARGE ? (ND + 15) / 16 : 1;   // 16-row tiles: 1, or 2 for DQ_4 (25 rows) - the tiles of an item
+                                                          // are worked off one after the other (one set of accumulators)
+  static constexpr int S4T = MT > 1 ? 4 : S4;              // row-quads per tile pass
+  static constexpr int NFRAG_V = 2 * KS * RT;              // per row tile
   static constexpr int NFRAG_L = NFACES * KSF * RT;
 };
 
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   typedef typename T2V<R>::v4 v4;
   constexpr unsigned EBY = sizeof(R), LB = 16 * sizeof(R);   // bytes per value / per 16-cell line
   constexpr int ND = G::ND, NF = G::NF, KS = G::KS, KSF = G::KSF, S4 = G::S4, RT = G::RT;
-  constexpr int NFC = G::NFACES, NCLS = G::NCLS;
+  constexpr int NFC = G::NFACES, NCLS = G::NCLS, MT = G::MT, S4T = G::S4T;
   constexpr bool LARGE = G::LARGE;
   constexpr int NC = (KIND == 0) ? 4 : 2;  // input components per node
   const int lane = threadIdx.x & 63;
@@ -122,11 +125,15 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   const T2Class& K = C.cls[k];
 
   // ---- operator fragments: registers, once per wave -----------------------------------------
+  // (MT > 1: the fragments of the row tile in work, re-read per item and tile - both tiles' would not fit the registers)
   R Av[G::NFRAG_V], Al[G::NFRAG_L];
+  auto load_frags = [&](int tile) {
 #pragma unroll
-  for (int j = 0; j < G::NFRAG_V; ++j) Av[j] = reinterpret_cast<const R*>(A.fragV)[j * 64 + lane];
+    for (int j = 0; j < G::NFRAG_V; ++j) Av[j] = reinterpret_cast<const R*>(A.fragV)[(tile * G::NFRAG_V + j) * 64 + lane];
 #pragma unroll
-  for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = reinterpret_cast<const R*>(A.fragL)[j * 64 + lane];
+    for (int j = 0; j < G::NFRAG_L; ++j) Al[j] = reinterpret_cast<const R*>(A.fragL)[(tile * G::NFRAG_L + j) * 64 + lane];
+  };
+  if constexpr (MT == 1) load_frags(0);
 
   // ---- class constants: one batch of scalar loads from the kernarg segment at an offset that depends on k only
   R Jv[2][2], cnv[NFC][2];
@@ -284,12 +291,52 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         ca *= r1;
         cnw *= r1;
       }
+      // sponge (elastic.py:207-208): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma, for every
+      // row-quad of the item.  With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave
+      // and the wave runs in program order, so these reads precede the stores (MT > 1: they are done before the
+      // first row tile is stored).
+      const bool sponge_here = __any(sslot >= 0);
+      R ssum[S4][2];
+      auto sponge_sums = [&]() {
+        if (sslot >= 0) {
+          const R* ua = reinterpret_cast<const R*>(A.uabs) + ubase + w;
+          const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND (double in both modes)
+#pragma unroll
+          for (int m = 0; m < S4; ++m) ssum[m][0] = ssum[m][1] = (R)0;
+          // chunks of CH columns: all of a chunk's loads are in flight together (one round trip per chunk)
+          constexpr int CH = ND <= 6 ? ND : (ND % 5 == 0 ? 5 : (ND % 4 == 0 ? 4 : 3));
+          static_assert(ND % CH == 0, "the sponge column chunks must tile the element's nodes");
+#pragma nounroll
+          for (int b0 = 0; b0 < ND; b0 += CH) {
+            R uu[CH][2], bb[S4][CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              uu[j][0] = ua[((b0 + j) * 2 + 0) * 16];
+              uu[j][1] = ua[((b0 + j) * 2 + 1) * 16];
+#pragma unroll
+              for (int m = 0; m < S4; ++m) bb[m][j] = (R)B[((4 * m + q < ND) ? m * 4 * ND : 0) + b0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+              for (int m = 0; m < S4; ++m) {
+                ssum[m][0] += bb[m][j] * uu[j][0];
+                ssum[m][1] += bb[m][j] * uu[j][1];
+              }
+          }
+        }
+      };
+      if (MT > 1 && sponge_here) sponge_sums();
+#pragma unroll
+      for (int tile = 0; tile < MT; ++tile) {
+      if constexpr (MT > 1) load_frags(tile);
       // in-place combine operands, requested before the arithmetic
-      R po[S4][2], pa[S4][2];
+      R po[S4T][2], pa[S4T][2];
       if (MODE == 1) {
 #pragma unroll
-        for (int m = 0; m < S4; ++m) {
-          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 2 * 16 + w) * EBY);
+        for (int m = 0; m < S4T; ++m) {
+          const int a = 16 * tile + 4 * m + q;
+          const unsigned ro = (unsigned)((((a < ND) ? a : 0) * 2 * 16 + w) * EBY);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             po[m][i] = t2_ld(outb, ro + i * LB);
@@ -318,47 +365,20 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
             const R fl = wf[f] * (cnv[f][0] * tn[f][ks][i * 2 + 0] + cnv[f][1] * tn[f][ks][i * 2 + 1]);
             t2_mma<LARGE, S4>(&Al[(f * KSF + ks) * RT], fl, acc[i]);
           }
-      // sponge (elastic.py:207-208): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
-      // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
-      // wave runs in program order, so these reads precede the stores below.
-      if (__any(sslot >= 0)) {
+      if (sponge_here) {
+        if (MT == 1) sponge_sums();
         if (sslot >= 0) {
-          const R* ua = reinterpret_cast<const R*>(A.uabs) + ubase + w;
-          const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND (double in both modes)
-          R s[S4][2];
 #pragma unroll
-          for (int m = 0; m < S4; ++m) s[m][0] = s[m][1] = (R)0;
-          // chunks of CH columns: all of a chunk's loads are in flight together (one round trip per chunk)
-          constexpr int CH = ND <= 6 ? ND : (ND % 5 == 0 ? 5 : (ND % 4 == 0 ? 4 : 3));
-          static_assert(ND % CH == 0, "the sponge column chunks must tile the element's nodes");
-#pragma nounroll
-          for (int b0 = 0; b0 < ND; b0 += CH) {
-            R uu[CH][2], bb[S4][CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-              uu[j][0] = ua[((b0 + j) * 2 + 0) * 16];
-              uu[j][1] = ua[((b0 + j) * 2 + 1) * 16];
-#pragma unroll
-              for (int m = 0; m < S4; ++m) bb[m][j] = (R)B[((4 * m + q < ND) ? m * 4 * ND : 0) + b0 + j];
+          for (int m = 0; m < S4T; ++m)
+            if (4 * tile + m < S4) {
+              acc[0][m] -= ssum[4 * tile + m][0];
+              acc[1][m] -= ssum[4 * tile + m][1];
             }
-#pragma unroll
-            for (int j = 0; j < CH; ++j)
-#pragma unroll
-              for (int m = 0; m < S4; ++m) {
-                s[m][0] += bb[m][j] * uu[j][0];
-                s[m][1] += bb[m][j] * uu[j][1];
-              }
-          }
-#pragma unroll
-          for (int m = 0; m < S4; ++m) {
-            acc[0][m] -= s[m][0];
-            acc[1][m] -= s[m][1];
-          }
         }
       }
 #pragma unroll
-      for (int m = 0; m < S4; ++m) {
-        const int a = 4 * m + q;
+      for (int m = 0; m < S4T; ++m) {
+        const int a = 16 * tile + 4 * m + q;
         const unsigned ro = (unsigned)((a * 2 * 16 + w) * EBY);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -367,6 +387,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           if (active && a < ND) t2_st(outb, ro + i * LB, v);
         }
       }
+      }  // row tiles
     } else {
       // ---- G ---------------------------------------------------------------------------------
       const R lam = (R)(A.per_cell ? A.lam[e] : A.lam0);
@@ -375,11 +396,15 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       const long sbase = ((long)item * ND) * 4 * 16;
       R* outb = out + sbase;            // wave-uniform
       const R* auxb = aux + sbase;
-      R po[S4][3], pa[S4][3], pl[S4], pal[S4];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
+#pragma unroll
+      for (int tile = 0; tile < MT; ++tile) {
+      if constexpr (MT > 1) load_frags(tile);
+      R po[S4T][3], pa[S4T][3], pl[S4T], pal[S4T];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
       if (MODE == 1) {
 #pragma unroll
-        for (int m = 0; m < S4; ++m) {
-          const unsigned ro = (unsigned)((((4 * m + q < ND) ? 4 * m + q : 0) * 4 * 16 + w) * EBY);
+        for (int m = 0; m < S4T; ++m) {
+          const int a = 16 * tile + 4 * m + q;
+          const unsigned ro = (unsigned)((((a < ND) ? a : 0) * 4 * 16 + w) * EBY);
           po[m][0] = t2_ld(outb, ro + 0 * LB);
           po[m][1] = t2_ld(outb, ro + 1 * LB);
           po[m][2] = t2_ld(outb, ro + 3 * LB);
@@ -397,7 +422,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       auto fold = [&](const R c0, const R c1, const v4 (&v)[2]) {
         // W_ik += c_k v_i
 #pragma unroll
-        for (int m = 0; m < S4; ++m) {
+        for (int m = 0; m < S4T; ++m) {
           Sd[0][m] += c0 * v[0][m];
           Sd[1][m] += c1 * v[1][m];
           So[m] += c1 * v[0][m] + c0 * v[1][m];
@@ -422,8 +447,8 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         fold(cnv[f][0], cnv[f][1], acc);
       }
 #pragma unroll
-      for (int m = 0; m < S4; ++m) {
-        const int a = 4 * m + q;
+      for (int m = 0; m < S4T; ++m) {
+        const int a = 16 * tile + 4 * m + q;
         const unsigned ro = (unsigned)((a * 4 * 16 + w) * EBY);
         const R tr = lam * (Sd[0][m] + Sd[1][m]);
         R v00 = (R)2 * mu * Sd[0][m] + tr, v11 = (R)2 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
@@ -450,6 +475,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           t2_st(outb, ro + 3 * LB, v11);
         }
       }
+      }  // row tiles
     }
   }
 }
@@ -532,7 +558,7 @@ static int launch_t2p(int kind, const StageArgs& a, const T2Const& c, long nitem
 }
 
 bool tile2d_supported(int dim, int P) { return dim == 2 && P >= 1 && P <= 4; }
-bool tile2d_supported_quad(int P) { return P >= 1 && P <= 3; }   // DQ_4 has 25 rows: two tiles (not built)
+bool tile2d_supported_quad(int P) { return P >= 1 && P <= 4; }   // DQ_4 has 25 rows: two row tiles, one after the other
 
 int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, long nitems, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -541,6 +567,7 @@ int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, l
       case 1: return launch_t2p<1, 1>(kind, a, c, nitems, s);
       case 2: return launch_t2p<2, 1>(kind, a, c, nitems, s);
       case 3: return launch_t2p<3, 1>(kind, a, c, nitems, s);
+      case 4: return launch_t2p<4, 1>(kind, a, c, nitems, s);
     }
     return -1;
   }

@@ -140,62 +140,71 @@ std::vector<float> mfma32_frags_L(const RefElem& re) {
 // ---- 2-D tile kernels ---------------------------------------------------------------------------
 static inline int tile2d_row(bool large, int t, int l) { return large ? (l & 15) : 4 * t + (l & 3); }
 
+// Row tiles: elements with more than 16 nodes (DQ_4: 25) use ceil(nd / 16) 16-row tiles; the tables hold tile 0's
+// fragments of every (operator, k-step), then tile 1's (the kernels work the tiles off one after the other).
+static inline int tile2d_ntiles(const RefElem& re, bool large) { return large ? (re.nd + 15) / 16 : 1; }
+
 std::vector<double> tile2d_frags_V(const RefElem& re, double sign) {
   const int ks = (re.nd + 3) / 4, s4 = (re.nd + 3) / 4;
   const bool large = re.nd > SG_T2_LARGE_FROM;
-  const int rt = large ? 1 : s4;
-  std::vector<double> out((size_t)2 * ks * rt * 64, 0.0);
-  for (int r = 0; r < 2; ++r)
-    for (int k0 = 0; k0 < ks; ++k0)
-      for (int t = 0; t < rt; ++t) {
-        size_t frag = ((size_t)r * ks + k0) * rt + t;
-        for (int l = 0; l < 64; ++l) out[frag * 64 + l] = sign * Eval(re, r, tile2d_row(large, t, l), 4 * k0 + (l >> 4));
-      }
+  const int rt = large ? 1 : s4, mt = tile2d_ntiles(re, large);
+  std::vector<double> out((size_t)mt * 2 * ks * rt * 64, 0.0);
+  for (int tile = 0; tile < mt; ++tile)
+    for (int r = 0; r < 2; ++r)
+      for (int k0 = 0; k0 < ks; ++k0)
+        for (int t = 0; t < rt; ++t) {
+          size_t frag = (((size_t)tile * 2 + r) * ks + k0) * rt + t;
+          for (int l = 0; l < 64; ++l)
+            out[frag * 64 + l] = sign * Eval(re, r, 16 * tile + tile2d_row(large, t, l), 4 * k0 + (l >> 4));
+        }
   return out;
 }
 
 std::vector<double> tile2d_frags_L(const RefElem& re) {
   const int ksf = (re.nf + 3) / 4, s4 = (re.nd + 3) / 4;
   const bool large = re.nd > SG_T2_LARGE_FROM;
-  const int rt = large ? 1 : s4;
-  std::vector<double> out((size_t)re.nfaces * ksf * rt * 64, 0.0);
-  for (int f = 0; f < re.nfaces; ++f)
-    for (int k0 = 0; k0 < ksf; ++k0)
-      for (int t = 0; t < rt; ++t) {
-        size_t frag = ((size_t)f * ksf + k0) * rt + t;
-        for (int l = 0; l < 64; ++l) {
-          int a = tile2d_row(large, t, l), b = 4 * k0 + (l >> 4);
-          out[frag * 64 + l] = (a < re.nd && b < re.nf) ? 0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
+  const int rt = large ? 1 : s4, mt = tile2d_ntiles(re, large);
+  std::vector<double> out((size_t)mt * re.nfaces * ksf * rt * 64, 0.0);
+  for (int tile = 0; tile < mt; ++tile)
+    for (int f = 0; f < re.nfaces; ++f)
+      for (int k0 = 0; k0 < ksf; ++k0)
+        for (int t = 0; t < rt; ++t) {
+          size_t frag = (((size_t)tile * re.nfaces + f) * ksf + k0) * rt + t;
+          for (int l = 0; l < 64; ++l) {
+            int a = 16 * tile + tile2d_row(large, t, l), b = 4 * k0 + (l >> 4);
+            out[frag * 64 + l] = (a < re.nd && b < re.nf) ? 0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
+          }
         }
-      }
   return out;
 }
 
-
-// The same two tables for the float tile kernels: always ONE zero-padded 16-row tile per (operator, k-step), and MFMA
-// row i holds node 4 (i & 3) + (i >> 2) - v_mfma_f32_16x16x4_f32 returns row 4 (lane >> 4) + reg, and the kernels
-// keep "accumulator register m of lane group q = node row 4 m + q" in both precisions.
+// The same two tables for the float tile kernels: always zero-padded 16-row tiles (ceil(nd / 16) of them), and MFMA
+// row i holds node 4 (i & 3) + (i >> 2) of its tile - v_mfma_f32_16x16x4_f32 returns row 4 (lane >> 4) + reg, and the
+// kernels keep "accumulator register m of lane group q = node row 4 m + q" in both precisions.
 static inline int tile2d_row32(int l) { return 4 * (l & 3) + ((l & 15) >> 2); }
 
 std::vector<float> tile2d_frags32_V(const RefElem& re, double sign) {
-  const int ks = (re.nd + 3) / 4;
-  std::vector<float> out((size_t)2 * ks * 64, 0.0f);
-  for (int r = 0; r < 2; ++r)
-    for (int k0 = 0; k0 < ks; ++k0)
-      for (int l = 0; l < 64; ++l)
-        out[((size_t)r * ks + k0) * 64 + l] = (float)(sign * Eval(re, r, tile2d_row32(l), 4 * k0 + (l >> 4)));
+  const int ks = (re.nd + 3) / 4, mt = (re.nd + 15) / 16;
+  std::vector<float> out((size_t)mt * 2 * ks * 64, 0.0f);
+  for (int tile = 0; tile < mt; ++tile)
+    for (int r = 0; r < 2; ++r)
+      for (int k0 = 0; k0 < ks; ++k0)
+        for (int l = 0; l < 64; ++l)
+          out[(((size_t)tile * 2 + r) * ks + k0) * 64 + l] = (float)(sign * Eval(re, r, 16 * tile + tile2d_row32(l), 4 * k0 + (l >> 4)));
   return out;
 }
 
 std::vector<float> tile2d_frags32_L(const RefElem& re) {
-  const int ksf = (re.nf + 3) / 4;
-  std::vector<float> out((size_t)re.nfaces * ksf * 64, 0.0f);
-  for (int f = 0; f < re.nfaces; ++f)
-    for (int k0 = 0; k0 < ksf; ++k0)
-      for (int l = 0; l < 64; ++l) {
-        const int a = tile2d_row32(l), b = 4 * k0 + (l >> 4);
-        out[((size_t)f * ksf + k0) * 64 + l] = (a < re.nd && b < re.nf) ? (float)(0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b]) : 0.0f;
-      }
+  const int ksf = (re.nf + 3) / 4, mt = (re.nd + 15) / 16;
+  std::vector<float> out((size_t)mt * re.nfaces * ksf * 64, 0.0f);
+  for (int tile = 0; tile < mt; ++tile)
+    for (int f = 0; f < re.nfaces; ++f)
+      for (int k0 = 0; k0 < ksf; ++k0)
+        for (int l = 0; l < 64; ++l) {
+          const int a = 16 * tile + tile2d_row32(l), b = 4 * k0 + (l >> 4);
+          out[(((size_t)tile * re.nfaces + f) * ksf + k0) * 64 + l] =
+              (a < re.nd && b < re.nf) ? (float)(0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b]) : 0.0f;
+        }
   return out;
 }
 

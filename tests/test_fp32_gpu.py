@@ -1,6 +1,6 @@
 """The FP32 second mode (sg_config.dtype = 1; SURVEY 8b `dtype`, 8d "optional second mode, 32 B per
 DoF-update"): float storage and arithmetic on the 3-D MFMA path and on the 2-D MFMA tile kernels - triangles P1-P4,
-quadrilaterals DQ_1-3 - (v_mfma_f32_16x16x4_f32).
+quadrilaterals DQ_1-4 - (v_mfma_f32_16x16x4_f32).
 The reference is FP64 throughout (seigen/elastic.py:442), so this mode is checked against the same
 FP64 oracle with float tolerances, stated here:
 
@@ -103,15 +103,14 @@ def test_fp32_needs_an_mfma_path(gpu, monkeypatch):
     from seigen_amd.backend import HipBlock
     with pytest.raises(_lib.SeigenHipError, match="f32"):
         HipBlock(1, 2, (8,), (0.25,), (0.0,), dtype="f32")                                      # 1-D: lane / generic kernels
-    with pytest.raises(_lib.SeigenHipError, match="f32"):
-        HipBlock(2, 4, (4, 4), (0.25, 0.25), (0.0, 0.0), "quadrilateral", dtype="f32")          # DQ_4: generic kernels
     monkeypatch.setenv("SEIGEN_HIP_PATH", "generic")
     with pytest.raises(_lib.SeigenHipError, match="f32"):
         HipBlock(2, 2, (4, 4), (0.25, 0.25), (0.0, 0.0), dtype="f32")
 
 
 CASES_2D = [(1, (9, 7), "left"), (2, (8, 5), "right"), (3, (17, 3), "left"), (4, (6, 6), "left"),
-            (1, (7, 9), "quadrilateral"), (2, (8, 5), "quadrilateral"), (3, (17, 3), "quadrilateral")]
+            (1, (7, 9), "quadrilateral"), (2, (8, 5), "quadrilateral"), (3, (17, 3), "quadrilateral"),
+            (4, (7, 5), "quadrilateral")]
 
 
 @pytest.mark.parametrize("degree,n,diagonal", CASES_2D)

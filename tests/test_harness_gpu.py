@@ -343,7 +343,7 @@ def test_multiblock_random_grids(gpu, seed):
     n = tuple(int(g * rng.integers(1, 4) + rng.integers(0, 2)) for g in grid)
     diagonal = "quadrilateral" if (dim == 2 and seed % 4 == 3) else "left"
     # every fifth case in the float mode, where an MFMA kernel family runs the blocks
-    f32_ok = (dim == 3 and degree >= 2) or (dim == 2 and not (diagonal == "quadrilateral" and degree == 4))
+    f32_ok = (dim == 3 and degree >= 2) or dim == 2
     dtype = "f32" if (seed % 5 == 4 and f32_ok) else "f64"
     _multiblock_case(dim, degree, n, grid, bool(seed % 2 == 0), extras=(seed % 3 != 1), diagonal=diagonal, dtype=dtype)
 

@@ -309,7 +309,7 @@ def test_kernel_families_agree_on_random_blocks(gpu, monkeypatch, seed):
     for path in ("generic", "lane", "mfma", "tile"):
         if path == "mfma" and dim != 3:
             continue
-        if path == "tile" and (dim != 2 or (quad and degree == 4)):
+        if path == "tile" and dim != 2:
             continue
         if path == "lane" and ((dim == 3 and degree > 2) or quad):
             continue
@@ -420,7 +420,7 @@ def test_random_field_ranges_round_trip(gpu, monkeypatch, seed):
         path = ""
     if path:
         monkeypatch.setenv("SEIGEN_HIP_PATH", path)
-    f32_ok = not path and ((dim == 3 and degree >= 2) or (dim == 2 and not (quad and degree == 4)))
+    f32_ok = not path and ((dim == 3 and degree >= 2) or dim == 2)
     dtype = "f32" if (f32_ok and rng.integers(0, 2)) else "f64"
     blk = HipBlock(dim, degree, n, [0.5] * dim, [0.0] * dim, diagonal, dtype=dtype)
     hold = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype == "f32" else (lambda a: a)

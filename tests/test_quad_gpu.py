@@ -72,11 +72,11 @@ def test_eigenmode_sweep_on_quadrilaterals_matches_goldens_and_converges(gpu):
         assert ou > floor and os_ > floor, (P, ou, os_)
 
 
-@pytest.mark.parametrize("P,path", [(1, None), (2, None), (2, "generic"), (3, None), (4, None)])
+@pytest.mark.parametrize("P,path", [(1, None), (2, None), (2, "generic"), (3, None), (4, None), (4, "generic")])
 def test_sponge_source_and_material_on_quadrilaterals(gpu, monkeypatch, P, path):
     """The extras of the explosive-source set-up on quadrilateral cells: DG4 sponge (elastic.py:207-208), a nodal
     source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle - on the MFMA tile kernels
-    (DQ_1..3 by default), the generic kernels (DQ_4; DQ_2 forced)."""
+    (the default; DQ_4 with two row tiles) and on the generic kernels (forced)."""
     if path:
         monkeypatch.setenv("SEIGEN_HIP_PATH", path)
     from seigen_amd import _lib
@@ -119,7 +119,7 @@ def test_sponge_source_and_material_on_quadrilaterals(gpu, monkeypatch, P, path)
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
 
 
-@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
 @pytest.mark.parametrize("n", [(37, 23), (16, 1), (5, 40), (129, 3)])
 def test_quadrilateral_tile_kernels_agree_with_the_generic_kernels(gpu, monkeypatch, P, n):
     """Ragged blocks (cell groups of 16 straddling rows, one-row and narrow blocks): the MFMA tile kernels against
