@@ -569,6 +569,26 @@ def test_eigenmode_bench_record(gpu, tmp_path):
     assert json.loads(path.read_text())["meta"]["dofs"] == rec["meta"]["dofs"]
 
 
+def test_explosive_source_bench_record(gpu, tmp_path):
+    """The pybench-style record of tests/explosive_source/explosive_source_bench.py:15-24: series h, T, explicit; the
+    run's named timers."""
+    import json
+    import seigen_amd
+    import seigen_amd.helpers as helpers
+    import seigen_amd.harness.explosive_source as hx
+    helpers.log = seigen_amd.elastic.log = hx.log = lambda s: None
+    from seigen_amd.harness.explosive_source_bench import explosive_source_record
+    path = tmp_path / "ExplosiveSourceLF4.json"
+    rec = explosive_source_record(T=0.01, h=2.5, explicit=True, path=str(path), dt=0.001)
+    assert rec["series"] == {"np": 1, "h": 2.5, "T": 0.01, "explicit": True}
+    assert rec["meta"] == {"dofs": 120 * 60 * 2 * 6 * 4, "steps": 10}
+    for task in ("mesh generation", "timestepping", "solver setup", "elastic-run"):
+        assert rec["timings"][task] > 0, (task, rec["timings"])
+    assert json.loads(path.read_text())["series"] == rec["series"]
+    rec2 = explosive_source_record(T=0.005, explicit=False, dt=0.001)       # the implicit class runs too
+    assert rec2["series"]["explicit"] is False and rec2["meta"]["steps"] == 5
+
+
 def test_separable_source(gpu):
     """sg_set_source_separable (one slice + a weight per step) against sg_set_source with the table of the products:
     bitwise equal, on the fused-source 2-D tile path and on the launch path (3-D); through the solver class an
