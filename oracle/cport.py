@@ -30,23 +30,34 @@ def build(arch=None, force=False):
     return LIB
 
 
-def reference_operators(dim, P):
-    nd = refelem.nnodes(dim, P)
-    xq, wq = refelem.simplex_quadrature(dim, 2 * P)
-    phi, dphi = refelem.tabulate(dim, P, xq)
+def reference_operators(dim, P, kind="simplex"):
+    """D_r = Mhat^-1 Shat_r, L_f = Mhat^-1 Mface_f restricted to the facet's nodes, facet node lists - by quadrature of
+    the oracle's own basis (simplices, or kind "tensor": quadrilaterals, refelem.el_*)."""
+    nd = refelem.el_nnodes(dim, P, kind)
+    xq, wq = refelem.el_quadrature(dim, 2 * P, kind)
+    phi, dphi = refelem.el_tabulate(dim, P, xq, kind)
     Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wq, phi, phi))
     D = np.stack([Minv @ np.einsum('q,qa,qb->ab', wq, dphi[:, :, r], phi) for r in range(dim)])
-    nf = refelem.nnodes(dim - 1, P) if dim > 1 else 1
-    xf, wf = refelem.simplex_quadrature(dim - 1, 2 * P)
-    bary = np.concatenate([1 - xf.sum(1, keepdims=True), xf], axis=1)
-    V = np.vstack([np.zeros(dim), np.eye(dim)])
-    L = np.zeros((dim + 1, nd, nf))
-    fnode = np.zeros((dim + 1, nf), dtype=np.int32)
-    for f in range(dim + 1):
-        fn = refelem.face_nodes(dim, P, f)
+    nfaces = refelem.el_nfaces(dim, kind)
+    if kind == "tensor":
+        nf = P + 1
+        t, wf = refelem.simplex_quadrature(1, 2 * P)
+        bary = np.concatenate([1 - t, t], axis=1)
+        V = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+        fact = 1.0
+    else:
+        nf = refelem.nnodes(dim - 1, P) if dim > 1 else 1
+        xf, wf = refelem.simplex_quadrature(dim - 1, 2 * P)
+        bary = np.concatenate([1 - xf.sum(1, keepdims=True), xf], axis=1)
+        V = np.vstack([np.zeros(dim), np.eye(dim)])
+        fact = float(math.factorial(dim - 1))
+    L = np.zeros((nfaces, nd, nf))
+    fnode = np.zeros((nfaces, nf), dtype=np.int32)
+    for f in range(nfaces):
+        fn = refelem.el_face_nodes(dim, P, f, kind)
         fnode[f] = fn
-        ph, _ = refelem.tabulate(dim, P, bary @ V[refelem.face_vertices(dim, f)])
-        Mf = np.einsum('q,qa,qb->ab', wf * math.factorial(dim - 1), ph, ph)
+        ph, _ = refelem.el_tabulate(dim, P, bary @ V[refelem.el_face_vertices(dim, f, kind)], kind)
+        Mf = np.einsum('q,qa,qb->ab', wf * fact, ph, ph)
         L[f] = (Minv @ Mf)[:, fn]
     return D, L, fnode
 
@@ -56,16 +67,16 @@ def sponge_blocks(mesh, P, sigma_nodes, sigma_degree):
     where the DG_q field sigma (nodal values [nc, nd_q]) is not identically zero: the blocks of
     oracle.forms.ScalarOperators.absorption_matrix (elastic.py:207-208), built for those cells only so that
     full-size meshes need no global sparse operators."""
-    d = mesh.dim
+    d, kind = mesh.dim, getattr(mesh, "kind", "simplex")
     sig = np.asarray(sigma_nodes, dtype=np.float64).reshape(mesh.ncells, -1)
     cells = np.nonzero(np.abs(sig).max(axis=1) > 0)[0]
     slot = -np.ones(mesh.ncells, dtype=np.int64)
     slot[cells] = np.arange(len(cells))
-    xq, wq = refelem.simplex_quadrature(d, 2 * P + sigma_degree)
-    phi, _ = refelem.tabulate(d, P, xq)
-    psi, _ = refelem.tabulate(d, sigma_degree, xq)
-    xm, wm = refelem.simplex_quadrature(d, 2 * P)
-    pm, _ = refelem.tabulate(d, P, xm)
+    xq, wq = refelem.el_quadrature(d, 2 * P + sigma_degree, kind)
+    phi, _ = refelem.el_tabulate(d, P, xq, kind)
+    psi, _ = refelem.el_tabulate(d, sigma_degree, xq, kind)
+    xm, wm = refelem.el_quadrature(d, 2 * P, kind)
+    pm, _ = refelem.el_tabulate(d, P, xm, kind)
     Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wm, pm, pm))          # |det J| cancels against the integral's
     sig_q = np.einsum('qc,nc->nq', psi, sig[cells])
     loc = np.einsum('q,nq,qa,qb->nab', wq, sig_q, phi, phi)
@@ -84,8 +95,8 @@ class CPort(object):
         self.lib.so_max_threads.restype = C.c_int
         self.mesh, self.P = mesh, P
         d = self.dim = mesh.dim
-        D, L, fnode = reference_operators(d, P)
-        nd, nf, nfaces, nc = D.shape[1], L.shape[2], d + 1, mesh.ncells
+        D, L, fnode = reference_operators(d, P, getattr(mesh, "kind", "simplex"))
+        nd, nf, nfaces, nc = D.shape[1], L.shape[2], L.shape[0], mesh.ncells
         self.nd = nd
         X = mesh.node_coords(P)
         nbr = -np.ones((nc, nfaces), dtype=np.int64)

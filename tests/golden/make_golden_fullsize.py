@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Oracle-backed goldens at BASELINE's full sizes (tests/fullsize_cases.py) -> tests/golden/fullsize_c{2,3,5}.npz.
-Run from the repo root in the build container:  python tests/golden/make_golden_fullsize.py [c3] [c2] [c5]
+Run from the repo root in the build container:  python tests/golden/make_golden_fullsize.py [c3] [c2] [c5] [c2q]
 
 The step is the oracle's plain-C restatement (oracle/c/seigen_oracle.c through oracle/cport.py: so_step_ex with
 sponge, source, per-cell material and density), itself validated against the numpy oracle on small meshes
@@ -68,11 +68,11 @@ def box_source(m, P, lo, hi, dt, steps):
     return nodes, vals
 
 
-def c2():
+def c2(quadrilateral=False):
     c = fc.C2
     n, h, P = c["n"], c["h"], c["P"]
     L = n * h
-    m = omesh.RectangleMesh(n, n, L, L)
+    m = omesh.RectangleMesh(n, n, L, L, quadrilateral=quadrilateral)
     cp = CPort(m, P)
     Xs = m.node_coords(c["sigma_degree"])
     sig = np.where((Xs[..., 0] <= c["sponge"]) | (Xs[..., 0] >= L - c["sponge"]) | (Xs[..., 1] <= c["sponge"]), c["sigma"], 0.0)
@@ -83,7 +83,12 @@ def c2():
     u, s = fc.smooth_state(m.node_coords(P), c["k"], c["s_scale"])
     u, s = cp.step_ex(u, s, c["rho"], c["dt"], c["lam"], c["mu"], c["steps"], inplace=True)
     nd = cp.nd
-    save("fullsize_c2.npz", cp, u, s, n, np.unique(nodes // nd), dict(src_nodes=nodes))
+    save("fullsize_c2q.npz" if quadrilateral else "fullsize_c2.npz", cp, u, s, n, np.unique(nodes // nd), dict(src_nodes=nodes))
+
+
+def c2q():
+    """config 2's set-up on quadrilateral cells (DQ_2, 512 x 512 squares): build-defined row"""
+    c2(quadrilateral=True)
 
 
 def c5():
@@ -111,4 +116,4 @@ def c5():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["c5", "c2", "c3"]
     for w in what:
-        {"c2": c2, "c3": c3, "c5": c5}[w]()
+        {"c2": c2, "c3": c3, "c5": c5, "c2q": c2q}[w]()

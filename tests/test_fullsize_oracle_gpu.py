@@ -72,16 +72,18 @@ def _box_source_expression(lo, hi, t0):
     return Expression(((code, "0.0"), ("0.0", code)), a=fc.A_RICKER, t0=t0, t=0)
 
 
-def test_config2_full_size_vs_oracle(gpu):
+@pytest.mark.parametrize("quadrilateral", [False, True])
+def test_config2_full_size_vs_oracle(gpu, quadrilateral):
     """2-D explosive source, 512 x 512 squares, P2, DG4 sponge + box-Ricker source (BASELINE config 2) through the
-    solver class on the 2-D MFMA tile kernels, 20 steps from a smooth state."""
+    solver class on the 2-D MFMA tile kernels, 20 steps from a smooth state - on triangles (the reference's mesh) and
+    on quadrilateral cells (DQ_2; golden fullsize_c2q.npz from the same C port of the oracle)."""
     _quiet()
     from seigen_amd import ElasticLF4, Expression, Function, FunctionSpace, RectangleMesh
     c = fc.C2
-    gold = np.load(os.path.join(GOLD, "fullsize_c2.npz"))
+    gold = np.load(os.path.join(GOLD, "fullsize_c2q.npz" if quadrilateral else "fullsize_c2.npz"))
     n, h = c["n"], c["h"]
     L = n * h
-    mesh = RectangleMesh(n, n, L, L)
+    mesh = RectangleMesh(n, n, L, L, quadrilateral=quadrilateral)
     el = ElasticLF4.create(mesh, "DG", c["P"], dimension=2, solver="explicit", output=False)
     el.density, el.mu, el.l, el.dt = c["rho"], c["mu"], c["lam"], c["dt"]
     sx, sy, hw = c["src"][0], c["src"][1], c["src_half"]

@@ -193,8 +193,8 @@ def test_quadrilateral_blocks_equal_the_single_block(gpu):
 
 def test_config2_setup_on_quadrilaterals_full_size_tile_vs_generic(gpu, monkeypatch):
     """Config 2's set-up (512 x 512 squares, P2, DG4 sponge, box-Ricker source) on quadrilateral cells at full size:
-    the MFMA tile kernels against the table-driven generic kernels after 20 steps (no oracle at this size: the C port
-    knows simplices only), and the float tile kernels against the double ones."""
+    the MFMA tile kernels against the table-driven generic kernels after 20 steps, and the float tile kernels against
+    the double ones (against the oracle at this size: tests/test_fullsize_oracle_gpu.py, golden fullsize_c2q.npz)."""
     _quiet()
     import seigen_amd.harness.explosive_source as hx
     hx.log = lambda s: None
