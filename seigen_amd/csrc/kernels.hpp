@@ -157,7 +157,7 @@ struct T2Const {
 };
 T2Const tile2d_const(const MeshDev& md_host);
 bool tile2d_supported(int dim, int P);
-bool tile2d_supported_quad(int P);   // quadrilateral cells (StageArgs::tensor): DQ_1..3
+bool tile2d_supported_quad(int P);   // quadrilateral cells (StageArgs::tensor): DQ_1..4
 int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, long nitems, void* stream);
 
 // host layout [cell][node][comp] <-> device layout (MeshDev::gw) for `ncells` cells from `cell0`

@@ -1,4 +1,5 @@
-// MFMA tile stage kernels for 2-D blocks, P1..P4 (gfx950, FP64).
+// MFMA tile stage kernels for 2-D blocks: triangles P1..P4 and quadrilaterals DQ_1..4 (gfx950; FP64, and float as the
+// second mode).
 //
 // Same data layout idea as the 3-D MFMA path (kernels_mfma.hip): gw = 16, i.e. the 16 values of one
 // (node, component) of 16 consecutive squares' cells of one class form one 128-byte line, and one
@@ -7,7 +8,8 @@
 //
 //     [operator tile (nd rows) x 4]  x  [4 nodes x 16 cells]  ->  [nd rows x 16 cells]
 //
-// With nd <= 15 every operator is at most ONE 16-row tile per k-step (P3, P4: v_mfma_f64_16x16x4_f64)
+// With nd <= 16 every operator is at most ONE 16-row tile per k-step (P3, P4, DQ_2, DQ_3: v_mfma_f64_16x16x4_f64;
+// DQ_4's 25 rows: two such tiles, worked off one after the other)
 // or one / two 4-row tiles (P1, P2: v_mfma_f64_4x4x4_4b_f64), so the whole operator set of a degree is
 // 5..14 doubles per lane and lives in REGISTERS for the life of the wave: no LDS, no barrier.
 //
@@ -35,8 +37,8 @@
 
 namespace sg {
 
-// TP = 1: quadrilateral cells, tensor-product element DQ_P (one class per square, four facets; P <= 3: at most
-// one 16-row tile)
+// TP = 1: quadrilateral cells, tensor-product element DQ_P (one class per square, four facets; DQ_4: two 16-row
+// tiles, MT below)
 // R = float (sg_config::dtype = 1, the second mode of SURVEY 8d): v_mfma_f32_16x16x4_f32 for every degree (gfx950 has
 // no 4-row f32 shape with K = 4), one zero-padded 16-row tile; its C/D rows are 4 (lane >> 4) + reg, so the float
 // operator tiles hold node 4 (i & 3) + (i >> 2) in MFMA row i (mfma_tables.cpp tile2d_frags32_*) and accumulator
