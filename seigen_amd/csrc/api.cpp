@@ -60,6 +60,7 @@ void sg_destroy(sg_handle* h) {
     if (h->field[f]) (void)hipFree(h->field[f]);
   if (h->md_dev) (void)hipFree(h->md_dev);
   if (h->mk_dev) (void)hipFree(h->mk_dev);
+  if (h->err_word) (void)hipHostFree(h->err_word);
   if (h->nbr_tab) (void)hipFree(h->nbr_tab);
   if (h->Dt) (void)hipFree(h->Dt);
   if (h->Lt) (void)hipFree(h->Lt);
@@ -197,6 +198,18 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     const MfmaConst mk = mfma_const(h->md);
     HIPCHECK(h, hipMalloc((void**)&h->mk_dev, sizeof(MfmaConst)));
     HIPCHECK(h, hipMemcpy(h->mk_dev, &mk, sizeof(MfmaConst), hipMemcpyHostToDevice));
+    // trace-sharing F kernels (kernels_mfma.hip mfma_stage_FT): double, degrees 3 and 4, Kuhn split
+    h->team = 0;
+    if (mk.team_ok && !h->f32 && cfg->degree >= 3) {
+      h->team = SG_TEAM_DEFAULT;
+      if (const char* te = std::getenv("SEIGEN_HIP_TEAM")) {
+        const int t = std::atoi(te);
+        h->team = (t == 4 || t == 8) ? t : 0;
+      }
+      HIPCHECK(h, hipHostMalloc((void**)&h->err_word, sizeof(int32_t), hipHostMallocMapped));
+      *h->err_word = 0;
+      HIPCHECK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_word, 0));
+    }
     if ((h->md.ncube_pad / 16) * 6 * 16 >= ((int64_t)1 << 31))     // cell slots are int32 (288 GB hold far fewer cells)
       return fail(h, SG_ERR_ARG, "block too large for the MFMA path's neighbour table");
     {
@@ -379,7 +392,7 @@ int sg_sync(sg_handle* h) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   if (int rc = join_second(h)) return rc;
   HIPCHECK(h, sync_all(h));
-  return SG_OK;
+  return check_kernel_error(h);
 }
 
 // Node coordinates of a block: the affine image of the reference lattice under every cell's vertex map (one

@@ -29,11 +29,19 @@ struct ElemDims {
 // MeshDev in LDS: about 45 DEPENDENT ds_read / s_waitcnt round trips per item in front of the first trace load
 // (tools/wave_sim.py, profiles/r03/kernel_experiments.txt) - the lesson of the 2-D tile kernels' T2Const.
 constexpr int MK_KSF = 4;     // facet k-steps at degree 4 (15 facet nodes)
+constexpr int MK_KS = 9;      // volume k-steps at degree 4 (35 nodes)
+#ifndef SG_TEAM_DEFAULT
+#define SG_TEAM_DEFAULT 0     // waves per team of the trace-sharing F kernels unless SEIGEN_HIP_TEAM says otherwise
+#endif
 struct MfmaClassConst {
   int32_t nb_axis[4], nb_dir[4], nb_cls[4];
   int32_t slot_ord[4];        // ordinal of the matching facet among the neighbour cube's facets on that side
   uint32_t nbw[4][MK_KSF];    // [f][ks] byte q: neighbour ELEMENT node matching my facet node 4 ks + q (MeshDev::nb_node)
   uint32_t nfw[4][MK_KSF];    // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
+  int32_t nb_face[4];         // neighbour's local facet (MeshDev::nb_face)
+  // team F kernels: (c n) of the NEIGHBOUR across my intra-cube facets 1 and 2 (its table entry, bit for bit), so that
+  // the trace I publish for it, (c n)_j T_ij at my nodes, is exactly what it would compute from my tensor itself
+  double pcn[2][3];
 };
 struct MfmaConst {
   int32_t n[3];
@@ -42,6 +50,12 @@ struct MfmaConst {
   int32_t pad_[2];
   int64_t ncube, ncube_pad;
   uint32_t fw[4][MK_KSF];     // [f][ks] byte q: my element node of facet node 4 ks + q (MeshDev::fnode)
+  // team F kernels: [ks] byte q = row of the wave's trace stash that element node 4 ks + q is published to, for the
+  // intra-cube facets 1 (word [0][ks]) and 2 ([1][ks]): (f - 1) * nf + position in the facet's node list, or the
+  // dummy row 2 * nf for a node that is not on the facet (the stores are unconditional)
+  uint32_t pubw[2][MK_KS];
+  int32_t team_ok;            // facets 1 and 2 are the intra-cube ones for every class (Kuhn split): the team kernels apply
+  int32_t pad2_;
   MfmaClassConst cls[6];
 };
 MfmaConst mfma_const(const MeshDev& md_host);
@@ -112,6 +126,10 @@ struct StageArgs {
   // layer together, so the z-neighbour traces and the own rows of the next layer meet in the Infinity Cache.
   int32_t order_chunk;
   int32_t nitems;               // MFMA path: items of this launch (the item list's length, or cell groups x classes)
+  // MFMA path, F stages: waves per team of the trace-sharing kernels (kernels_mfma.hip mfma_stage_FT; 0 = the plain
+  // kernels), and a device word they set when a team barrier gives up (never, unless the kernel is broken)
+  int32_t team;
+  int32_t* err;
   // 2-D tile path, G stages: the sparse nodal source (elastic.py:217-218) added inside the stage kernel instead of
   // by a launch of its own.  src_slot[item] = slot of an item (16 cells of one class) that holds source nodes, or -1;
   // src_idx[slot][node][cell] = row of that node in this step's value table src_vals[row][dim*dim], or -1.

@@ -415,6 +415,52 @@ __device__ __forceinline__ void load_tables(R* sAV, R* sAL, MeshDev* sMd, const 
   __syncthreads();
 }
 
+
+// (c n)_j T_ij for one row i of a tensor, in ONE fixed order of operations: the consumer of a facet trace (lifts of
+// mfma_stage_F / mfma_stage_FT) and the neighbour that publishes the same product through LDS (mfma_stage_FT) must
+// agree bit for bit, whichever of the two a launch happens to use for a facet.
+template <typename R>
+__device__ __forceinline__ R ndot(R c0, R c1, R c2, R t0, R t1, R t2) {
+  R r = c0 * t0;
+  r = __builtin_fma(c1, t1, r);
+  r = __builtin_fma(c2, t2, r);
+  return r;
+}
+template <>
+__device__ __forceinline__ float ndot<float>(float c0, float c1, float c2, float t0, float t1, float t2) {
+  float r = c0 * t0;
+  r = __builtin_fmaf(c1, t1, r);
+  r = __builtin_fmaf(c2, t2, r);
+  return r;
+}
+
+// Barrier among the TEAM waves of a workgroup that share traces (mfma_stage_FT): an LDS counter every wave bumps once
+// per barrier and then polls.  (gfx950 has one hardware barrier per workgroup and no named barriers; the two teams of
+// a block must stay independent of each other.)  LDS operations of one wave are performed in order, and a poll that
+// sees the bump of a sibling is performed after it, so everything the sibling wrote to LDS before is visible: no
+// vmcnt wait - the global loads in flight across the barrier are the point.  The poll gives up after SG_TEAM_SPIN
+// rounds (some tens of milliseconds) so that a broken launch ends with wrong numbers and an error word, not a hung GPU.
+#ifndef SG_TEAM_SPIN
+#define SG_TEAM_SPIN (1 << 18)
+#endif
+__device__ __forceinline__ bool team_sync(unsigned* ctr, unsigned target, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  bool ok = true;
+  int spins = 0;
+  for (;;) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - target) >= 0) break;
+    if (++spins > SG_TEAM_SPIN) {
+      ok = false;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return ok;
+}
+
 // --------------------------------------------------------------------------------------------
 //  G: sh_ij = lam d_ij W_kk + mu (W_ij + W_ji),  W_ik = -Jinv_rk (D_r u_i) + sum_f (c n)_k L_f u^_i
 //  Row tile t of every D_r leaves node a = 4 m + q in lane-group q (m = 4 t + reg for a large
@@ -943,8 +989,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
             R fl[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-              fl[i] = wf[f] * (cnf[f][0] * nq[s % PFL][i * 3 + 0] + cnf[f][1] * nq[s % PFL][i * 3 + 1] +
-                               cnf[f][2] * nq[s % PFL][i * 3 + 2]);
+              fl[i] = wf[f] * ndot<R>(cnf[f][0], cnf[f][1], cnf[f][2], nq[s % PFL][i * 3 + 0], nq[s % PFL][i * 3 + 1],
+                                      nq[s % PFL][i * 3 + 2]);
             if (s + PFL < NS) {
               const int f1 = (s + PFL) / KSF, k1 = (s + PFL) % KSF;
               load_trace<SYM, GHOST>(np[f1] + noff[f1][k1], gh[f1], fax[f1], nq[s % PFL]);
@@ -1108,6 +1154,404 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   STAMP_FLUSH;
 }
 
+
+// --------------------------------------------------------------------------------------------
+//  F with traces shared through LDS ("team" kernel; double, degrees 3 and 4).
+//
+//  The plain F kernel above reads every facet value once as own data and about 1.7 times as somebody's neighbour
+//  trace, and most of those trace reads miss the L2 (profiles/r03: F<4,0> moves 6.8 GB over the fabric for 4.0 GB of
+//  own data).  Half of a cell's facets - 1 and 2, opposite the vertices 1 and 2 of the Kuhn tetrahedron - lie INSIDE
+//  its cube: the neighbour is another class of the same cube, i.e. the same lane of another item of the same cell
+//  group, and the items of a group are consecutive.  So the TEAM waves of a team (blocks are eight waves = 8 / TEAM
+//  teams) take TEAM consecutive items in lock-step, and every wave
+//    * in its volume phase, while the own tensors pass through its registers anyway, PUBLISHES for its two intra-cube
+//      facets what the neighbour needs from it - (c n)_j T_ij with the NEIGHBOUR's scaled normal, three values per
+//      facet node instead of six or nine - into its stash in LDS (31 rows of 3 x 16 values: 15 per facet + one dummy
+//      row that takes the stores of the nodes on neither facet, so that the stores need no branch);
+//    * after the team's barrier looks for the items of its two intra-cube neighbours among its team mates and, where
+//      it finds one, lifts that facet from the mate's stash (12 ds_read_b64) instead of 24-36 global loads; the
+//      fall-back (the neighbour's item belongs to another team or round: with TEAM = 4 a third of the intra-cube
+//      facets, with 8 a sixth) is the global path, which gives the same bits (ndot).
+//  The two facets on cube faces keep the global path; their first loads are in flight across the barrier.
+//  LDS: 66 KB of operator tiles (once per CU instead of twice) + 8 x 11.6 KB of stashes = 158 KB, one block per CU.
+// --------------------------------------------------------------------------------------------
+template <typename R, int P, int MODE, int SYM, int GHOST, int TEAM>
+__global__ __launch_bounds__(512, 1) void mfma_stage_FT(StageArgs A) {
+  using M = MG<P, R>;
+  typedef typename RT<R>::v4 d4;
+  constexpr int PRIO3 = MODE ? SG_PRIO_F1 : SG_PRIO_F0;
+  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
+  constexpr int NW = 8;                           // waves per block
+  constexpr int STASH = (2 * NF + 1) * 3 * 16;    // values per wave
+  static_assert(NW % TEAM == 0 && KS <= MK_KS && KSF <= MK_KSF, "team kernel shape");
+  __shared__ R sAV[M::NFRAG_F * 64];
+  __shared__ R sAL[M::NFRAG_L * 64];
+  __shared__ R sTr[NW * STASH];
+  __shared__ int sItem[NW];
+  __shared__ unsigned sCtr[NW / TEAM];
+  if (threadIdx.x < NW) sItem[threadIdx.x] = -1;
+  if (threadIdx.x < NW / TEAM) sCtr[threadIdx.x] = 0u;
+  load_tables<M::NFRAG_F, M::NFRAG_L, R, 512>(sAV, sAL, A);
+  const cMfmaConst& mk = *(const cMfmaConst*)(unsigned long long)A.mk;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team0 = wave & ~(TEAM - 1);
+  const int q = lane >> 4, w = lane & 15;
+  typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
+  const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
+  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
+  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
+  R* __restrict__ out = reinterpret_cast<R*>(A.out);
+  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
+  const long ngroups = mk.ncube_pad >> 4;
+  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
+  // every wave of a team makes the same number of rounds (a wave without an item still meets the barriers)
+  const long lo_team = ir.lo - (wave - team0);
+  const long nrounds = ir.hi > lo_team ? (ir.hi - lo_team + ir.step - 1) / ir.step : 0;
+  unsigned* const ctr = &sCtr[wave / TEAM];
+  unsigned epoch = 0;
+  bool sync_ok = true;
+  R* const mytr = sTr + wave * STASH;
+
+  STAMP_DECL;
+  for (long rnd = 0; rnd < nrounds; ++rnd) {
+    STAMP(st0);
+    const long it = ir.lo + rnd * ir.step;
+    long item = -1;
+    if (it < ir.hi) {
+      const long iti = item_of(ir, it);
+      if (iti >= 0) item = A.item_list ? (long)A.item_list[iti] : iti;
+    }
+    const long itemc = item < 0 ? 0 : item;
+    const long g = itemc / 6;
+    const int k = (int)(itemc - g * 6);
+    const LaneGeo L = A.all_active ? lane_geo_all(mk.ncube, g, w) : lane_geo(mk, A, g, w);
+    const bool work = __builtin_amdgcn_readfirstlane((item >= 0 && __any(L.active)) ? 1 : 0) != 0;
+    const cMfmaClassConst& kc = mk.cls[k];
+    // opaque per item: the stash rows of the publication (mk.pubw) are item-invariant, and LLVM would compute all 18
+    // of them once, outside the item loop, and keep them in (spilled) registers
+    int qsh = q * 8;
+    asm volatile("" : "+v"(qsh));
+    const nbr4 nbe = load_nbr4(A, itemc, w);
+    const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+    int qo = q * 9 * 16;  // B rows: see mfma_stage_G
+    asm volatile("" : "+v"(qo));
+    const R* ownq = own + qo;
+    const R* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 9 * 16 : own;
+    auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 9 * 16; };
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+
+    // my team mates have read what they wanted from my stash of the previous round
+    epoch += TEAM;
+    sync_ok = team_sync(ctr, epoch, lane) && sync_ok;
+    if (lane == 0) sItem[wave] = work ? (int)item : -1;
+
+    R Jm[3][3];
+    d4 acc[3][M::MTFA];
+    R accs[3][M::NSMA];
+    // The facets that come from memory - 0 and 3 (cube faces), and an intra-cube facet whose neighbour no team mate
+    // holds - are worked off as ONE stream of facets with the facet number a wave-uniform run-time value: one copy of
+    // the code, and the fall-back does by construction the arithmetic of the normal case.
+    constexpr int PFL = (KSF % SG_PFLF == 0) ? SG_PFLF : KSF;   // k-steps of traces in flight; divides KSF (register rotation)
+    struct FSet {       // where a facet's traces are found
+      const R* p;
+      int off[KSF];
+      R wf, cn[3];
+      bool gh;
+      int fax;
+    };
+    auto facet_setup = [&](int f) {
+      FSet S;
+      const int e = f == 0 ? nbe[0] : (f == 1 ? nbe[1] : (f == 2 ? nbe[2] : nbe[3]));
+      const int axis = kc.nb_axis[f];
+      const NbrRef<R> NR = nbr_from_entry<ND, NF, 9>(A, e, 2 * axis + (kc.nb_dir[f] > 0 ? 1 : 0), own);
+      S.p = NR.p;
+      S.gh = GHOST && NR.ghost;
+      S.fax = GHOST ? axis : 0;
+      S.wf = NR.physical ? R(-1) : R(1);
+#pragma unroll
+      for (int ks = 0; ks < KSF; ++ks) {
+        const int on = word_byte(mk.fw[f][ks], qsh);
+        const int nn = NR.ghost ? word_byte(kc.nfw[f][ks], qsh) : (NR.physical ? on : word_byte(kc.nbw[f][ks], qsh));
+        S.off[ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) S.cn[j] = (R)md->cn[k][f][j];
+      return S;
+    };
+    R nq[PFL][9];
+    FSet cur;
+    if (work) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Jm[r][j] = (R)md->Jinv[k][r][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int t = 0; t < MTF; ++t) acc[i][t] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NSM; ++t) accs[i][t] = R(0);
+      }
+      SG_PRIO(SG_PRIO_VOL);
+      STAMP(st1);
+      // ---- volume (as in mfma_stage_F) + publication of the two intra-cube traces
+      {
+        R pcn[2][3];
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) pcn[fi][j] = (R)kc.pcn[fi][j];
+        constexpr int PFV = SG_PFV;
+        R Tq[PFV][9];
+#pragma unroll
+        for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          R T[9];
+#pragma unroll
+          for (int c = 0; c < 9; ++c) T[c] = Tq[ks % PFV][c];
+          if (ks + PFV < KS) {
+            load_tensor<SYM>(brow(ks + PFV), 16, Tq[ks % PFV]);
+          }
+#pragma unroll
+          for (int fi = 0; fi < 2; ++fi) {
+            const int row = word_byte(mk.pubw[fi][ks], qsh);
+            R* dst = mytr + row * 48 + w;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              dst[i * 16] = ndot<R>(pcn[fi][0], pcn[fi][1], pcn[fi][2], T[i * 3 + 0], T[i * 3 + 1], T[i * 3 + 2]);
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            R Tt[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
+#pragma unroll
+            for (int t = 0; t < MTT; ++t) {
+              const R a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                if (t < MTF)
+                  acc[i][t < MTF ? t : 0] = MFMA64(a, Tt[i], acc[i][t < MTF ? t : 0]);
+                else
+                  accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, Tt[i], accs[i][t < MTF ? 0 : t - MTF]);
+              }
+            }
+          }
+        }
+      }
+      STAMP(st2);
+      SG_PRIO(SG_PRIO_LIFT);
+      // ---- the first loads of the facet stream (facet 0): in flight across the barrier and the stash facets
+      cur = facet_setup(0);
+#pragma unroll
+      for (int s = 0; s < PFL; ++s) load_trace<SYM, GHOST>(cur.p + cur.off[s], cur.gh, cur.fax, nq[s]);
+    }
+
+    // every mate has published this round's traces
+    STAMP(sta);
+    epoch += TEAM;
+    sync_ok = team_sync(ctr, epoch, lane) && sync_ok;
+    STAMP(stb);
+    if (!work) continue;
+
+    // one k-step of one facet's lifts from the three values per facet node in fl; lof = lane + the facet's tiles
+    auto lift_step = [&](int lof, int ks, const R (&fl)[3]) {
+#pragma unroll
+      for (int t = 0; t < MTT; ++t) {
+        const R a = sAL[(t * KSF + ks) * 64 + lof];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (t < MTF)
+            acc[i][t < MTF ? t : 0] = MFMA64(a, fl[i], acc[i][t < MTF ? t : 0]);
+          else
+            accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, fl[i], accs[i][t < MTF ? 0 : t - MTF]);
+        }
+      }
+    };
+    // ---- the lifts, always in the facet order 0, 3, 1, 2 (the sums must not depend on where a trace came from: a
+    //      multi-block run is bitwise the single-block run).  Facets 0 and 3 lie on cube faces: traces from memory.
+    //      Facets 1 and 2 lie inside the cube: from a team mate's stash where one holds the neighbour's item, else
+    //      from memory like the others.  The facets from memory form one stream - PFL k-steps of traces in flight,
+    //      the next such facet's set-up made a facet ahead, its first loads issued during the last k-steps of this one.
+    int sl[2];
+    unsigned mcode = 0u | (3u << 2);   // the facets that come from memory, in order, two bits each
+    int nmem = 2;
+    {
+      int mates[TEAM];
+#pragma unroll
+      for (int j = 0; j < TEAM; ++j) mates[j] = sItem[team0 + j];
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi) {
+        const int want = (int)(g * 6) + kc.nb_cls[1 + fi];
+        int s1 = -1;
+#pragma unroll
+        for (int j = 0; j < TEAM; ++j) s1 = (mates[j] == want) ? team0 + j : s1;
+        sl[fi] = __builtin_amdgcn_readfirstlane(s1);
+        if (sl[fi] < 0) {
+          mcode |= (unsigned)(1 + fi) << (2 * nmem);
+          nmem += 1;
+        }
+      }
+    }
+    int jm = 0;
+    for (int j = 0; j < 4; ++j) {
+      const int f = (int)((0x9Cu >> (2 * j)) & 3u);   // 0, 3, 1, 2
+      const int lof = lo + f * (MTT * KSF * 64);
+      const int slj = j < 2 ? -1 : (j == 2 ? sl[0] : sl[1]);
+      if (slj >= 0) {
+        const R* tb = sTr + slj * STASH + (kc.nb_face[f] - 1) * (NF * 48) + w;
+        R fl[KSF][3];
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) {
+          const int pos = word_byte(kc.nfw[f][ks], qsh);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) fl[ks][i] = tb[pos * 48 + i * 16];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) lift_step(lof, ks, fl[ks]);
+      } else {
+        const bool more = jm + 1 < nmem;
+        FSet nxt = cur;
+        if (more) nxt = facet_setup((int)((mcode >> (2 * jm + 2)) & 3u));
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) {
+          R fl[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            fl[i] = cur.wf * ndot<R>(cur.cn[0], cur.cn[1], cur.cn[2], nq[ks % PFL][i * 3 + 0], nq[ks % PFL][i * 3 + 1],
+                                     nq[ks % PFL][i * 3 + 2]);
+          if (ks + PFL < KSF) {
+            load_trace<SYM, GHOST>(cur.p + cur.off[ks + PFL], cur.gh, cur.fax, nq[ks % PFL]);
+          } else if (more) {
+            load_trace<SYM, GHOST>(nxt.p + nxt.off[ks + PFL - KSF], nxt.gh, nxt.fax, nq[ks % PFL]);
+          }
+          lift_step(lof, ks, fl);
+        }
+        cur = nxt;
+        jm += 1;
+      }
+    }
+
+    SG_PRIO(SG_PRIO_EPI);
+    STAMP(st3);
+    // ---- sponge and epilogue: as in mfma_stage_F
+    const long e = (L.valid ? L.c : 0) * 6 + k;
+    const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    int qo3 = q * 3 * 16;
+    asm volatile("" : "+v"(qo3));
+    const long ub_q = ubase + qo3;
+    if (A.sponge_slot != nullptr) {
+      const int slot = L.active ? A.sponge_slot[e] : -1;
+      if (__any(slot >= 0)) {
+        if (slot >= 0) {
+          auto damp = [&](int a, R& r0, R& r1, R& r2) {
+            if (a < ND) {
+              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
+              const R* ua = reinterpret_cast<const R*>(A.uabs);
+              R s0 = 0, s1 = 0, s2 = 0;
+              for (int b = 0; b < ND; ++b) {
+                const R bb = (R)B[b];
+                s0 += bb * ua[ubase + (b * 3 + 0) * 16];
+                s1 += bb * ua[ubase + (b * 3 + 1) * 16];
+                s2 += bb * ua[ubase + (b * 3 + 2) * 16];
+              }
+              r0 -= s0;
+              r1 -= s1;
+              r2 -= s2;
+            }
+          };
+#pragma unroll
+          for (int t = 0; t < MTF; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              R r0 = acc[0][t][reg], r1 = acc[1][t][reg], r2 = acc[2][t][reg];
+              damp(16 * t + 4 * reg + q, r0, r1, r2);
+              acc[0][t][reg] = r0;
+              acc[1][t][reg] = r1;
+              acc[2][t][reg] = r2;
+            }
+#pragma unroll
+          for (int t = 0; t < NSM; ++t) damp(16 * MTF + 4 * t + q, accs[0][t], accs[1][t], accs[2][t]);
+        }
+      }
+    }
+    if (MODE == 1) {
+      R cs = c_self, ca = c_aux, cn = c_new;
+      if (A.rho2 != nullptr) {
+        cs = (R)A.rho2[2 * e];
+        ca *= (R)A.rho2[2 * e + 1];
+        cn *= (R)A.rho2[2 * e + 1];
+      }
+      R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
+            pa[t][reg][i] = LD_STREAM(&aux[o + i * 16]);
+          }
+        }
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) {
+        const int a = 16 * MTF + 4 * t + q;
+        const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          pos[t][i] = LD_STREAM(&out[o + i * 16]);
+          pas[t][i] = LD_STREAM(&aux[o + i * 16]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            R v = cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg];
+            asm volatile("" : "+v"(v));
+            acc[i][t][reg] = v;
+          }
+#pragma unroll
+      for (int t = 0; t < NSM; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          accs[i][t] = cs * pos[t][i] + ca * pas[t][i] + cn * accs[i][t];
+          asm volatile("" : "+v"(accs[i][t]));
+        }
+    }
+    if (L.active) {
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], acc[i][t][reg]);
+        }
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) {
+        const int a = 16 * MTF + 4 * t + q;
+        if (a < ND) {
+          const long o = ub_q + (long)(16 * MTF + 4 * t) * 3 * 16;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], accs[i][t]);
+        }
+      }
+    }
+    STAMP(st4);
+    STAMP_ACC;
+  }
+  if (!sync_ok && A.err != nullptr && lane == 0) atomicOr(A.err, 1);
+  STAMP_FLUSH;
+}
+
 template <typename R, int P, int SYM>
 static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
   // persistent grid, at most 2 blocks per CU; a multiple of 8 (one item range per XCD label)
@@ -1123,6 +1567,32 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
     // blocks without neighbour blocks never meet a packed remote trace: GHOST = 0 instantiation
     bool ghosts = false;
     for (int sd = 0; sd < 6; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
+    if constexpr (sizeof(R) == 8 && P >= 3) {
+      if (a.team == 4 || a.team == 8) {
+        // blocks of eight waves, one per CU: half as many blocks for the same number of wave slots
+        unsigned nb2 = (unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512) / 2u;
+        if (a.nitems > 0 && !a.spread) {
+          const unsigned need = (((unsigned)a.nitems + 7u) / 8u + 7u) / 8u * 8u;
+          nb2 = need < nb2 ? need : nb2;
+        }
+        nb2 = nb2 < 8u ? 8u : nb2 / 8u * 8u;
+        const dim3 g2(nb2), b2(512);
+#define SG_LAUNCH_FT(MODE_, GH_)                                                            \
+  do {                                                                                      \
+    if (a.team == 4)                                                                        \
+      hipLaunchKernelGGL((mfma_stage_FT<R, P, MODE_, SYM, GH_, 4>), g2, b2, 0, s, a);       \
+    else                                                                                    \
+      hipLaunchKernelGGL((mfma_stage_FT<R, P, MODE_, SYM, GH_, 8>), g2, b2, 0, s, a);       \
+  } while (0)
+        if (a.mode == 0) {
+          if (ghosts) SG_LAUNCH_FT(0, 1); else SG_LAUNCH_FT(0, 0);
+        } else {
+          if (ghosts) SG_LAUNCH_FT(1, 1); else SG_LAUNCH_FT(1, 0);
+        }
+#undef SG_LAUNCH_FT
+        return (int)hipGetLastError();
+      }
+    }
     if (a.mode == 0) {
       if (ghosts)
         hipLaunchKernelGGL((mfma_stage_F<R, P, 0, SYM, 1>), grid, block, 0, s, a);

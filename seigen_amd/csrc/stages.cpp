@@ -94,6 +94,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.md = h->md_dev;
   a.mk = h->mk_dev;
   a.nbr_tab = h->nbr_tab;
+  a.team = (kind == 0) ? h->team : 0;
+  a.err = h->err_dev;
   a.all_active = region == SG_REGION_ALL ? 1 : 0;
   a.tensor = h->re.kind == KIND_TENSOR ? 1 : 0;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
@@ -412,7 +414,7 @@ int sg_step(sg_handle* h, int64_t nsteps) {
   float ms = 0;
   HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  return SG_OK;
+  return check_kernel_error(h);
 }
 
 int sg_last_step_ms(sg_handle* h, double* ms) {
