@@ -549,45 +549,88 @@ def main():
     if halo is not None:
         out["halo"] = halo
 
-    # multi-GPU, weak-scaling workload: how the step time depends on the share of block slots the launches that run
-    # beside an exchange leave to RCCL's kernels (default 15/16; it was tuned on ONE device against a self-send)
-    if world > 1 and workload == "c3" and args.grid_sweep and "SEIGEN_HIP_GRID_BLOCKS" not in os.environ:
+    # ---- extras of a multi-GPU job (grid-size sweep, config 4 in the same processes).  The headline record above is
+    # complete; nothing below may lose it.  Each extra runs under its own deadline: a rank that is still inside the
+    # extra when it expires (a hang in an exchange, a slow build) ends the job THERE - rank 0 prints the headline with
+    # an error note in place of the extra, every rank leaves with exit code 0 - and an exception inside an extra
+    # degrades to the same note.  The job-wide watchdog (stacks + exit 1) stays armed for the headline phases only.
+    def finish(record):
+        if rank == 0:
+            if world == 1 and not args.no_cpu_baseline:
+                record["cpu_baseline"] = cpu_baseline(P)
+            print(json.dumps(record))
+            sys.stdout.flush()
+
+    class ExtraDeadline(object):
+        def __init__(self, key, seconds):
+            import threading
+            self.key = key
+            self.timer = threading.Timer(seconds, self.expire)
+            self.timer.daemon = True
+
+        def expire(self):
+            note = dict(out)
+            note[self.key] = {"error": "timed out after the headline measurement; headline unaffected"}
+            try:
+                finish(note)
+            finally:
+                os._exit(0)
+
+        def __enter__(self):
+            self.timer.start()
+            return self
+
+        def __exit__(self, *exc):
+            self.timer.cancel()
+            return False
+
+    extra_budget = max(60.0, min(420.0, 0.4 * args.timeout))
+    want_sweep = world > 1 and workload == "c3" and args.grid_sweep and "SEIGEN_HIP_GRID_BLOCKS" not in os.environ
+    want_c4 = args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4")
+    if want_sweep or want_c4:
+        faulthandler.cancel_dump_traceback_later()
         elastic._exchanger = None
         blk.close()
         del elastic, blk
-        sweep = {}
-        for gb in [v for v in args.grid_sweep.split(",") if v.strip()]:
-            os.environ["SEIGEN_HIP_GRID_BLOCKS"] = gb.strip()
-            el_s, _, _, _, _ = build_config3(args, rank, world)
-            ms_s = measure(el_s, args, comm, 30, 3)
-            sweep[gb.strip()] = ms_s["elapsed"] / ms_s["steps"] * 1e3
-            el_s._exchanger = None
-            el_s.block.close()
-            del el_s
-        del os.environ["SEIGEN_HIP_GRID_BLOCKS"]
-        out["halo"]["grid_blocks_sweep_ms_per_step"] = sweep
         elastic = blk = None
 
+    # multi-GPU, weak-scaling workload: how the step time depends on the share of block slots the launches that run
+    # beside an exchange leave to RCCL's kernels (default 15/16; it was tuned on ONE device against a self-send)
+    if want_sweep:
+        sweep = {}
+        try:
+            with ExtraDeadline("grid_blocks_sweep", extra_budget):
+                for gb in [v for v in args.grid_sweep.split(",") if v.strip()]:
+                    os.environ["SEIGEN_HIP_GRID_BLOCKS"] = gb.strip()
+                    el_s, _, _, _, _ = build_config3(args, rank, world)
+                    ms_s = measure(el_s, args, comm, 30, 3)
+                    sweep[gb.strip()] = ms_s["elapsed"] / ms_s["steps"] * 1e3
+                    el_s._exchanger = None
+                    el_s.block.close()
+                    del el_s
+            out["halo"]["grid_blocks_sweep_ms_per_step"] = sweep
+        except Exception as e:      # noqa: BLE001 - anything here must not cost the headline
+            out["halo"]["grid_blocks_sweep_ms_per_step"] = {"error": repr(e), "partial": sweep}
+        os.environ.pop("SEIGEN_HIP_GRID_BLOCKS", None)
+
     # 8 ranks, no explicit workload: BASELINE config 4 in the same job (its own mesh, its own barriers)
-    if args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4"):
-        if elastic is not None:
-            elastic._exchanger = None
-            blk.close()
-            del elastic, blk
-        el4, grid4, gn4, wname4, _ = build_config4(args, rank, world, args.c4_steps + 3 + 1)
-        m4 = measure(el4, args, comm, args.c4_steps, 3)
-        dofs4 = int(round(sum(comm.gather(el4.block.u_dofs + el4.block.s_dofs))))
-        own4 = m4["own_ms_per_step"]
-        out["config4"] = {"workload": wname4, "value": dofs4 * m4["steps"] / m4["elapsed"] / 1e6, "unit": "M DoF-updates/s",
-                          "ms_per_step": m4["elapsed"] / m4["steps"] * 1e3, "steps": m4["steps"], "warmup": 3,
-                          "scaling": "strong (fixed global size)", "block_grid": list(grid4), "dofs": dofs4,
-                          "block_cubes": list(el4.mesh.partition.n), "dt": el4.dt,
-                          "rank_ms_per_step": {"min": min(own4), "max": max(own4), "per_rank": own4},
-                          "halo": halo_block(el4, m4, comm, backend)}
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P)
-        print(json.dumps(out))
+    if want_c4:
+        try:
+            with ExtraDeadline("config4", extra_budget):
+                el4, grid4, gn4, wname4, _ = build_config4(args, rank, world, args.c4_steps + 3 + 1)
+                m4 = measure(el4, args, comm, args.c4_steps, 3)
+                dofs4 = int(round(sum(comm.gather(el4.block.u_dofs + el4.block.s_dofs))))
+                own4 = m4["own_ms_per_step"]
+                c4 = {"workload": wname4, "value": dofs4 * m4["steps"] / m4["elapsed"] / 1e6, "unit": "M DoF-updates/s",
+                      "ms_per_step": m4["elapsed"] / m4["steps"] * 1e3, "steps": m4["steps"], "warmup": 3,
+                      "scaling": "strong (fixed global size)", "block_grid": list(grid4), "dofs": dofs4,
+                      "block_cubes": list(el4.mesh.partition.n), "dt": el4.dt,
+                      "rank_ms_per_step": {"min": min(own4), "max": max(own4), "per_rank": own4},
+                      "halo": halo_block(el4, m4, comm, backend)}
+            out["config4"] = c4
+        except Exception as e:      # noqa: BLE001
+            out["config4"] = {"error": repr(e)}
+    finish(out)
     faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         dist.destroy_process_group()

@@ -99,6 +99,8 @@ void sg_destroy(sg_handle* h) {
   if (h->src_values) (void)hipFree(h->src_values);
   if (h->src_slot_d) (void)hipFree(h->src_slot_d);
   if (h->src_idx_d) (void)hipFree(h->src_idx_d);
+  if (h->src_ctr_d) (void)hipFree(h->src_ctr_d);
+  if (h->src_weights_d) (void)hipFree(h->src_weights_d);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -590,6 +592,10 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
     (void)hipFree(h->src_idx_d);
     h->src_idx_d = nullptr;
   }
+  if (h->src_weights_d) {
+    (void)hipFree(h->src_weights_d);
+    h->src_weights_d = nullptr;
+  }
   h->src_fused = false;
   h->src_nnz = 0;
   h->src_nsteps = 0;
@@ -709,6 +715,10 @@ int sg_set_source(sg_handle* h, int64_t nnz, const int64_t* nodes, int64_t nstep
       h->src_fused = true;
     }
   }
+  if (!h->src_ctr_d) {   // device-side step counter for graph replay (stages.cpp sg_step)
+    HIPCHECK(h, hipMalloc((void**)&h->src_ctr_d, sizeof(int64_t)));
+    HIPCHECK(h, hipMemset(h->src_ctr_d, 0, sizeof(int64_t)));
+  }
   h->src_nnz = nnz;
   h->src_nsteps = nsteps;
   h->src_static = is_static;
@@ -724,6 +734,8 @@ int sg_set_source_separable(sg_handle* h, int64_t nnz, const int64_t* nodes, con
   if (rc != SG_OK) return rc;
   h->src_weights.assign(weights, weights + nsteps);
   h->src_nsteps = nsteps;
+  HIPCHECK(h, hipMalloc((void**)&h->src_weights_d, (size_t)nsteps * sizeof(double)));
+  HIPCHECK(h, hipMemcpy(h->src_weights_d, weights, (size_t)nsteps * sizeof(double), hipMemcpyHostToDevice));
   return SG_OK;
 }
 

@@ -75,6 +75,12 @@ struct sg_handle {
   int64_t src_step = 0;
   bool src_static = false;  // one time slice that holds at every step
   std::vector<double> src_weights;  // separable source: src_values is one slice, scaled by src_weights[src_step]
+  // graph replay with a source: the step index lives in a device word that the captured launches read and a one-thread
+  // launch bumps at the end of every step (kernels.hpp SrcStep); sg_step sets it to src_step before it replays
+  int64_t* src_ctr_d = nullptr;
+  double* src_weights_d = nullptr;
+  bool capture_src = false;   // stage launches issued now (a capture) take slice and weight from src_ctr_d
+  bool graph_src = false;     // the captured graphs contain the source launches
   // 2-D tile path: the source is added inside the G stage kernels (StageArgs::src_slot / src_idx)
   bool src_fused = false;
   int32_t* src_slot_d = nullptr;

@@ -449,9 +449,15 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& mh, const void* field, int
 // ---- sparse source ----------------------------------------------------------------------
 template <typename T>
 __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64_t* offs, const double* values,
-                              double coef, double scale) {
+                              double coef, double scale, SrcStep ss) {
   long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= nnz * ncomp) return;
+  if (ss.ctr != nullptr) {   // graph replay: this step's slice and weight from the device-side counter
+    const int64_t st = *ss.ctr;
+    if (!ss.is_static && st >= ss.nsteps) return;
+    if (!ss.is_static) values += st * ss.stride;
+    if (ss.weights != nullptr) scale = ss.weights[st];
+  }
   long k = idx / ncomp;
   int c = (int)(idx - k * ncomp);
   // every node appears once (sg_set_source merges the entries of a node listed twice): a plain read-modify-write
@@ -459,16 +465,23 @@ __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64
   *p = *p + (T)(coef * sg_mul_rounded(scale, values[idx]));
 }
 
+__global__ void step_counter_kernel(int64_t* ctr, int64_t value, int add) { *ctr = add ? *ctr + value : value; }
+
+int launch_step_counter(int64_t* ctr, int64_t value, int add, void* stream) {
+  hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, value, add);
+  return (int)hipGetLastError();
+}
+
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
-                  double scale, int f32, void* stream) {
+                  double scale, const SrcStep& ss, int f32, void* stream) {
   if (nnz <= 0) return 0;
   long total = nnz * ncomp;
   if (f32)
     hipLaunchKernelGGL(source_kernel<float>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       (float*)field, ncomp, gw, (long)nnz, offs, values, coef, scale);
+                       (float*)field, ncomp, gw, (long)nnz, offs, values, coef, scale, ss);
   else
     hipLaunchKernelGGL(source_kernel<double>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       (double*)field, ncomp, gw, (long)nnz, offs, values, coef, scale);
+                       (double*)field, ncomp, gw, (long)nnz, offs, values, coef, scale, ss);
   return (int)hipGetLastError();
 }
 

@@ -77,6 +77,19 @@ __host__ __device__ __forceinline__ double sg_mul_rounded(double a, double b) {
 }
 #endif
 
+// A source whose time slice is chosen ON THE DEVICE: a captured hipGraph freezes kernel arguments, so a launch that
+// is to be replayed step after step reads the step index from a device word (bumped by a one-thread launch at the end
+// of every step) instead of getting this step's slice and weight from the host (elastic.py:285-288 re-interpolates
+// the source Expression before every step).
+struct SrcStep {
+  const int64_t* ctr;      // device word: index of the current step; null: the host chose slice and scale
+  int64_t nsteps;          // steps the source covers (a step beyond them adds nothing)
+  int64_t stride;          // doubles between two time slices of the value table (0: one slice for every step)
+  const double* weights;   // separable source: weight per step (device), else null
+  int32_t is_static;       // one slice that holds at every step
+  int32_t pad_;
+};
+
 struct StageArgs {
   const double* in;    // stress for F, velocity for G           [cell][node][comp]
   double* out;         // result, or in-place target of a fused combine
@@ -137,6 +150,7 @@ struct StageArgs {
   const int32_t* src_idx;
   const double* src_vals;
   double src_scale;          // factor on src_vals (a separable source's weight of this step, else 1)
+  SrcStep src_step;          // graph replay: slice and weight from the device-side step counter (ctr != null)
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)
@@ -196,6 +210,8 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& md_host, const void* field
 // field[off[k] + c*gw] += coef * values[k][c] at the sparse source nodes (off = device offset of comp 0)
 // (values are scaled by `scale` and rounded first: a separable source's weight of this step)
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
-                  double scale, int f32, void* stream);
+                  double scale, const SrcStep& ss, int f32, void* stream);
+// the device-side step counter of SrcStep: *ctr = value (add = 0) or *ctr += value (add = 1), one thread
+int launch_step_counter(int64_t* ctr, int64_t value, int add, void* stream);
 
 }  // namespace sg

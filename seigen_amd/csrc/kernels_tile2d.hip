@@ -456,12 +456,22 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         R v00 = (R)2 * mu * Sd[0][m] + tr, v11 = (R)2 * mu * Sd[1][m] + tr, v01 = mu * So[m], v10 = v01;
         if (sslot_src >= 0) {  // wave-uniform, a handful of items: + S_ij at the source nodes (elastic.py:217-218)
           const int ix = (a < ND) ? A.src_idx[(sslot_src * ND + a) * 16 + w] : -1;
-          if (ix >= 0) {
-            const double* sv = A.src_vals + (long)ix * 4;
-            v00 += (R)sg_mul_rounded(A.src_scale, sv[0]);   // rounded product first: bitwise = a table of the products
-            v01 += (R)sg_mul_rounded(A.src_scale, sv[1]);
-            v10 += (R)sg_mul_rounded(A.src_scale, sv[2]);
-            v11 += (R)sg_mul_rounded(A.src_scale, sv[3]);
+          const double* svb = A.src_vals;
+          double ssc = A.src_scale;
+          bool son = true;
+          if (A.src_step.ctr != nullptr) {   // graph replay: slice and weight of the step the device-side counter names
+            const int64_t st = *A.src_step.ctr;
+            son = A.src_step.is_static || st < A.src_step.nsteps;
+            const int64_t s2 = son ? st : 0;
+            if (!A.src_step.is_static) svb += s2 * A.src_step.stride;
+            if (A.src_step.weights != nullptr) ssc = A.src_step.weights[s2];
+          }
+          if (ix >= 0 && son) {
+            const double* sv = svb + (long)ix * 4;
+            v00 += (R)sg_mul_rounded(ssc, sv[0]);   // rounded product first: bitwise = a table of the products
+            v01 += (R)sg_mul_rounded(ssc, sv[1]);
+            v10 += (R)sg_mul_rounded(ssc, sv[2]);
+            v11 += (R)sg_mul_rounded(ssc, sv[3]);
           }
         }
         if (MODE == 1) {

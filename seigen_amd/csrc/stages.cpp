@@ -69,6 +69,20 @@ void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int regio
 static bool source_active(const sg_handle* h) {
   return h->src_nnz != 0 && (h->src_static || h->src_step < h->src_nsteps);
 }
+// launches of a capture: slice and weight of the step the device-side counter names (kernels.hpp SrcStep)
+static SrcStep source_stepper(const sg_handle* h) {
+  SrcStep ss;
+  std::memset(&ss, 0, sizeof(ss));
+  if (!h->capture_src) return ss;
+  const int64_t dd = (int64_t)h->cfg.dim * h->cfg.dim;
+  ss.ctr = h->src_ctr_d;
+  ss.nsteps = h->src_nsteps;
+  ss.is_static = h->src_static ? 1 : 0;
+  ss.weights = h->src_weights.empty() ? nullptr : h->src_weights_d;
+  ss.stride = (h->src_static || !h->src_weights.empty()) ? 0 : h->src_nnz * dd;
+  if (ss.stride == 0 && ss.weights == nullptr) ss.is_static = 1;
+  return ss;
+}
 // separable source: the one stored slice, scaled by this step's weight
 static bool source_one_slice(const sg_handle* h) { return h->src_static || !h->src_weights.empty(); }
 static double source_scale(const sg_handle* h) {
@@ -115,7 +129,13 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.c_self = c_self;
   a.c_aux = c_aux;
   a.c_new = c_new;
-  if (with_source && h->src_fused && source_active(h)) {  // tile path: the G kernel adds this step's source values
+  if (with_source && h->src_fused && h->capture_src) {     // ... of the step the device-side counter names
+    a.src_slot = h->src_slot_d;
+    a.src_idx = h->src_idx_d;
+    a.src_vals = h->src_values;
+    a.src_scale = 1.0;
+    a.src_step = source_stepper(h);
+  } else if (with_source && h->src_fused && source_active(h)) {  // tile path: the G kernel adds this step's source values
     a.src_slot = h->src_slot_d;
     a.src_idx = h->src_idx_d;
     a.src_vals = h->src_values + (size_t)(source_one_slice(h) ? 0 : h->src_step) * h->src_nnz * h->cfg.dim * h->cfg.dim;
@@ -209,7 +229,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
 // that wrote it (INTERIOR + BOUNDARY: all of it after the second launch)
 static int add_source(sg_handle* h, int field, double coef, int region = SG_REGION_ALL) {
   if (h->src_fused) return SG_OK;  // added by the stage kernel (run_op with_source)
-  if (h->src_nnz == 0 || (!h->src_static && h->src_step >= h->src_nsteps) || region == SG_REGION_INTERIOR) return SG_OK;
+  if (h->src_nnz == 0 || region == SG_REGION_INTERIOR) return SG_OK;
+  if (!h->capture_src && !h->src_static && h->src_step >= h->src_nsteps) return SG_OK;
   const int d = h->cfg.dim;
   int64_t off = 0, cnt = h->src_nnz;
   if (region == SG_REGION_FIRST) cnt = h->src_nfirst;
@@ -218,8 +239,10 @@ static int add_source(sg_handle* h, int field, double coef, int region = SG_REGI
     cnt = h->src_nnz - h->src_nfirst;
   }
   if (cnt == 0) return SG_OK;
-  const double* vals = h->src_values + ((size_t)(source_one_slice(h) ? 0 : h->src_step) * h->src_nnz + off) * d * d;
-  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, source_scale(h), h->f32, h->stream);
+  const SrcStep ss = source_stepper(h);
+  const double* vals = h->src_values + ((size_t)((source_one_slice(h) || ss.ctr) ? 0 : h->src_step) * h->src_nnz + off) * d * d;
+  int rc = launch_source(h->field[field], d * d, h->md.gw, cnt, h->src_nodes + off, vals, coef, ss.ctr ? 1.0 : source_scale(h), ss,
+                         h->f32, h->stream);
   if (rc != 0) return fail(h, SG_ERR_DEVICE, "source kernel launch failed");
   return SG_OK;
 }
@@ -351,16 +374,20 @@ static int enqueue_step(sg_handle* h) {
     int rc = run_stage_impl(h, st, SG_REGION_ALL);
     if (rc != SG_OK) return rc;
   }
+  if (h->capture_src && launch_step_counter(h->src_ctr_d, 1, 1, h->stream) != 0)   // the next step's slice
+    return fail(h, SG_ERR_DEVICE, "step counter launch failed");
   return SG_OK;
 }
 
 // capture `steps` steps into an executable graph; on any failure graphs are switched off for the handle
-static hipGraphExec_t capture_steps(sg_handle* h, int steps) {
+static hipGraphExec_t capture_steps(sg_handle* h, int steps, bool with_src) {
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
   int rc = SG_OK;
+  h->capture_src = with_src;
   for (int k = 0; k < steps && rc == SG_OK; ++k) rc = enqueue_step(h);
+  h->capture_src = false;
   hipError_t e = hipStreamEndCapture(h->stream, &g);
   if (rc == SG_OK && e == hipSuccess && g) {
     if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr;
@@ -377,18 +404,25 @@ int sg_step(sg_handle* h, int64_t nsteps) {
     if (h->md.has_nbr[s]) return fail(h, SG_ERR_STATE, "sg_step on a block with neighbours: drive stages + halo from the host");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   int64_t k = 0;
-  // launch-bound blocks: replay captured graphs (no per-stage timing, no per-step source values)
-  const bool graphs = h->graph_ok && !h->timing && h->src_nnz == 0 && nsteps >= 2;
-  if (graphs && h->graph_epoch != h->epoch) {
+  // launch-bound blocks: replay captured graphs (no per-stage timing).  A source that is still active is part of the
+  // graphs: its launches take this step's slice and weight from a device-side step counter (kernels.hpp SrcStep),
+  // set here to the step the replay starts from; one that has run out (or none) gives graphs without source launches.
+  const bool graphs = h->graph_ok && !h->timing && nsteps >= 2;
+  const bool with_src = source_active(h) && h->src_ctr_d != nullptr;
+  if (graphs && source_active(h) && !with_src) return fail(h, SG_ERR_STATE, "source without a device-side step counter");
+  if (graphs && (h->graph_epoch != h->epoch || h->graph_src != with_src)) {
     if (h->graph1) (void)hipGraphExecDestroy(h->graph1);
     if (h->graph8) (void)hipGraphExecDestroy(h->graph8);
-    h->graph1 = capture_steps(h, 1);
-    h->graph8 = h->graph1 ? capture_steps(h, 8) : nullptr;
+    h->graph1 = capture_steps(h, 1, with_src);
+    h->graph8 = h->graph1 ? capture_steps(h, 8, with_src) : nullptr;
     h->graph_epoch = h->epoch;
+    h->graph_src = with_src;
     if (!h->graph1 || !h->graph8) h->graph_ok = false;  // same kernels, launched one by one below
   }
   HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
   if (graphs && h->graph_ok) {
+    if (with_src && launch_step_counter(h->src_ctr_d, h->src_step, 0, h->stream) != 0)
+      return fail(h, SG_ERR_DEVICE, "step counter launch failed");
     for (; k + 8 <= nsteps; k += 8) HIPCHECK(h, hipGraphLaunch(h->graph8, h->stream));
     for (; k < nsteps; ++k) HIPCHECK(h, hipGraphLaunch(h->graph1, h->stream));
     for (int st = 0; st < 6; ++st) h->counters.launches[st] += nsteps;

@@ -296,10 +296,7 @@ class ElasticLF4(object):
             raise MemoryError("the source can be non-zero at %d nodes over %d steps: its table would take %.1f GB; "
                               "too much for a per-step table, and the source does not factorise into w(t) * pattern(x)"
                               % (len(nz), nsteps, nsteps * len(nz) * d * d * 8 / 1e9))
-        values = np.zeros((nsteps, len(nz), d, d))
-        for k in range(nsteps):
-            expr.t = times[k]
-            values[k] = expr.evaluate(Xs)
+        values = expr.evaluate_times(Xs, times).reshape(nsteps, len(nz), d, d)
         expr.t = t_keep
         return nz, values, False
 
@@ -379,10 +376,7 @@ class ElasticLF4(object):
                 return None
             piv = np.unravel_index(np.abs(pattern).argmax(), pattern.shape)
             xp = Xs[piv[0]:piv[0] + 1]
-            w = np.empty(n)
-            for k in range(n):
-                expr.t = times[k]
-                w[k] = expr.evaluate(xp).reshape(d, d)[piv[1], piv[2]] / pattern[piv]
+            w = expr.evaluate_times(xp, times).reshape(n, d, d)[:, piv[1], piv[2]] / pattern[piv]
             rng = np.random.default_rng(0)
             for k in sorted(set(int(v) for v in rng.integers(0, n, size=6)) | {0, n - 1}):
                 expr.t = times[k]

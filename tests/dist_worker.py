@@ -17,8 +17,13 @@ def main():
     n = tuple(int(x) for x in sys.argv[4].split(","))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ.get("SEIGEN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
-    dist.init_process_group(os.environ.get("SEIGEN_DIST_BACKEND", "gloo"))
+    dev = int(os.environ.get("SEIGEN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("SEIGEN_DIST_BACKEND", "gloo")
+    if backend == "nccl":      # RCCL, one rank per GPU (tests/test_multigpu_gpu.py)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
 
     from seigen_amd.mesh import Partition
@@ -27,7 +32,7 @@ def main():
     part = Partition(n, rank, world, grid)
     el, u, s = run_case(n, degree, nsteps, part, source)
     np.savez(os.path.join(out, "rank%d.npz" % rank), u=u, s=s, start=np.array(part.start), n=np.array(part.n),
-             bytes_sent=el._exchanger.bytes_sent, staged=int(el._exchanger.staged))
+             bytes_sent=el._exchanger.bytes_sent, staged=int(el._exchanger.staged), device=dev)
     dist.barrier()
     dist.destroy_process_group()
 

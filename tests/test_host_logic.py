@@ -502,3 +502,24 @@ def test_traffic_digest_follows_the_kernel_sources(tmp_path):
     import bench
     d = bench.csrc_digest()
     assert len(d) == 64 and d == bench.csrc_digest()
+
+
+def test_expression_evaluate_times_equals_per_step_evaluation():
+    """The per-step source table (elastic.py:285-288: the source Expression re-interpolated before every step) is
+    built in one vectorised pass over all steps; element for element it must be what `evaluate` gives with `t` set
+    - box-limited Ricker source (explosive_source_lf4.py:36-40), a condition that depends on t, a moving support."""
+    from seigen_amd.expression import Expression
+    rng = np.random.default_rng(0)
+    X = rng.uniform([44.0, 148.0], [46.0, 150.0], size=(60, 2))
+    times = [1e-3 * (k + 1) for k in range(300)]
+    box = "x[0] >= 44.5 && x[0] <= 45.5 && x[1] >= 148.5 && x[1] <= 149.5"
+    code = "%s ? (-1.0 + 2*a*pow(t - 0.3, 2))*exp(-a*pow(t - 0.3, 2)) : 0.0" % box
+    cases = [Expression(((code, "0.0"), ("0.0", code)), a=159.42, t=0),
+             Expression("t > 0.1 && x[0] < 45 + t ? sin(x[1]*t) : (t < 0.05 ? 1.0 : 0.0)", t=0),
+             Expression(("x[0]*t", "cos(t)"), t=0)]
+    for e in cases:
+        for chunk in (1 << 22, 128):      # one pass, and many small chunks of rows
+            V = e.evaluate_times(X, times, max_elems=chunk)
+            for k in (0, 7, 150, 299):
+                e.t = times[k]
+                assert np.array_equal(V[k], e.evaluate(X))
