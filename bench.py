@@ -345,6 +345,9 @@ def halo_block(elastic, m, comm, backend):
     st = ex.stats()
     ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
     return {"transport": "host-staged/%s" % backend if ex.staged else backend,
+            # who drives the exchange: the library itself (csrc/comm.cpp: one C-ABI call per run of steps) or the
+            # Python exchanger stage by stage (seigen_amd/parallel.py)
+            "driver": "native" if getattr(ex, "native", False) else "python",
             "pack_ms_per_step": comm.gather((c1["halo_pack_ms"] - c0["halo_pack_ms"]) / nst),
             "bytes_sent_per_step": comm.gather((c1["halo_bytes_packed"] - c0["halo_bytes_packed"]) / nst),
             "exposed_wait_ms_per_step": comm.gather(st["exposed_wait_ms"] / nst),

@@ -199,7 +199,9 @@ int sg_set_source_box_ricker(sg_handle* h, const double* lo, const double* hi, d
 
 /* ---- the hot path ---------------------------------------------------------------- */
 /* whole steps (all six stages, source included); replaces the body of
- * ElasticLF4.run's while-loop (elastic.py:283-313). */
+ * ElasticLF4.run's while-loop (elastic.py:283-313).  A block with neighbours needs a communicator
+ * (sg_comm_init): the exchanges then run inside this call; without one, drive stages and halo from the host
+ * (sg_run_stage + sg_halo_pack_sides + your transport). */
 int sg_step(sg_handle* h, int64_t nsteps);
 /* one fused stage over a region (multi-block overlap and stage-level tests). */
 int sg_run_stage(sg_handle* h, int stage, int region);
@@ -226,6 +228,29 @@ int sg_halo_pack(sg_handle* h, int field, int side, void* dev_out);
 /* the same for several sides in ONE launch: dev_out[side] = send buffer of that side or NULL, 6 entries */
 int sg_halo_pack_sides(sg_handle* h, int field, void* const* dev_out);
 int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in);
+/* ---- native exchange over RCCL (csrc/comm.cpp) --------------------------------------------
+ * The reference's halo exchange is implicit in every assemble (elastic.py:364; set-up :404-436).  With a
+ * communicator attached, sg_step on a block with neighbours runs the whole pipelined schedule itself - per stage
+ * FIRST, pack, grouped ncclSend/ncclRecv with the face neighbours on the handle's stream, SECOND beside them -
+ * for all six stages of all `nsteps` steps without returning to the caller; the handle owns the send / receive
+ * buffers.  One process per GPU: every rank of the block grid calls sg_comm_init (collective) with the SAME unique
+ * id - made by one rank with sg_comm_get_unique_id and distributed by whatever the host has (MPI_Bcast in the
+ * reference's world, torch.distributed here) - its rank, the number of ranks, and per block side the rank of the
+ * face neighbour (-1: none; must agree with sg_config::nbr_mask). */
+#define SG_COMM_ID_BYTES 128
+typedef struct sg_comm_stats {
+  int64_t exchanges;        /* grouped send/receive calls issued */
+  int64_t bytes_sent;       /* bytes handed to RCCL */
+  double exposed_wait_ms;   /* timing enabled: time the receives lasted beyond the SECOND launch beside them */
+} sg_comm_stats_t;
+int sg_comm_get_unique_id(void* id, size_t nbytes);
+int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nranks, const int32_t* peers);
+int sg_comm_finalize(sg_handle* h);
+int sg_comm_get_stats(sg_handle* h, sg_comm_stats_t* out, int reset);
+/* one exchange of `field`'s traces on its own (tests), and the device addresses of a side's buffers */
+int sg_comm_exchange(sg_handle* h, int field);
+int sg_comm_buffers(sg_handle* h, int kind, int side, void** send, void** recv, size_t* nbytes);
+
 /* Symmetric-stress storage is left automatically when THIS block is handed a
  * non-symmetric stress or source; blocks of one mesh must agree, so the host layer reads the
  * state of every block (sg_get_sym) and makes all of them leave together (sg_leave_sym). */

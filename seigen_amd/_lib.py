@@ -28,6 +28,13 @@ class SgInfo(C.Structure):
                 ("u_dofs", C.c_int64), ("s_dofs", C.c_int64), ("halo_faces", C.c_int32 * 6)]
 
 
+class SgCommStats(C.Structure):
+    _fields_ = [("exchanges", C.c_int64), ("bytes_sent", C.c_int64), ("exposed_wait_ms", C.c_double)]
+
+
+COMM_ID_BYTES = 128
+
+
 class SgCounters(C.Structure):
     _fields_ = [("kernel_ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("steps", C.c_int64),
                 ("halo_pack_ms", C.c_double), ("halo_pack_launches", C.c_int64), ("halo_bytes_packed", C.c_int64)]
@@ -65,6 +72,12 @@ SYMBOLS = {
     "sg_halo_pack": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sg_halo_pack_sides": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "sg_halo_attach": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "sg_comm_get_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "sg_comm_init": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "sg_comm_finalize": (C.c_int, [_P]),
+    "sg_comm_get_stats": (C.c_int, [_P, C.POINTER(SgCommStats), C.c_int]),
+    "sg_comm_exchange": (C.c_int, [_P, C.c_int]),
+    "sg_comm_buffers": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "sg_get_sym": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "sg_leave_sym": (C.c_int, [_P]),
     "sg_enable_timing": (C.c_int, [_P, C.c_int]),

@@ -10,6 +10,13 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def comm_unique_id():
+    """A fresh RCCL unique id (bytes) for sg_comm_init: made on one rank, handed to all ranks of the block grid."""
+    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    check(_lib.load().sg_comm_get_unique_id(buf, _lib.COMM_ID_BYTES))
+    return bytes(buf.raw)
+
+
 class HipBlock(object):
     def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None, dtype="f64"):
         self.lib = _lib.load()
@@ -219,6 +226,30 @@ class HipBlock(object):
         """ptrs: {side: device pointer}; every listed side in one launch."""
         arr = (C.c_void_p * 6)(*[C.c_void_p(ptrs.get(s)) if ptrs.get(s) else None for s in range(6)])
         check(self.lib.sg_halo_pack_sides(self.h, int(field), arr), self.h)
+
+    # ---- native exchange over RCCL (csrc/comm.cpp): step() then runs the whole pipelined schedule in the library
+    def comm_init(self, unique_id, rank, nranks, peers):
+        """peers: rank of the face neighbour per block side (2 * axis + hi), -1 / None where there is none."""
+        arr = (C.c_int32 * 6)(*[(-1 if (i >= len(peers) or peers[i] is None) else int(peers[i])) for i in range(6)])
+        buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        _lib.check(self.lib.sg_comm_init(self.h, buf, _lib.COMM_ID_BYTES, int(rank), int(nranks), arr), self.h)
+
+    def comm_finalize(self):
+        _lib.check(self.lib.sg_comm_finalize(self.h), self.h)
+
+    def comm_stats(self, reset=False):
+        st = _lib.SgCommStats()
+        _lib.check(self.lib.sg_comm_get_stats(self.h, C.byref(st), 1 if reset else 0), self.h)
+        return {"exchanges": int(st.exchanges), "bytes_sent": int(st.bytes_sent), "exposed_wait_ms": float(st.exposed_wait_ms)}
+
+    def comm_exchange(self, field):
+        _lib.check(self.lib.sg_comm_exchange(self.h, field), self.h)
+
+    def comm_buffers(self, kind, side):
+        """(send pointer, receive pointer, bytes) of a side's device buffers; kind 0: velocity-like, 1: stress-like."""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _lib.check(self.lib.sg_comm_buffers(self.h, kind, side, C.byref(a), C.byref(b), C.byref(n)), self.h)
+        return a.value, b.value, n.value
 
     def halo_attach(self, field, side, dev_ptr):
         check(self.lib.sg_halo_attach(self.h, field, side, C.c_void_p(dev_ptr)), self.h)

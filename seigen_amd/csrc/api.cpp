@@ -59,6 +59,7 @@ void sg_destroy(sg_handle* h) {
   for (int f = 0; f < 4; ++f)
     if (h->field[f]) (void)hipFree(h->field[f]);
   if (h->md_dev) (void)hipFree(h->md_dev);
+  comm_release(h);
   if (h->mk_dev) (void)hipFree(h->mk_dev);
   if (h->err_word) (void)hipHostFree(h->err_word);
   if (h->nbr_tab) (void)hipFree(h->nbr_tab);

@@ -22,8 +22,11 @@
 
 using namespace sg;
 
+struct sg_comm_state;   // comm.cpp: RCCL communicator, peers and halo buffers of the native exchange
+
 struct sg_handle {
   sg_config cfg;
+  sg_comm_state* comm = nullptr;
   RefElem re;
   MeshDev md;
   MeshDev* md_dev = nullptr;
@@ -199,3 +202,6 @@ inline void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) 
   region_boxes(h->cfg.dim, h->cfg.n, h->md.has_nbr, region, out, shell_width_x(h->md.gw));
 }
 int resolve_timing(sg_handle* h);
+// comm.cpp
+int comm_step(sg_handle* h, int64_t nsteps);
+void comm_release(sg_handle* h);

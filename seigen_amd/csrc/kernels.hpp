@@ -151,6 +151,7 @@ struct StageArgs {
   const double* src_vals;
   double src_scale;          // factor on src_vals (a separable source's weight of this step, else 1)
   SrcStep src_step;          // graph replay: slice and weight from the device-side step counter (ctr != null)
+  int32_t src_bump;          // 2-D tile path, first stage of a step (an F stage): bump that counter (one thread)
 };
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)

@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   const R* aux = reinterpret_cast<const R*>(A.aux);
   R* out = reinterpret_cast<R*>(A.out);
 
+  // graph replay with a source: the first stage of a step names the step (kernels.hpp SrcStep; the stages that read
+  // the counter - the G stages - run strictly before and after this launch, never beside it)
+  if (KIND == 0 && A.src_bump != 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    int64_t* ctr = const_cast<int64_t*>(A.src_step.ctr);
+    *ctr = *ctr + 1;
+  }
   const bool listed = A.item_list != nullptr;  // a region of a split stage: its active items (stages.cpp)
   const int nitems = listed ? A.nlist : C.ngroups * NCLS;
   // one contiguous item range per XCD label (blocks with equal blockIdx % 8 share an L2); ranges start on

@@ -129,6 +129,11 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.c_self = c_self;
   a.c_aux = c_aux;
   a.c_new = c_new;
+  if (kind == 0 && in_f == SG_FIELD_S && mode == 0 && h->capture_src && h->src_fused) {
+    // stage UH1 of a captured step on the tile path: the launch that opens the step also names it
+    a.src_step = source_stepper(h);
+    a.src_bump = 1;
+  }
   if (with_source && h->src_fused && h->capture_src) {     // ... of the step the device-side counter names
     a.src_slot = h->src_slot_d;
     a.src_idx = h->src_idx_d;
@@ -374,7 +379,8 @@ static int enqueue_step(sg_handle* h) {
     int rc = run_stage_impl(h, st, SG_REGION_ALL);
     if (rc != SG_OK) return rc;
   }
-  if (h->capture_src && launch_step_counter(h->src_ctr_d, 1, 1, h->stream) != 0)   // the next step's slice
+  // the next step's slice (tile path: stage UH1 bumps the counter itself, run_op)
+  if (h->capture_src && !h->src_fused && launch_step_counter(h->src_ctr_d, 1, 1, h->stream) != 0)
     return fail(h, SG_ERR_DEVICE, "step counter launch failed");
   return SG_OK;
 }
@@ -400,9 +406,13 @@ static hipGraphExec_t capture_steps(sg_handle* h, int steps, bool with_src) {
 int sg_step(sg_handle* h, int64_t nsteps) {
   if (!h || nsteps < 0) return SG_ERR_ARG;
   if (!h->params_set) return fail(h, SG_ERR_STATE, "sg_set_params must be called before stepping");
-  for (int s = 0; s < 6; ++s)
-    if (h->md.has_nbr[s]) return fail(h, SG_ERR_STATE, "sg_step on a block with neighbours: drive stages + halo from the host");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
+  for (int s = 0; s < 6; ++s)
+    if (h->md.has_nbr[s]) {
+      if (h->comm) return comm_step(h, nsteps);     // the native exchange (comm.cpp)
+      return fail(h, SG_ERR_STATE, "sg_step on a block with neighbours: attach a communicator (sg_comm_init) or drive "
+                                   "stages + halo from the host");
+    }
   int64_t k = 0;
   // launch-bound blocks: replay captured graphs (no per-stage timing).  A source that is still active is part of the
   // graphs: its launches take this step's slice and weight from a device-side step counter (kernels.hpp SrcStep),
@@ -421,7 +431,8 @@ int sg_step(sg_handle* h, int64_t nsteps) {
   }
   HIPCHECK(h, hipEventRecord(h->ev0, h->stream));
   if (graphs && h->graph_ok) {
-    if (with_src && launch_step_counter(h->src_ctr_d, h->src_step, 0, h->stream) != 0)
+    // (tile path: the counter is bumped by the launch that OPENS a step, so it starts one short)
+    if (with_src && launch_step_counter(h->src_ctr_d, h->src_step - (h->src_fused ? 1 : 0), 0, h->stream) != 0)
       return fail(h, SG_ERR_DEVICE, "step counter launch failed");
     for (; k + 8 <= nsteps; k += 8) HIPCHECK(h, hipGraphLaunch(h->graph8, h->stream));
     for (; k < nsteps; ++k) HIPCHECK(h, hipGraphLaunch(h->graph1, h->stream));

@@ -29,7 +29,7 @@ from . import _lib
 from .backend import HipBlock
 from .functionspace import Function, FunctionSpace, TensorFunctionSpace, VectorFunctionSpace
 from .helpers import log, allreduce_sum
-from .parallel import world, HaloExchanger
+from .parallel import world, HaloExchanger, NativeExchanger
 from .profiling import timed_region
 
 _SOLVER_MODES = ("implicit", "explicit", "parloop", "fusion", "tiling", "hip")
@@ -245,7 +245,13 @@ class ElasticLF4(object):
             if self.mesh.partition.world > 1 and self._exchanger is None:
                 import torch
                 dev = torch.device("cuda", _device_for_rank())
-                self._exchanger = HaloExchanger(self._block, self.mesh.partition, dev, stream=self._torch_stream)
+                import torch.distributed as dist
+                native = dist.get_backend() == "nccl" and os.environ.get("SEIGEN_HALO_NATIVE", "1") != "0" \
+                    and os.environ.get("SEIGEN_HALO_SCHEDULE", "pipelined") != "plain"
+                if native:      # the exchange inside the library: one C-ABI call per run of steps (csrc/comm.cpp)
+                    self._exchanger = NativeExchanger(self._block, self.mesh.partition)
+                else:           # driven from here stage by stage (gloo / host-staged transports, the plain schedule)
+                    self._exchanger = HaloExchanger(self._block, self.mesh.partition, dev, stream=self._torch_stream)
 
     @property
     def loop_context(self):

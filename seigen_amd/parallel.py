@@ -60,6 +60,49 @@ def world():
     return dist.get_rank(), dist.get_world_size()
 
 
+class NativeExchanger(object):
+    """The exchange inside the library (csrc/comm.cpp): one RCCL communicator per block grid, created from a unique
+    id that rank 0 makes and the default process group broadcasts; `step` is ONE call into the C-ABI that runs every
+    stage, pack, grouped ncclSend/ncclRecv and SECOND launch of all the steps (the reference's exchange is as
+    implicit: elastic.py:364).  Same surface as HaloExchanger as far as ElasticLF4 and bench.py use it."""
+    staged = False
+    native = True
+
+    def __init__(self, block, partition, group=None):
+        import torch
+        import torch.distributed as dist
+        from .backend import comm_unique_id
+        self.block, self.part = block, partition
+        self.sides = [s for s in range(2 * partition.dim) if partition.neighbour(s) is not None]
+        rank, nranks = dist.get_rank(group), dist.get_world_size(group)
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        block.comm_init(box[0], rank, nranks, [partition.neighbour(s) for s in range(2 * partition.dim)])
+        self._sent0 = 0
+        self.timing = False
+
+    @property
+    def bytes_sent(self):
+        return self.block.comm_stats()["bytes_sent"]
+
+    def reset_stats(self, timing=False):
+        self.timing = bool(timing)
+        self.block.comm_stats(reset=True)
+
+    def stats(self):
+        st = self.block.comm_stats()
+        return {"exposed_wait_ms": st["exposed_wait_ms"], "exchanges": st["exchanges"], "bytes_sent": st["bytes_sent"],
+                "host_blocked_ms": 0.0}
+
+    def step(self, nsteps=1):
+        if int(nsteps) > 0:
+            self.block.step(int(nsteps))
+
+    def step_unpipelined(self, nsteps=1):
+        raise RuntimeError("the native exchange runs the pipelined schedule only (SEIGEN_HALO_NATIVE=0 for the "
+                           "host-driven exchanger and its plain schedule)")
+
+
 class HaloExchanger(object):
     """Per-stage trace exchange for one block.
 

@@ -134,6 +134,20 @@ def test_rccl_transport_on_one_rank(gpu):
     assert r.stdout.count("rccl self-exchange ok") == 2, r.stdout
 
 
+def test_native_rccl_exchange_on_one_rank(gpu):
+    """The exchange inside the library (csrc/comm.cpp: sg_comm_init, then sg_step runs stages, packs and grouped
+    ncclSend / ncclRecv for all steps in one call) on the test box's single GPU, bitwise against the host-driven
+    exchanger (tests/rccl_native_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("SEIGEN_DIST_BACKEND", "SEIGEN_HIP_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "rccl_native_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("native rccl exchange ok") == 2, r.stdout
+
+
 def test_bench_one_rank_under_torchrun_with_rccl(gpu):
     """bench.py as the driver launches it for N > 1, with the RCCL process group really initialised
     (a world of one rank: collectives and the reductions of the line run over RCCL)."""

@@ -64,6 +64,35 @@ def main():
               "for traces, %.1f MB sent per step" % (grid_env or "480 (default)", dt, st["exposed_wait_ms"] / steps,
                                                     st["bytes_sent"] / steps / 1e6), flush=True)
         blk.close()
+    # the same schedule driven from inside the library (csrc/comm.cpp): one sg_step call for all the steps
+    from seigen_amd.backend import comm_unique_id
+    for grid_env in ((None, "512", "496")[:int(os.environ.get("SEIGEN_BENCH_GRIDS", "3"))] if not grids else tuple(grids.split(","))):
+        if grid_env:
+            os.environ["SEIGEN_HIP_GRID_BLOCKS"] = grid_env
+        else:
+            os.environ.pop("SEIGEN_HIP_GRID_BLOCKS", None)
+        part = SelfNeighbour(n, 0, 1)
+        blk = HipBlock(3, P, n, h, [0.0] * 3, "left", part.nbr_mask)
+        blk.set_params(1.0, 0.5 / 64 / 8, 0.5, 0.25)
+        layer = 64 * 64 * 6
+        u = rng.uniform(-1, 1, (layer,) + blk.field_shape(_lib.FIELD_U)[1:]) * 1e-3
+        for k in range(64):
+            blk.set_field_range(_lib.FIELD_U, k * layer, u)
+        blk.comm_init(comm_unique_id(), 0, 1, [None, None, None, None, 0, 0])
+        blk.step(3)
+        blk.sync()
+        blk.comm_stats(reset=True)
+        blk.enable_timing(True)
+        t0 = time.perf_counter()
+        blk.step(steps)
+        blk.sync()
+        dt = (time.perf_counter() - t0) / steps * 1e3
+        st = blk.comm_stats()
+        blk.enable_timing(False)
+        print("NATIVE exchange (csrc/comm.cpp), z+- neighbours over RCCL (self), persistent grid %s blocks while exchanging: %.3f ms/step, "
+              "receives lasted %.3f ms/step beyond SECOND, %.1f MB sent per step"
+              % (grid_env or "480 (default)", dt, st["exposed_wait_ms"] / steps, st["bytes_sent"] / steps / 1e6), flush=True)
+        blk.close()
     os.environ.pop("SEIGEN_HIP_GRID_BLOCKS", None)
     blk = HipBlock(3, P, n, h, [0.0] * 3)
     blk.set_params(1.0, 0.5 / 64 / 8, 0.5, 0.25)
