@@ -78,7 +78,7 @@ def fill_initial_condition(elastic, dt):
     for k in range(nz):
         cfg = block_config(mesh, elastic.degree)
         cfg.n[2] = 1
-        cfg.origin[2] = mesh.origin[2] + (part.start[2] + k) * mesh.h[2]
+        cfg.cube0[2] = part.start[2] + k
         X = np.empty((cells_per_layer, blk.nd, 3))
         _lib.check(lib.sg_block_node_coords(C.byref(cfg), elastic.degree, X.ctypes.data, X.nbytes))
         u, T = eigenmode3d_fields(X, 0.0, dt / 2.0)
@@ -350,7 +350,10 @@ def halo_block(elastic, m, comm, backend):
             "driver": "native" if getattr(ex, "native", False) else "python",
             "pack_ms_per_step": comm.gather((c1["halo_pack_ms"] - c0["halo_pack_ms"]) / nst),
             "bytes_sent_per_step": comm.gather((c1["halo_bytes_packed"] - c0["halo_bytes_packed"]) / nst),
+            # everything a stage waited for its traces (same definition as the round-1/2 records) ...
             "exposed_wait_ms_per_step": comm.gather(st["exposed_wait_ms"] / nst),
+            # ... and the transport's share of it (host-staged: without the wait for the rank's own launch and copies)
+            "exposed_wait_transport_ms_per_step": comm.gather(st.get("exposed_wait_transport_ms", st["exposed_wait_ms"]) / nst),
             "host_blocked_ms_per_step": comm.gather(st.get("host_blocked_ms", 0.0) / nst),
             "exchanges_per_step": st["exchanges"] / nst,
             # split stages count once, with the longer of their two concurrent launches (sg_get_counters)

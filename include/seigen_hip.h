@@ -77,7 +77,7 @@ typedef struct sg_config {
   int32_t degree;    /* 1..4               (ElasticLF4.create(..., degree)) */
   int32_t n[3];      /* squares / cubes per axis in THIS block */
   double h[3];       /* cell size per axis */
-  double origin[3];  /* physical coordinate of the block's low corner */
+  double origin[3];  /* physical coordinate of the block's low corner (of cube -cube0, see below) */
   int32_t diagonal;  /* 2-D only: 0 = "left" (Firedrake default), 1 = "right": how each square is cut into two
                         triangles; 2 = not at all: quadrilateral cells with the tensor-product element DQ_k, what
                         FunctionSpace(mesh, "DG", k) (elastic.py:81-82) is on a quadrilateral mesh */
@@ -89,6 +89,13 @@ typedef struct sg_config {
                         tile kernels; SG_ERR_ARG elsewhere: 1-D blocks, forced generic / lane kernels).  The C-ABI
                         keeps double on the host side in both modes; halo buffers hold the device type. */
   void* stream;      /* hipStream_t to launch on, or NULL for the handle's own stream */
+  int32_t cube0[3];  /* index of the block's first square / cube counted from `origin` (0: origin is the block's own low
+                        corner).  Node coordinates are origin + (cube0 + cube + lattice) * h with the integers added
+                        first: a block of a partitioned mesh, or a slab / sub-box of a block evaluated on its own
+                        (sg_block_node_coords), given the MESH's origin and its integer offset, gets bit for bit the
+                        coordinates the whole mesh gets - a source box whose faces lie on node lines
+                        (explosive_source_lf4.py:36-38) then selects the same nodes under every partition. */
+  int32_t pad_;
 } sg_config;
 
 typedef struct sg_info {

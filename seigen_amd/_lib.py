@@ -19,7 +19,7 @@ class SgConfig(C.Structure):
     _fields_ = [("dim", C.c_int32), ("degree", C.c_int32), ("n", C.c_int32 * 3),
                 ("h", C.c_double * 3), ("origin", C.c_double * 3),
                 ("diagonal", C.c_int32), ("nbr_mask", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("cube0", C.c_int32 * 3), ("pad_", C.c_int32)]
 
 
 class SgInfo(C.Structure):

@@ -18,7 +18,10 @@ def comm_unique_id():
 
 
 class HipBlock(object):
-    def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None, dtype="f64"):
+    def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None, dtype="f64",
+                 cube0=None):
+        """origin: the block's low corner - or, with `cube0` (the block's first cube counted from there), the origin
+        of the whole mesh: node coordinates are then bitwise those of the unpartitioned mesh (sg_config::cube0)."""
         self.lib = _lib.load()
         if dtype not in ("f64", "f32"):
             raise ValueError("dtype must be 'f64' or 'f32'")
@@ -30,6 +33,7 @@ class HipBlock(object):
             cfg.n[a] = int(n[a]) if a < dim else 1
             cfg.h[a] = float(h[a]) if a < dim else 1.0
             cfg.origin[a] = float(origin[a]) if a < dim else 0.0
+            cfg.cube0[a] = int(cube0[a]) if (cube0 is not None and a < dim) else 0
         cfg.diagonal = {"left": 0, "right": 1, "quadrilateral": 2}[diagonal]   # 2: the squares are the cells
         cfg.nbr_mask = int(nbr_mask)
         cfg.device = int(device)

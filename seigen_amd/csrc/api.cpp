@@ -127,6 +127,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     h->cfg.n[a] = 1;
     h->cfg.h[a] = 1.0;
     h->cfg.origin[a] = 0.0;
+    h->cfg.cube0[a] = 0;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -428,7 +429,7 @@ struct NodeGeom {
   void node(const int c[3], int k, int a, double x[3]) const {
     double X[4][3];
     for (int v = 0; v <= d; ++v)
-      for (int i = 0; i < d; ++i) X[v][i] = cfg->origin[i] + (double)(c[i] + off[k][v][i]) * cfg->h[i];
+      for (int i = 0; i < d; ++i) X[v][i] = cfg->origin[i] + (double)(cfg->cube0[i] + c[i] + off[k][v][i]) * cfg->h[i];
     for (int i = 0; i < d; ++i) {
       double xv = X[0][i];
       for (int m = 0; m < d; ++m) xv += (X[m + 1][i] - X[0][i]) * ((double)lat[a * d + m] / (double)degree);
@@ -750,8 +751,8 @@ int sg_set_source_box_ricker(sg_handle* h, const double* lo, const double* hi, d
   int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
   for (int i = 0; i < d; ++i) {
     if (!(lo[i] <= hi[i])) return fail(h, SG_ERR_ARG, "source box: lo must not exceed hi");
-    const double t0c = std::floor((lo[i] - h->cfg.origin[i]) / h->cfg.h[i]) - 1.0;
-    const double t1c = std::floor((hi[i] - h->cfg.origin[i]) / h->cfg.h[i]) + 1.0;
+    const double t0c = std::floor((lo[i] - h->cfg.origin[i]) / h->cfg.h[i]) - (double)h->cfg.cube0[i] - 1.0;
+    const double t1c = std::floor((hi[i] - h->cfg.origin[i]) / h->cfg.h[i]) - (double)h->cfg.cube0[i] + 1.0;
     c0[i] = (int)std::max(0.0, std::min(t0c, (double)h->cfg.n[i]));
     c1[i] = (int)std::max(-1.0, std::min(t1c, (double)h->cfg.n[i] - 1.0));
   }

@@ -298,8 +298,9 @@ int resolve_timing(sg_handle* h) {
       if (h->first_ms_pending[st] >= 0) h->counters.kernel_ms[st] += h->first_ms_pending[st];  // a FIRST without SECOND
       h->first_ms_pending[st] = ms;
     } else if (id & 32) {
+      // (a SECOND whose FIRST was not timed - timing switched on between the two - counts with its own time)
       const double f = h->first_ms_pending[st];
-      h->counters.kernel_ms[st] += (f > ms ? f : (double)ms);
+      h->counters.kernel_ms[st] += (f >= 0 && f > ms) ? f : (double)ms;
       h->first_ms_pending[st] = -1;
     } else {
       h->counters.kernel_ms[st] += ms;
@@ -606,7 +607,7 @@ int sg_region_boxes(const sg_config* cfg, int region, int32_t* boxes, int max_bo
   for (int a = 0; a < cfg->dim; ++a) n[a] = cfg->n[a];
   for (int s2 = 0; s2 < 2 * cfg->dim; ++s2) has_nbr[s2] = (cfg->nbr_mask >> s2) & 1;
   std::vector<Box> out;
-  region_boxes(cfg->dim, n, has_nbr, region, out, shell_width_x(choose_kernel_path(*cfg).gw));
+  region_boxes(cfg->dim, n, has_nbr, region, out, shell_width_x(choose_kernel_path(*cfg).gw, n[0], has_nbr[0] != 0, has_nbr[1] != 0));
   int cnt = 0;
   for (const Box& b : out) {
     if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;

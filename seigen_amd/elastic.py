@@ -140,10 +140,10 @@ class ElasticLF4(object):
     # ---- device block ---------------------------------------------------------------------
     def _create_block(self):
         part = self.mesh.partition
-        origin = [self.mesh.origin[a] + part.start[a] * self.mesh.h[a] for a in range(self.mesh.dim)]
-        block = HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, origin,
+        # the mesh's origin + the block's integer offset: coordinates bitwise those of the unpartitioned mesh
+        block = HipBlock(self.mesh.dim, self.degree, part.n, self.mesh.h, list(self.mesh.origin),
                          "quadrilateral" if self.mesh.quadrilateral else self.mesh.diagonal,
-                         part.nbr_mask, device=_device_for_rank(), dtype=self.dtype)
+                         part.nbr_mask, device=_device_for_rank(), dtype=self.dtype, cube0=list(part.start))
         self._torch_stream = None
         if part.world > 1:
             # One process per GPU: the library's launch stream, wrapped for torch, is made current
@@ -333,7 +333,7 @@ class ElasticLF4(object):
         cfg = block_config(mesh, self.degree)
         for a in range(d):
             cfg.n[a] = rng[a][1]
-            cfg.origin[a] = mesh.origin[a] + (part.start[a] + rng[a][0]) * mesh.h[a]
+            cfg.cube0[a] = part.start[a] + rng[a][0]      # integer offset: the coordinates of the full scan, bit for bit
         nsub = int(np.prod([r[1] for r in rng])) * ncls
         X = np.empty((nsub, self.S.nd, d))
         _lib.check(_lib.load().sg_block_node_coords(C.byref(cfg), self.degree, X.ctypes.data, X.nbytes))

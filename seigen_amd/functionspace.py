@@ -31,7 +31,8 @@ def block_config(mesh, degree=1, device=0):
         if a < mesh.dim:
             cfg.n[a] = part.n[a]
             cfg.h[a] = mesh.h[a]
-            cfg.origin[a] = mesh.origin[a] + part.start[a] * mesh.h[a]
+            cfg.origin[a] = mesh.origin[a]
+            cfg.cube0[a] = part.start[a]
         else:
             cfg.n[a], cfg.h[a], cfg.origin[a] = 1, 1.0, 0.0
     cfg.diagonal = 2 if mesh.quadrilateral else (1 if mesh.diagonal == "right" else 0)
@@ -108,7 +109,7 @@ class FunctionSpace(object):
             nl = min(layers, part.n[d - 1] - k0)
             cfg = block_config(mesh, min(self.degree, 4))
             cfg.n[d - 1] = nl
-            cfg.origin[d - 1] = mesh.origin[d - 1] + (part.start[d - 1] + k0) * mesh.h[d - 1]
+            cfg.cube0[d - 1] = part.start[d - 1] + k0
             X = np.empty((per_layer * nl, self.nd, d))
             _lib.check(lib.sg_block_node_coords(C.byref(cfg), self.degree, X.ctypes.data, X.nbytes))
             yield k0 * per_layer, X

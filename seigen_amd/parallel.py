@@ -91,8 +91,8 @@ class NativeExchanger(object):
 
     def stats(self):
         st = self.block.comm_stats()
-        return {"exposed_wait_ms": st["exposed_wait_ms"], "exchanges": st["exchanges"], "bytes_sent": st["bytes_sent"],
-                "host_blocked_ms": 0.0}
+        return {"exposed_wait_ms": st["exposed_wait_ms"], "exposed_wait_transport_ms": st["exposed_wait_ms"],
+                "exchanges": st["exchanges"], "bytes_sent": st["bytes_sent"], "host_blocked_ms": 0.0}
 
     def step(self, nsteps=1):
         if int(nsteps) > 0:
@@ -178,8 +178,14 @@ class HaloExchanger(object):
 
     def stats(self):
         self._resolve_wait_events()
-        return {"exposed_wait_ms": self._wait_dev_ms + 1e3 * self._wait_host_s, "exchanges": self.exchanges,
-                "bytes_sent": self.bytes_sent, "host_blocked_ms": 1e3 * self._host_blocked_s}
+        # exposed_wait_ms keeps the definition of the round-1/2 records: everything the consumer waited for an
+        # exchange - on the stream with a device-aware transport, on the host (copy-out synchronisation included)
+        # with the host-staged one.  exposed_wait_transport_ms is the part that belongs to the transport alone
+        # (host-staged: the send / receive wait without the wait for this rank's own FIRST launch and copies).
+        host_staged = self.staged or self.stream is None
+        return {"exposed_wait_ms": self._wait_dev_ms + 1e3 * (self._host_blocked_s if host_staged else self._wait_host_s),
+                "exposed_wait_transport_ms": self._wait_dev_ms + 1e3 * self._wait_host_s,
+                "exchanges": self.exchanges, "bytes_sent": self.bytes_sent, "host_blocked_ms": 1e3 * self._host_blocked_s}
 
     def start(self, field):
         """Pack the block-side traces of `field` and post the sends / receives."""
