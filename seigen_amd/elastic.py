@@ -249,8 +249,19 @@ class ElasticLF4(object):
                 native = dist.get_backend() == "nccl" and os.environ.get("SEIGEN_HALO_NATIVE", "1") != "0" \
                     and os.environ.get("SEIGEN_HALO_SCHEDULE", "pipelined") != "plain"
                 if native:      # the exchange inside the library: one C-ABI call per run of steps (csrc/comm.cpp)
-                    self._exchanger = NativeExchanger(self._block, self.mesh.partition)
-                else:           # driven from here stage by stage (gloo / host-staged transports, the plain schedule)
+                    # every rank must end up on the same path: agree on whether the communicator came up everywhere
+                    try:
+                        ex, failed = NativeExchanger(self._block, self.mesh.partition), 0
+                    except Exception as e:      # noqa: BLE001 - whatever it was, the host-driven exchanger still works
+                        ex, failed = None, 1
+                        log("native halo exchange unavailable on this rank (%r): falling back to the host-driven one" % (e,))
+                    if allreduce_sum(failed) > 0:
+                        if ex is not None:
+                            self._block.comm_finalize()
+                        native = False
+                    else:
+                        self._exchanger = ex
+                if not native:  # driven from here stage by stage (gloo / host-staged transports, the plain schedule)
                     self._exchanger = HaloExchanger(self._block, self.mesh.partition, dev, stream=self._torch_stream)
 
     @property
