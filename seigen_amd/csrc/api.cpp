@@ -62,6 +62,8 @@ void sg_destroy(sg_handle* h) {
   comm_release(h);
   if (h->mk_dev) (void)hipFree(h->mk_dev);
   if (h->err_word) (void)hipHostFree(h->err_word);
+  if (h->fragQ) (void)hipFree(h->fragQ);
+  if (h->fragP) (void)hipFree(h->fragP);
   if (h->nbr_tab) (void)hipFree(h->nbr_tab);
   if (h->Dt) (void)hipFree(h->Dt);
   if (h->Lt) (void)hipFree(h->Lt);
@@ -267,6 +269,21 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragF, fF.data(), fF.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragG, fG.data(), fG.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
+    // factorised G volume (mfma_tables.hpp): D_r = P_r Q
+    const char* gq = std::getenv("SEIGEN_HIP_GQ");
+    if (h->use_mfma && cfg->degree >= 3 && (gq ? std::atoi(gq) != 0 : SG_GQ_DEFAULT != 0)) {
+      std::vector<double> fQ, fP;
+      try {
+        fQ = mfma_frags_Q(h->re);
+        fP = mfma_frags_P(h->re);
+      } catch (const std::exception& e) {
+        return fail(h, SG_ERR_ARG, e.what());
+      }
+      HIPCHECK(h, hipMalloc((void**)&h->fragQ, fQ.size() * sizeof(double)));
+      HIPCHECK(h, hipMalloc((void**)&h->fragP, fP.size() * sizeof(double)));
+      HIPCHECK(h, hipMemcpy(h->fragQ, fQ.data(), fQ.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHECK(h, hipMemcpy(h->fragP, fP.data(), fP.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   if (h->use_mfma || h->use_lane || h->use_tile) {
     // symmetric-stress mode: fields start at zero, g only produces symmetric tensors;

@@ -48,6 +48,10 @@ struct sg_handle {
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
+  // G stages with the factorised volume term (kernels_mfma.hip mfma_stage_GQ; double, degrees 3 and 4;
+  // SEIGEN_HIP_GQ): the Q tiles and the P_r tiles, or null
+  double* fragQ = nullptr;
+  double* fragP = nullptr;
   double* staging = nullptr;  // host-layout staging buffer for layout conversion
   // large transfers: two pinned host slots + two device slots, so that the DMA of one chunk, the
   // layout kernel of the next and the host-side copy of the previous one overlap

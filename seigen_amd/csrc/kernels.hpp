@@ -30,6 +30,9 @@ struct ElemDims {
 // (tools/wave_sim.py, profiles/r03/kernel_experiments.txt) - the lesson of the 2-D tile kernels' T2Const.
 constexpr int MK_KSF = 4;     // facet k-steps at degree 4 (15 facet nodes)
 constexpr int MK_KS = 9;      // volume k-steps at degree 4 (35 nodes)
+#ifndef SG_GQ_DEFAULT
+#define SG_GQ_DEFAULT 0       // G stages with the factorised volume term (mfma_stage_GQ) unless SEIGEN_HIP_GQ says otherwise
+#endif
 #ifndef SG_TEAM_DEFAULT
 #define SG_TEAM_DEFAULT 0     // waves per team of the trace-sharing F kernels unless SEIGEN_HIP_TEAM says otherwise
 #endif
@@ -110,6 +113,7 @@ struct StageArgs {
   int32_t tensor;          // generic path: quadrilateral cells (ElemDims<2, P, 1>)
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
+  const double* fragQ;     // MFMA path, G stages with the factorised volume term (mfma_stage_GQ): the Q tiles; fragV = the P_r tiles
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null
   const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
   const double* sponge_B;      // [slot][nd(a)][nd(b)]

@@ -65,13 +65,23 @@ struct MG {
   static constexpr int NFRAG_F = MTT * 3 * KS;
   static constexpr int NFRAG_G = 3 * MTT * KS;
   static constexpr int NFRAG_L = 4 * MTT * KSF;
+  // factorised G volume (mfma_tables.hpp MfmaFactGeom): rank of the D_r = dim P_{p-1}, row tiles of Q, k-steps over the rank
+  static constexpr int RK = (P >= 2) ? ElemDims<3, (P >= 2 ? P - 1 : 1)>::ND : 1;
+  static constexpr int QLT = RK / 16;
+  static constexpr int QST = (RK % 16 + 3) / 4;
+  static constexpr int KR = (RK + 3) / 4;
+  static constexpr int NFRAG_Q = (QLT + QST) * KS;
+  static constexpr int NFRAG_P = 3 * MTT * KR;
 };
 
 // Streaming accesses (SG_STREAM_HINT): old values of the fused combine and all results are touched
 // once per launch; the non-temporal hint keeps them from displacing the cell data that the
 // neighbours' lift phases are about to ask the L2 for: fabric reads -4 % (F) to -23 % (G<4,0>), step
 // time -2 %.  (The same hint on the trace loads themselves changes no traffic and costs time.)
-#ifndef SG_NO_STREAM_HINT
+#if defined(SG_PLAIN_STORES)      // experiment: results through the L2 as ordinary write-back lines, old values still streamed
+#define LD_STREAM(p) __builtin_nontemporal_load(p)
+#define ST_STREAM(p, v) (*(p) = (v))
+#elif !defined(SG_NO_STREAM_HINT)
 #define LD_STREAM(p) __builtin_nontemporal_load(p)
 #define ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
 #else
@@ -661,6 +671,412 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
         for (int t = 0; t < MTT; ++t) {
           // next facet's traces: asked for a whole facet ahead
           if (t == 0 && f + NB - 1 < 4) request(f + NB - 1, nx[(f + NB - 1) % NB]);
+          // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
+          auto fold = [&](int m0, int nm, const R (&v)[3][4]) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+              const R c = cnf[f][kk];
+              if (uniform_nonzero(c)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    if (j < nm && m0 + j < S4) {
+                      if (i == kk)
+                        Sd[i][m0 + j] += c * v[i][j];
+                      else
+                        So[i + kk - 1][m0 + j] += c * v[i][j];
+                    }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nm && m0 + j < S4) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m0 + j]), "+v"(So[i][m0 + j]));
+              }
+          };
+          if (t < MTF) {
+            d4 tmp[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSF; ++ks) {
+              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
+            }
+            {
+              R v[3][4];
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) v[i][reg] = tmp[i][reg];
+              fold(4 * t, 4, v);
+            }
+          } else {
+            R tmp[3] = {R(0), R(0), R(0)};
+#pragma unroll
+            for (int ks = 0; ks < KSF; ++ks) {
+              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) tmp[i] = MFMA4(a, flf[ks][i], tmp[i]);
+            }
+            {
+              const R v[3][4] = {{tmp[0], 0, 0, 0}, {tmp[1], 0, 0, 0}, {tmp[2], 0, 0, 0}};
+              fold(4 * MTF + (t - MTF), 1, v);
+            }
+          }
+        }
+      }
+    }
+
+    SG_PRIO(SG_PRIO_EPI);
+    STAMP(st3);
+    // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
+    //      vmcnt counts loads and stores together and the two kinds complete out of order with
+    //      each other, so any wait for a load (or a scratch reload) with stores in flight becomes a
+    //      wait for every store's acknowledgement.  Hence: finish ALL loads first, building the
+    //      results in place in Sd/So, and issue the item's stores back to back at the very end.
+    {
+      const long e = (L.valid ? L.c : 0) * 6 + k;
+      const R lam = (R)(A.per_cell ? A.lam[e] : A.lam0);
+      const R mu = (R)(A.per_cell ? A.mu[e] : A.mu0);
+      const long obase = ((g * 6 + k) * (long)ND) * 9 * 16 + w;
+      // row-quad m of this lane = node 4 m + q: per-item base + compile-time offsets (see brow)
+      int qo9 = q * 9 * 16;
+      asm volatile("" : "+v"(qo9));
+      const long ob_q = obase + qo9;
+      const long ob_l = (4 * (S4 - 1) + q < ND) ? ob_q + (long)(S4 - 1) * 4 * 9 * 16 : obase;
+      auto orow = [&](int m) { return (m == S4 - 1) ? ob_l : ob_q + (long)m * 4 * 9 * 16; };
+      if constexpr (SYM || MODE == 0) {
+        constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+#ifndef SG_PDE
+#define SG_PDE 4
+#endif
+        constexpr int PDE = SG_PDE;      // row-quads of old values in flight (MODE 1)
+        R po[PDE][6], pa[PDE][6];
+        auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
+        auto fetch_old = [&](int m) {
+          const long o1 = orow(m);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            po[m % PDE][c] = LD_STREAM(&out[o1 + line(c) * 16]);
+            pa[m % PDE][c] = LD_STREAM(&aux[o1 + line(c) * 16]);
+          }
+        };
+        if (MODE == 1) {
+#pragma unroll
+          for (int m = 0; m < PDE && m < S4; ++m) fetch_old(m);
+        }
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          const R tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            Sd[i][m] = R(2) * mu * Sd[i][m] + tr;
+            So[i][m] = mu * So[i][m];
+          }
+          if (MODE == 1) {
+            // line order of the six slots: Sd0 So0 So1 Sd1 So2 Sd2
+            Sd[0][m] = c_self * po[m % PDE][0] + c_aux * pa[m % PDE][0] + c_new * Sd[0][m];
+            So[0][m] = c_self * po[m % PDE][1] + c_aux * pa[m % PDE][1] + c_new * So[0][m];
+            So[1][m] = c_self * po[m % PDE][2] + c_aux * pa[m % PDE][2] + c_new * So[1][m];
+            Sd[1][m] = c_self * po[m % PDE][3] + c_aux * pa[m % PDE][3] + c_new * Sd[1][m];
+            So[2][m] = c_self * po[m % PDE][4] + c_aux * pa[m % PDE][4] + c_new * So[2][m];
+            Sd[2][m] = c_self * po[m % PDE][5] + c_aux * pa[m % PDE][5] + c_new * Sd[2][m];
+            if (m + PDE < S4) fetch_old(m + PDE);
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+        }
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          const int a = 4 * m + q;
+          const long o = orow(m);
+          if (L.active && a < ND) {
+            ST_STREAM(&out[o + 0 * 16], Sd[0][m]);
+            ST_STREAM(&out[o + 1 * 16], So[0][m]);
+            ST_STREAM(&out[o + 2 * 16], So[1][m]);
+            ST_STREAM(&out[o + 4 * 16], Sd[1][m]);
+            ST_STREAM(&out[o + 5 * 16], So[2][m]);
+            ST_STREAM(&out[o + 8 * 16], Sd[2][m]);
+            if (!SYM) {
+              ST_STREAM(&out[o + 3 * 16], So[0][m]);
+              ST_STREAM(&out[o + 6 * 16], So[1][m]);
+              ST_STREAM(&out[o + 7 * 16], So[2][m]);
+            }
+          }
+        }
+        (void)NL;
+      } else {
+        // full-tensor in-place combine (asymmetric user data, rare): nine results per node
+#pragma unroll
+        for (int m = 0; m < S4; ++m) {
+          const int a = 4 * m + q;
+          const long o = orow(m);
+          const R tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
+          R s[9];
+          s[0] = R(2) * mu * Sd[0][m] + tr;
+          s[4] = R(2) * mu * Sd[1][m] + tr;
+          s[8] = R(2) * mu * Sd[2][m] + tr;
+          s[1] = s[3] = mu * So[0][m];
+          s[2] = s[6] = mu * So[1][m];
+          s[5] = s[7] = mu * So[2][m];
+#pragma unroll
+          for (int ij = 0; ij < 9; ++ij) s[ij] = c_self * out[o + ij * 16] + c_aux * aux[o + ij * 16] + c_new * s[ij];
+          if (L.active && a < ND) {
+#pragma unroll
+            for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
+          }
+        }
+      }
+    }
+    STAMP(st4);
+    STAMP_ACC;
+  }
+  STAMP_FLUSH;
+}
+
+// --------------------------------------------------------------------------------------------
+//  G with the volume term FACTORISED (double, degrees 3 and 4; mfma_tables.hpp): the three D_r of a degree-p element
+//  differentiate, so they have rank dim P_{p-1} and share their row space: D_r = P_r Q.  y_i = Q u_i once, then
+//  z_ri = P_r y_i - 8640 matrix cycles per 16 cells at degree 4 instead of 11664, and ONE pass over the own rows
+//  instead of three.  The price: the own-trace half of the central flux cannot stay folded into the volume tiles
+//  (E_r has full rank), so the lifts take 1/2 (own + neighbour) again and load the own traces as well.
+//  Everything else - folds, epilogue, regions, ghosts - is mfma_stage_G.
+// --------------------------------------------------------------------------------------------
+template <typename R, int P, int MODE, int SYM>
+__global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_GQ(StageArgs A) {
+  using M = MG<P, R>;
+  typedef typename RT<R>::v4 d4;
+  constexpr int PRIO3 = MODE ? SG_PRIO_G1 : SG_PRIO_G0;
+  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
+#ifndef SG_PF
+#define SG_PF 4
+#endif
+  // B-operand prefetch distance, in k-steps.  A float k-step is 96 matrix cycles per component against 144 in
+  // double, so the same latency needs more k-steps in flight (measured: G<float,4,0> 1.10 -> 0.97 ms with 6, 0.94 with 8,
+  // which costs the fused kernel more than it gains)
+  constexpr int PF = sizeof(R) == 4 ? 6 : SG_PF;
+  constexpr int RK = M::RK, QLT = M::QLT, QST = M::QST, KR = M::KR;
+  __shared__ R sQ[M::NFRAG_Q * 64];
+  __shared__ R sP[M::NFRAG_P * 64];
+  __shared__ R sAL[M::NFRAG_L * 64];
+  __shared__ MeshDev sMd;
+  copy_to_lds<M::NFRAG_Q * 64>(sQ, reinterpret_cast<const R*>(A.fragQ));
+  load_tables<M::NFRAG_P, M::NFRAG_L>(sP, sAL, &sMd, A);   // A.fragV holds the P_r tiles for this kernel
+  (void)RK;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, w = lane & 15;
+  // uniform reads of class constants: constant address space => s_load (scalar cache)
+  typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
+  const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
+  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
+  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
+  R* __restrict__ out = reinterpret_cast<R*>(A.out);
+  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
+  const long ngroups = sMd.ncube_pad >> 4;
+  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
+
+  STAMP_DECL;
+  for (long it = ir.lo; it < ir.hi; it += ir.step) {
+    STAMP(st0);
+    const long iti = item_of(ir, it);
+    if (iti < 0) continue;
+    const long item = A.item_list ? (long)A.item_list[iti] : iti;
+    const long g = item / 6;
+    const int k = (int)(item - g * 6);
+    const LaneGeo L = A.all_active ? lane_geo_all(sMd.ncube, g, w) : lane_geo(sMd, A, g, w);
+    const nbr4 nbe = load_nbr4(A, item, w);
+    if (!__any(L.active)) continue;
+    const R* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    // B row of this lane at k-step ks = node 4 ks + q: one pointer per item plus compile-time
+    // offsets (a table of per-k-step offsets is item-invariant, gets hoisted out of the item loop
+    // as 64-bit values and spilled; every reload then waits for ALL loads in flight).  Only the last
+    // k-step can run past ND; those rows meet all-zero operator columns, so any finite value will
+    // do there: clamp instead of branching.
+    int qo = q * 3 * 16;
+    asm volatile("" : "+v"(qo));
+    const R* ownq = own + qo;
+    const R* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 3 * 16 : own;
+    auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 3 * 16; };
+    // operator tiles are item-invariant: an opaque lane offset keeps the compiler from hoisting
+    // all of them into registers (and, unlike a laundered pointer, keeps the reads ds_read_b64)
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+
+    R Jm[3][3], cnf[4][3];  // class constants (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Jm[r][j] = (R)(-md->Jinv[k][r][j]);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cnf[f][j] = (R)md->cn[k][f][j];
+
+    R Sd[3][S4], So[3][S4];  // W_ii and W_ij + W_ji for (0,1), (0,2), (1,2)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = R(0);
+
+#ifndef SG_GNBUF
+#define SG_GNBUF 2
+#endif
+    constexpr int NB = SG_GNBUF;   // trace buffers: facet f in nx[f % NB], the next NB - 1 facets on their way
+    R nx[NB][KSF][3], nxo[NB][KSF][3];
+    auto request = [&](int f, R (&dst)[KSF][3], R (&dso)[KSF][3]) {
+      const NbrRef<R> NR = nbr_from_entry<ND, NF, 3>(A, nbe[f], 2 * sMd.nb_axis[k][f] + (sMd.nb_dir[k][f] > 0 ? 1 : 0), own);
+#pragma unroll
+      for (int ks = 0; ks < KSF; ++ks) {
+        const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
+        const int on = sMd.fnode[f][bb];
+        const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
+        // u^ = 1/2 (own + neighbour) (own + own on a boundary facet); the 1/2 is in the lift tiles.  Two loads
+        // per value: the own rows were read a phase ago and come out of the L2.
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          dst[ks][i] = NR.p[(nn * 3 + i) * NR.cstride];
+#ifdef SG_EXP_NOOWN   // timing experiment only (wrong results): what the lifts cost without the own-trace loads
+          dso[ks][i] = R(0);
+#else
+          dso[ks][i] = own[(on * 3 + i) * 16];
+#endif
+        }
+      }
+    };
+    SG_PRIO(SG_PRIO_VOL);
+    STAMP(st1);
+    // ---- volume, factorised: y_i = Q u_i (one pass over the own rows, PF k-steps ahead), then per reference
+    //      direction z = P_r y_i with the results of the first product as B operands of the second as they are
+    //      (accumulator register `reg` of a large tile = k-step `reg`; a small tile's value = its k-step), folded
+    //      into W with J^-1 as in mfma_stage_G.
+    {
+      d4 yl[QLT > 0 ? QLT : 1][3];
+      R ys[QST > 0 ? QST : 1][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int t = 0; t < QLT; ++t) yl[t][i] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < QST; ++t) ys[t][i] = R(0);
+      }
+      R bq[PF][3];
+#pragma unroll
+      for (int s = 0; s < PF && s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bq[s][i] = brow(s)[i * 16];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        R b[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = bq[ks % PF][i];
+        if (ks + PF < KS) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bq[ks % PF][i] = brow(ks + PF)[i * 16];
+        }
+#pragma unroll
+        for (int t = 0; t < QLT + QST; ++t) {
+          const R a = sQ[(t * KS + ks) * 64 + lo];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            if (t < QLT)
+              yl[t < QLT ? t : 0][i] = MFMA64(a, b[i], yl[t < QLT ? t : 0][i]);
+            else
+              ys[t < QLT ? 0 : t - QLT][i] = MFMA4(a, b[i], ys[t < QLT ? 0 : t - QLT][i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        d4 acc[M::MTFA][3];
+        R accs[M::NSMA][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int t = 0; t < MTF; ++t) acc[t][i] = d4{0, 0, 0, 0};
+#pragma unroll
+          for (int t = 0; t < NSM; ++t) accs[t][i] = R(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks) {
+          R b[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) b[i] = (ks < 4 * QLT) ? yl[(ks / 4) < QLT ? ks / 4 : 0][i][ks % 4] : ys[(ks - 4 * QLT) >= 0 && (ks - 4 * QLT) < QST ? ks - 4 * QLT : 0][i];
+#pragma unroll
+          for (int t = 0; t < MTT; ++t) {
+            const R a = sP[((r * MTT + t) * KR + ks) * 64 + lo];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              if (t < MTF)
+                acc[t < MTF ? t : 0][i] = MFMA64(a, b[i], acc[t < MTF ? t : 0][i]);
+              else
+                accs[t < MTF ? 0 : t - MTF][i] = MFMA4(a, b[i], accs[t < MTF ? 0 : t - MTF][i]);
+            }
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          const R c = Jm[r][kk];
+          if (uniform_nonzero(c)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+              for (int t = 0; t < MTF; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                  if (4 * t + reg >= S4) continue;
+                  if (i == kk)
+                    Sd[i][4 * t + reg] += c * acc[t][i][reg];
+                  else
+                    So[i + kk - 1][4 * t + reg] += c * acc[t][i][reg];
+                }
+#pragma unroll
+              for (int t = 0; t < NSM; ++t) {
+                if (i == kk)
+                  Sd[i][4 * MTF + t] += c * accs[t][i];
+                else
+                  So[i + kk - 1][4 * MTF + t] += c * accs[t][i];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < S4; ++m)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+      }
+    }
+
+    STAMP(st2);
+    // ---- facet lifts.  u^ = avg(u) on interior facets, own trace on the boundary
+    //      (elastic.py:213-216).  The own half of avg(u) is part of the volume tiles (E_r,
+    //      mfma_tables.cpp), so the lift carries 1/2 u- on interior facets and the missing
+    //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
+    //      (a boundary lane's neighbour pointer is its own cell); the 1/2 is in the lift tiles.
+    //      Register budget: the facet's KSF*3 B values stay resident while the row tiles are
+    //      accumulated one at a time (3 accumulators instead of 3*MTT); the next facet's values are
+    //      requested before the last tile pass.  Row tile t covers the row-quads m = 4t .. 4t+3
+    //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
+    {
+#pragma unroll
+      for (int f0 = 0; f0 < NB - 1; ++f0) request(f0, nx[f0], nxo[f0]);
+      SG_PRIO(SG_PRIO_LIFT);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        R flf[KSF][3];
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) flf[ks][i] = nx[f % NB][ks][i] + nxo[f % NB][ks][i];
+#pragma unroll
+        for (int t = 0; t < MTT; ++t) {
+          // next facet's traces: asked for a whole facet ahead
+          if (t == 0 && f + NB - 1 < 4) request(f + NB - 1, nx[(f + NB - 1) % NB], nxo[(f + NB - 1) % NB]);
           // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
           auto fold = [&](int m0, int nm, const R (&v)[3][4]) {
 #pragma unroll
@@ -1605,6 +2021,15 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((mfma_stage_F<R, P, 1, SYM, 0>), grid, block, 0, s, a);
     }
   } else {
+    if constexpr (sizeof(R) == 8 && P >= 3) {
+      if (a.fragQ != nullptr) {      // factorised volume term (StageArgs::fragQ; a.fragV then holds the P_r tiles)
+        if (a.mode == 0)
+          hipLaunchKernelGGL((mfma_stage_GQ<R, P, 0, SYM>), grid, block, 0, s, a);
+        else
+          hipLaunchKernelGGL((mfma_stage_GQ<R, P, 1, SYM>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+      }
+    }
     if (a.mode == 0)
       hipLaunchKernelGGL((mfma_stage_G<R, P, 0, SYM>), grid, block, 0, s, a);
     else

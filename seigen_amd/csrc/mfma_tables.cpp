@@ -1,6 +1,8 @@
 #include "mfma_tables.hpp"
 
+#include <cmath>
 #include <cstring>
+#include <stdexcept>
 
 #include "kernels.hpp"
 
@@ -92,6 +94,101 @@ std::vector<double> mfma_frags_L(const RefElem& re) {
           out[frag * 64 + l] = (a < re.nd && b < re.nf) ? 0.5 * re.L[((size_t)f * re.nd + a) * re.nf + b] : 0.0;
         }
       }
+  return out;
+}
+
+// ---- factorised G volume ------------------------------------------------------------------------
+MfmaFactGeom mfma_fact_geom(const RefElem& re) {
+  MfmaFactGeom f;
+  f.rk = re.P >= 2 ? num_nodes(re.dim, re.P - 1) : 1;     // dim P_{p-1}
+  f.qlt = f.rk / 16;
+  f.qst = (f.rk % 16 + 3) / 4;
+  f.kr = (f.rk + 3) / 4;
+  return f;
+}
+
+// Orthonormal basis of the common row space of D_0, D_1, D_2 by modified Gram-Schmidt with pivoting over their
+// 3 nd rows (long double; two orthogonalisation sweeps per vector), then P_r = D_r Q^T.
+void mfma_factorise_D(const RefElem& re, std::vector<double>& Q, std::vector<double>& Pm) {
+  const int nd = re.nd, d = re.dim, rk = mfma_fact_geom(re).rk;
+  std::vector<long double> rows((size_t)d * nd * nd);
+  for (size_t i = 0; i < rows.size(); ++i) rows[i] = re.D[i];
+  std::vector<long double> q((size_t)rk * nd, 0.0L);
+  long double first = 0.0L;
+  for (int k = 0; k < rk; ++k) {
+    int best = -1;
+    long double bn = -1.0L;
+    for (int r = 0; r < d * nd; ++r) {
+      long double n2 = 0.0L;
+      for (int j = 0; j < nd; ++j) n2 += rows[(size_t)r * nd + j] * rows[(size_t)r * nd + j];
+      if (n2 > bn) {
+        bn = n2;
+        best = r;
+      }
+    }
+    if (k == 0) first = bn;
+    if (!(bn > 1e-20L * first)) throw std::runtime_error("D_r: rank below dim P_{p-1}");
+    long double* v = &q[(size_t)k * nd];
+    for (int j = 0; j < nd; ++j) v[j] = rows[(size_t)best * nd + j];
+    for (int sweep = 0; sweep < 2; ++sweep)
+      for (int m = 0; m < k; ++m) {
+        long double dot = 0.0L;
+        for (int j = 0; j < nd; ++j) dot += v[j] * q[(size_t)m * nd + j];
+        for (int j = 0; j < nd; ++j) v[j] -= dot * q[(size_t)m * nd + j];
+      }
+    long double nrm = 0.0L;
+    for (int j = 0; j < nd; ++j) nrm += v[j] * v[j];
+    nrm = std::sqrt(nrm);
+    for (int j = 0; j < nd; ++j) v[j] /= nrm;
+    for (int r = 0; r < d * nd; ++r) {       // deflate every row
+      long double dot = 0.0L;
+      for (int j = 0; j < nd; ++j) dot += rows[(size_t)r * nd + j] * v[j];
+      for (int j = 0; j < nd; ++j) rows[(size_t)r * nd + j] -= dot * v[j];
+    }
+  }
+  long double left = 0.0L;
+  for (long double x : rows) left = std::max(left, std::fabs(x));
+  if (left > 1e-11L * std::sqrt(first)) throw std::runtime_error("D_r: rank above dim P_{p-1}");
+  Q.assign((size_t)rk * nd, 0.0);
+  for (size_t i = 0; i < Q.size(); ++i) Q[i] = (double)q[i];
+  Pm.assign((size_t)d * nd * rk, 0.0);
+  for (int r = 0; r < d; ++r)
+    for (int a = 0; a < nd; ++a)
+      for (int k = 0; k < rk; ++k) {
+        long double s = 0.0L;
+        for (int j = 0; j < nd; ++j) s += (long double)re.D[((size_t)r * nd + a) * nd + j] * q[(size_t)k * nd + j];
+        Pm[((size_t)r * nd + a) * rk + k] = (double)s;
+      }
+}
+
+std::vector<double> mfma_frags_Q(const RefElem& re) {
+  const MfmaGeom g = mfma_geom(re);
+  const MfmaFactGeom f = mfma_fact_geom(re);
+  std::vector<double> Q, Pm;
+  mfma_factorise_D(re, Q, Pm);
+  std::vector<double> out((size_t)(f.qlt + f.qst) * g.ks * 64, 0.0);
+  for (int t = 0; t < f.qlt + f.qst; ++t)
+    for (int k0 = 0; k0 < g.ks; ++k0)
+      for (int l = 0; l < 64; ++l) {
+        const int row = t < f.qlt ? 16 * t + (l & 15) : 16 * f.qlt + 4 * (t - f.qlt) + (l & 3), col = 4 * k0 + (l >> 4);
+        out[((size_t)t * g.ks + k0) * 64 + l] = (row < f.rk && col < re.nd) ? Q[(size_t)row * re.nd + col] : 0.0;
+      }
+  return out;
+}
+
+std::vector<double> mfma_frags_P(const RefElem& re) {
+  const MfmaGeom g = mfma_geom(re);
+  const MfmaFactGeom f = mfma_fact_geom(re);
+  std::vector<double> Q, Pm;
+  mfma_factorise_D(re, Q, Pm);
+  std::vector<double> out((size_t)3 * g.mtt * f.kr * 64, 0.0);
+  for (int r = 0; r < 3; ++r)
+    for (int t = 0; t < g.mtt; ++t)
+      for (int k0 = 0; k0 < f.kr; ++k0)
+        for (int l = 0; l < 64; ++l) {
+          const int row = tile_row(g, t, l), col = 4 * k0 + (l >> 4);
+          out[(((size_t)r * g.mtt + t) * f.kr + k0) * 64 + l] = (row < re.nd && col < f.rk) ? Pm[((size_t)r * re.nd + row) * f.rk + col] : 0.0;
+        }
   return out;
 }
 

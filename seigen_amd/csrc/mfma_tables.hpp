@@ -51,6 +51,29 @@ std::vector<double> mfma_frags_G(const RefElem& re);
 // (the 1/2 of the central flux average: both kernels lift +-1/2 of a neighbour trace)
 std::vector<double> mfma_frags_L(const RefElem& re);
 
+// Factorised G volume (kernels_mfma.hip mfma_stage_GQ).  The three D_r = Mhat^-1 Shat_r of degree p have rank
+// dim P_{p-1} (they differentiate: 20 of 35 at degree 4, 10 of 20 at degree 3) and SHARE their row space, so
+//     D_r = P_r Q,   Q [rk x nd] an orthonormal basis of that row space,   P_r = D_r Q^T [nd x rk]:
+// y_i = Q u_i once per velocity component, then z_ri = P_r y_i per direction, instead of three dense D_r u_i:
+// at degree 4 the volume phase takes 8640 matrix cycles per 16 cells instead of 11664.  (These are the UNFOLDED
+// D_r: the own-trace half of the central flux, which mfma_frags_G folds into E_r and which has full rank, goes
+// back to the lifts.)  The results of the first product come out of the MFMA in exactly the register layout the
+// second one wants its B operand in (row 4 reg + q <-> k-step reg, lane group q).
+//   Q: frag (t * ks + k0): A[row][col] = Q[row0q(t) + row][4 k0 + col], floor(rk / 16) large row tiles, then
+//      ceil((rk % 16) / 4) small ones;   P: frag ((r * mtt + t) * kr + k0): A[row][col] = P_r[row0(t) + row][4 k0 + col],
+//      kr = ceil(rk / 4) k-steps over the rank.
+struct MfmaFactGeom {
+  int rk;    // rank of the D_r
+  int qlt;   // large row tiles of Q = floor(rk / 16)
+  int qst;   // small row tiles of Q = ceil((rk % 16) / 4)
+  int kr;    // k-steps over the rank = ceil(rk / 4)
+};
+MfmaFactGeom mfma_fact_geom(const RefElem& re);
+// fills Q [rk][nd] and P [3][nd][rk] (row-major); throws if the numerical rank is not dim P_{p-1}
+void mfma_factorise_D(const RefElem& re, std::vector<double>& Q, std::vector<double>& Pm);
+std::vector<double> mfma_frags_Q(const RefElem& re);
+std::vector<double> mfma_frags_P(const RefElem& re);
+
 // The same three tables for the float kernels (v_mfma_f32_16x16x4_f32): every row tile is a
 // 16-row tile (ceil(nd / 16) of them, the last one zero-padded), and lane l of tile t holds the
 // operator row of node 16 t + 4 (l & 3) + ((l & 15) >> 2): the f32 shape returns row 4 q + reg in

@@ -114,6 +114,10 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.tensor = h->re.kind == KIND_TENSOR ? 1 : 0;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
+  if (kind == 1 && h->fragQ) {      // G stages with the factorised volume term
+    a.fragV = h->fragP;
+    a.fragQ = h->fragQ;
+  }
   a.sym = h->sym ? 1 : 0;
   a.f32 = h->f32;
   a.dbg = h->dbg ? h->dbg + 8 * (kind * 2 + (mode ? 1 : 0)) : nullptr;

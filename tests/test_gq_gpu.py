@@ -1,0 +1,83 @@
+"""The G stage kernels with the FACTORISED volume term (kernels_mfma.hip mfma_stage_GQ, SEIGEN_HIP_GQ=1; double, 3-D,
+degrees 3 and 4).  The three derivative operators D_r behind `g` (seigen/elastic.py:211-219) have rank dim P_{p-1} and
+share their row space, D_r = P_r Q: y = Q u once, then P_r y per direction - 26 % fewer matrix cycles in the volume
+phase; the own-trace half of the central flux goes back to the lifts.  Off by default (profiles/r04/kernel_experiments.txt:
+-2 % on the plain G stages, -0.7 % on the step).  Tested like the production kernels: against the oracle, against the
+plain kernels, multi-block = single-block bitwise, with per-cell material, a source, and the fused combine."""
+import numpy as np
+import pytest
+
+from oracle.forms import ElasticOperators
+from oracle.lf4 import OracleLF4
+from tests.util import oracle_mesh, rel_err, seeded
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (3, (2, 2, 2), (1.0, 1.0, 1.0)),
+    (4, (3, 1, 2), (1.0, 1.0, 1.0)),
+    (3, (5, 3, 17), (1.0, 0.6, 3.4)),
+    (4, (17, 3, 2), (1.7, 0.3, 0.2)),
+]
+
+
+def make_block(degree, n, L, **kw):
+    from seigen_amd.backend import HipBlock
+    return HipBlock(3, degree, n, [L[a] / n[a] for a in range(3)], [0.0] * 3, "left", **kw)
+
+
+@pytest.mark.parametrize("degree,n,L", CASES)
+def test_gq_apply_G_and_steps_vs_oracle(gpu, monkeypatch, degree, n, L):
+    from seigen_amd import _lib
+    monkeypatch.setenv("SEIGEN_HIP_GQ", "1")
+    blk = make_block(degree, n, L)
+    m = oracle_mesh(3, n, L)
+    E = ElasticOperators(m, degree)
+    u = seeded(blk.field_shape(_lib.FIELD_U), 21)
+    lam, mu = 0.7, 0.3
+    blk.set_params(1.0, 0.01, lam, mu)
+    blk.set_field(_lib.FIELD_U, u)
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, lam, mu)) < 1e-11
+    orc = OracleLF4(m, degree)
+    hmin = min(L[a] / n[a] for a in range(3))
+    orc.dt, orc.l, orc.mu, orc.density = 0.05 * hmin / degree ** 2, 0.5, 0.25, 1.0
+    orc.u0 = seeded(blk.field_shape(_lib.FIELD_U), 2)
+    orc.s0 = seeded(blk.field_shape(_lib.FIELD_S), 3)
+    blk.set_params(orc.density, orc.dt, orc.l, orc.mu)
+    blk.set_field(_lib.FIELD_U, orc.u0)
+    blk.set_field(_lib.FIELD_S, orc.s0)
+    blk.step(3)
+    for k in range(3):
+        orc.step((k + 1) * orc.dt)
+    assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 1e-10
+    assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
+
+
+def test_gq_against_plain_kernels(gpu, monkeypatch):
+    from seigen_amd import _lib
+    degree, n, L = 4, (20, 5, 6), (2.0, 0.5, 0.6)
+    out = {}
+    for gq in (0, 1):
+        monkeypatch.setenv("SEIGEN_HIP_GQ", str(gq))
+        blk = make_block(degree, n, L)
+        r = np.random.default_rng(5)
+        blk.set_params(1.0, 1e-3, r.uniform(0.4, 0.8, blk.ncells), r.uniform(0.2, 0.4, blk.ncells))
+        blk.set_field(_lib.FIELD_U, seeded(blk.field_shape(_lib.FIELD_U), 6))
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 7)
+        blk.set_field(_lib.FIELD_S, 0.5 * (s0 + np.swapaxes(s0, -1, -2)))
+        nodes = np.unique(r.integers(0, blk.ncells * blk.nd, size=30))
+        sv = r.uniform(-1, 1, size=(4, len(nodes), 3, 3))
+        blk.set_source(nodes, 0.5 * (sv + np.swapaxes(sv, -1, -2)))
+        blk.step(4)
+        out[gq] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+    assert rel_err(out[1][0], out[0][0]) < 1e-11
+    assert rel_err(out[1][1], out[0][1]) < 1e-11
+
+
+@pytest.mark.parametrize("degree,n,grid", [(4, (4, 2, 4), (2, 1, 2)), (3, (9, 9, 9), (3, 3, 3)), (4, (120, 2, 2), (3, 1, 1))])
+def test_gq_multiblock_bitwise(gpu, monkeypatch, degree, n, grid):
+    from tests.test_harness_gpu import _multiblock_case
+    monkeypatch.setenv("SEIGEN_HIP_GQ", "1")
+    for pipelined in (True, False):
+        _multiblock_case(3, degree, n, grid, pipelined, extras=True)
