@@ -17,7 +17,10 @@ Differences, all documented in DESIGN.md:
     systems are DG mass matrices (block diagonal), so the solve IS the element-wise inverse the
     explicit path applies, up to the KSP tolerance.  Here it runs the same six launches with the
     implicit forms' density convention (``form_u1``, ``:175-178``: u1 = u0 + (...)/rho).
-  * VTK output (``:221-232``) is replaced by ``.npy`` snapshots.
+  * VTK output (``:221-232``): ``velocity_<k>.vtu`` / ``stress_<k>.vtu`` streams with ``.pvd`` indices
+    (``seigen_amd/vtu.py``; ``SEIGEN_OUTPUT=npy`` writes raw arrays instead).
+  * The halo exchange implicit in every assemble (``:364``, ``:404-436``) runs inside the library over RCCL
+    (``NativeExchanger``), or stage by stage from ``seigen_amd/parallel.py`` for process groups without device transport.
 """
 import os
 import sys

@@ -91,6 +91,22 @@ def main():
         ref.sync()
         torch.cuda.synchronize()
         assert np.array_equal(nat.get_field(_lib.FIELD_S), ref.get_field(_lib.FIELD_S))
+        # the host-side wrapper the solver class uses (unique id from rank 0 through the process group's broadcast,
+        # peers from the partition, statistics): a third twin block stepped through it
+        from seigen_amd.parallel import NativeExchanger
+        third = fresh()
+        third.set_field(_lib.FIELD_U, u0)
+        third.set_field(_lib.FIELD_S, s0)
+        nex = NativeExchanger(third, part)
+        assert nex.sides == [4, 5] and not nex.staged and nex.native
+        nex.reset_stats(timing=True)
+        nex.step(3)
+        nex.step(2)
+        third.sync()
+        assert np.array_equal(third.get_field(_lib.FIELD_S), ref.get_field(_lib.FIELD_S))
+        st3 = nex.stats()
+        assert st3["exchanges"] == 2 + 30 and nex.bytes_sent == st3["bytes_sent"] > 0 and st3["host_blocked_ms"] == 0.0
+        third.close()
         print("native rccl exchange ok (%s): %d exchanges, %.3f ms waited beyond SECOND, %d bytes sent"
               % (dtype, st["exchanges"], st["exposed_wait_ms"], st["bytes_sent"]))
         nat.close()

@@ -166,6 +166,11 @@ class _LocalExchange(object):
                         b.halo_attach(field, s, rcv[(kind, s)].data_ptr())
             self.send.append(snd)
             self.recv.append(rcv)
+        # the zero fills above run on torch's current stream, the blocks' packs on their own non-blocking streams:
+        # no fill may land after the first pack (seigen_amd/parallel.py HaloExchanger does the same).  Without this a
+        # multi-block test failed once in a long session (torch's caching allocator hands out blocks without a
+        # synchronising hipMalloc, so the fills really are asynchronous), never in a fresh process.
+        torch.cuda.synchronize()
 
     def _exchange(self, field):
         lib = self.lib
