@@ -468,10 +468,17 @@ def main():
     if mfma:
         # template arguments: <field type, degree, fused combine, symmetric storage(, reads packed remote traces)>
         ty, gh = ("float" if args.dtype == "f32" else "double"), (1 if world > 1 else 0)
-        names = (("sg::mfma_stage_F<%s, %d, 0, %d, %d>" % (ty, P, sym, gh), (0, 4)),
-                 ("sg::mfma_stage_F<%s, %d, 1, %d, %d>" % (ty, P, sym, gh), (2,)),
-                 ("sg::mfma_stage_G<%s, %d, 0, %d>" % (ty, P, sym), (1, 3)),
-                 ("sg::mfma_stage_G<%s, %d, 1, %d>" % (ty, P, sym), (5,)))
+        # G stages: the kernel with the factorised volume term (D_r = P_r Q) at degree 4 in double, or where
+        # SEIGEN_HIP_GQ forces it (csrc/api.cpp)
+        gq_env = os.environ.get("SEIGEN_HIP_GQ")
+        gq = ty == "double" and P >= 3 and ((int(gq_env) != 0) if gq_env is not None else P >= 4)
+        gname = "sg::mfma_stage_GQ" if gq else "sg::mfma_stage_G"
+        team = os.environ.get("SEIGEN_HIP_TEAM", "0")      # the trace-sharing F kernels, if someone switches them on
+        fname, ftail = ("sg::mfma_stage_FT", ", %s>" % team) if (team in ("4", "8") and ty == "double" and P >= 3) else ("sg::mfma_stage_F", ">")
+        names = (("%s<%s, %d, 0, %d, %d%s" % (fname, ty, P, sym, gh, ftail), (0, 4)),
+                 ("%s<%s, %d, 1, %d, %d%s" % (fname, ty, P, sym, gh, ftail), (2,)),
+                 ("%s<%s, %d, 0, %d>" % (gname, ty, P, sym), (1, 3)),
+                 ("%s<%s, %d, 1, %d>" % (gname, ty, P, sym), (5,)))
     else:
         names = (("sg::stage_kernel<3, %d, 0>" % P, (0, 2, 4)), ("sg::stage_kernel<3, %d, 1>" % P, (1, 3, 5)))
     if not sym:

@@ -271,7 +271,9 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     HIPCHECK(h, hipMemcpy(h->fragL, fL.data(), fL.size() * sizeof(double), hipMemcpyHostToDevice));
     // factorised G volume (mfma_tables.hpp): D_r = P_r Q
     const char* gq = std::getenv("SEIGEN_HIP_GQ");
-    if (h->use_mfma && cfg->degree >= 3 && (gq ? std::atoi(gq) != 0 : SG_GQ_DEFAULT != 0)) {
+    // default: degree 4 only (G<4,0> -2 %, step -0.7 .. -1 %; at degree 3, rank 10 of 20 on 4-row tiles, it is 12 % slower:
+    // profiles/r04/kernel_experiments.txt); SEIGEN_HIP_GQ=0 / 1 forces it off / on for degrees 3 and 4
+    if (h->use_mfma && cfg->degree >= 3 && (gq ? std::atoi(gq) != 0 : cfg->degree >= SG_GQ_FROM_DEGREE)) {
       std::vector<double> fQ, fP;
       try {
         fQ = mfma_frags_Q(h->re);

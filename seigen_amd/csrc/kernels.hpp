@@ -30,8 +30,8 @@ struct ElemDims {
 // (tools/wave_sim.py, profiles/r03/kernel_experiments.txt) - the lesson of the 2-D tile kernels' T2Const.
 constexpr int MK_KSF = 4;     // facet k-steps at degree 4 (15 facet nodes)
 constexpr int MK_KS = 9;      // volume k-steps at degree 4 (35 nodes)
-#ifndef SG_GQ_DEFAULT
-#define SG_GQ_DEFAULT 0       // G stages with the factorised volume term (mfma_stage_GQ) unless SEIGEN_HIP_GQ says otherwise
+#ifndef SG_GQ_FROM_DEGREE
+#define SG_GQ_FROM_DEGREE 4   // G stages with the factorised volume term (mfma_stage_GQ) from this degree on, unless SEIGEN_HIP_GQ says otherwise
 #endif
 #ifndef SG_TEAM_DEFAULT
 #define SG_TEAM_DEFAULT 0     // waves per team of the trace-sharing F kernels unless SEIGEN_HIP_TEAM says otherwise

@@ -1,9 +1,10 @@
 """The G stage kernels with the FACTORISED volume term (kernels_mfma.hip mfma_stage_GQ, SEIGEN_HIP_GQ=1; double, 3-D,
 degrees 3 and 4).  The three derivative operators D_r behind `g` (seigen/elastic.py:211-219) have rank dim P_{p-1} and
 share their row space, D_r = P_r Q: y = Q u once, then P_r y per direction - 26 % fewer matrix cycles in the volume
-phase; the own-trace half of the central flux goes back to the lifts.  Off by default (profiles/r04/kernel_experiments.txt:
--2 % on the plain G stages, -0.7 % on the step).  Tested like the production kernels: against the oracle, against the
-plain kernels, multi-block = single-block bitwise, with per-cell material, a source, and the fused combine."""
+phase; the own-trace half of the central flux goes back to the lifts.  The default at degree 4 (profiles/r04/
+kernel_experiments.txt: -2 % on the plain G stages, -0.7..-1 % on the step; at degree 3 it is 12 % slower and stays off).
+Here it is FORCED on at both degrees and tested like every production kernel: against the oracle, against the plain
+kernels (SEIGEN_HIP_GQ=0), multi-block = single-block bitwise, with per-cell material, a source, and the fused combine."""
 import numpy as np
 import pytest
 
