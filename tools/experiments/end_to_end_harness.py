@@ -5,7 +5,7 @@ import seigen_amd.harness.explosive_source as hx
 import seigen_amd.harness.eigenmode as he
 helpers.log = seigen_amd.elastic.log = hx.log = he.log = lambda s: None
 from seigen_amd.harness.explosive_source import ExplosiveSourceLF4
-for quad in (False, True):
+for quad in (False, True, False, True):      # the second pair runs warm (code objects loaded, allocator primed)
     es = ExplosiveSourceLF4()
     t0 = time.perf_counter()
     el = es.setup(300.0, 150.0, 2.5, degree=2, dt=0.001, quadrilateral=quad)
