@@ -52,6 +52,14 @@ def main():
         for b in (nat, ref):
             b.set_field(_lib.FIELD_U, u0)
             b.set_field(_lib.FIELD_S, s0)
+        # a source whose nodes lie in the shell and in the interior, and a sponge
+        nodes = np.unique(rng.integers(0, nat.ncells * nat.nd, size=40))
+        sv = rng.uniform(-1, 1, size=(8, len(nodes), 3, 3))
+        sv = 0.5 * (sv + np.swapaxes(sv, -1, -2))
+        sigma = np.where(rng.uniform(size=(nat.ncells, 35)) > 0.7, 2.0, 0.0)
+        for b in (nat, ref):
+            b.set_source(nodes, sv)
+            b.set_absorption(sigma, 4)
         nat.comm_init(comm_unique_id(), 0, 1, [None, None, None, None, 0, 0])
         # one exchange on its own: the buffer received for a side is the one packed for it (RCCL pairs the sends and
         # receives of one peer in posting order), and the two sides differ
@@ -97,6 +105,8 @@ def main():
         third = fresh()
         third.set_field(_lib.FIELD_U, u0)
         third.set_field(_lib.FIELD_S, s0)
+        third.set_source(nodes, sv)
+        third.set_absorption(sigma, 4)
         nex = NativeExchanger(third, part)
         assert nex.sides == [4, 5] and not nex.staged and nex.native
         nex.reset_stats(timing=True)
