@@ -3,8 +3,8 @@
 The reference's protocol runs NP in {1, 2, 4, 8, 16} MPI ranks (tests/eigenmode/README.md:7-13) with the halo
 exchange implicit in every assemble (seigen/elastic.py:364, :404-436).  Here: one process per GPU, RCCL send/receive
 of the packed facet traces (`T.n`) between face neighbours.  With >= 2 visible devices these tests start 2 ranks
-(>= 4 devices: 4; 8: 8, the 2 x 2 x 2 grid of SURVEY 8e / BASELINE config 4) with the **nccl** backend, through the
-solver class and through bench.py, and require
+(>= 4 devices: 4 - the box's process guard allows six GPU processes, so the eight ranks of the 2 x 2 x 2 grid are left to
+the driver's scaling run) with the **nccl** backend, through the solver class and through bench.py, and require
   * every rank's block bitwise equal to the single-block run of the whole mesh,
   * `n_gpus == N`, `halo.transport == "nccl"`, and the bytes sent per step equal to the closed-form `T.n` payload.
 On a one-GPU box they SKIP (they do not pass); what a one-GPU box can check of config 4's partition is the last
@@ -34,8 +34,10 @@ def _ndev():
 
 
 def _nranks():
+    """Ranks to start: one per device, but never more than four - a GPU box allows six processes on its cards at once,
+    and the test process itself is one of them (the 2 x 2 x 2 grid of eight ranks is the driver's scaling run)."""
     n = _ndev()
-    return 8 if n >= 8 else (4 if n >= 4 else (2 if n >= 2 else 0))
+    return 4 if n >= 4 else (2 if n >= 2 else 0)
 
 
 def _free_port():
@@ -57,7 +59,7 @@ def _launch_nccl(nproc, script_args, timeout=600):
 
 # mesh and process grid per rank count: blocks wider than 32 cubes along x wherever x is cut (the shell next to an x
 # side is a whole 16-cube layout group thick, csrc/handle.hpp shell_width_x)
-CASES = {2: ((16, 4, 8), (1, 1, 2)), 4: ((16, 8, 8), (1, 2, 2)), 8: ((80, 4, 4), (2, 2, 2))}
+CASES = {2: ((16, 4, 8), (1, 1, 2)), 4: ((80, 8, 4), (2, 2, 1))}      # four ranks: an x cut and a y cut
 
 
 @pytest.mark.parametrize("degree,source", [(4, False), (4, True), (3, "asym")])
@@ -108,7 +110,7 @@ def test_bench_over_rccl(gpu):
     assert out["n_gpus"] == world and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["cells"] == world * 16 ** 3 * 6
     grid = out["config"]["block_grid"]
-    assert int(np.prod(grid)) == world and (world != 8 or grid == [2, 2, 2])
+    assert int(np.prod(grid)) == world
     h = out["halo"]
     assert h["transport"] == "nccl"
     assert h["exchanges_per_step"] == (6 * steps + 1) / steps
@@ -120,8 +122,6 @@ def test_bench_over_rccl(gpu):
     assert len(out["rank_ms_per_step"]["per_rank"]) == world
     sw = h["grid_blocks_sweep_ms_per_step"]
     assert sorted(sw) == ["480", "512"] and all(v > 0 for v in sw.values())
-    if world == 8:
-        assert "config4" in out      # measured, or an error note - never a lost headline
 
 
 def test_config3_golden_split_2x2x2_on_one_device(gpu):
