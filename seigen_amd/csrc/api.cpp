@@ -61,6 +61,7 @@ void sg_destroy(sg_handle* h) {
   if (h->md_dev) (void)hipFree(h->md_dev);
   comm_release(h);
   if (h->mk_dev) (void)hipFree(h->mk_dev);
+  if (h->ftab_dev) (void)hipFree(h->ftab_dev);
   if (h->err_word) (void)hipHostFree(h->err_word);
   if (h->fragQ) (void)hipFree(h->fragQ);
   if (h->fragP) (void)hipFree(h->fragP);
@@ -204,6 +205,12 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     const MfmaConst mk = mfma_const(h->md);
     HIPCHECK(h, hipMalloc((void**)&h->mk_dev, sizeof(MfmaConst)));
     HIPCHECK(h, hipMemcpy(h->mk_dev, &mk, sizeof(MfmaConst), hipMemcpyHostToDevice));
+    {
+      std::vector<int32_t> ft;
+      mfma_trace_offsets(h->md, 9, ft);
+      HIPCHECK(h, hipMalloc((void**)&h->ftab_dev, ft.size() * sizeof(int32_t)));
+      HIPCHECK(h, hipMemcpy(h->ftab_dev, ft.data(), ft.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     // trace-sharing F kernels (kernels_mfma.hip mfma_stage_FT): double, degrees 3 and 4, Kuhn split
     h->team = 0;
     if (mk.team_ok && !h->f32 && cfg->degree >= 3) {

@@ -107,6 +107,7 @@ struct sg_handle {
   bool second_pending = false;
   int32_t* nbr_tab = nullptr;   // MFMA path: per-item neighbour table (StageArgs::nbr_tab)
   MfmaConst* mk_dev = nullptr;  // MFMA path: scalar-load copy of the mesh constants (kernels.hpp MfmaConst)
+  int32_t* ftab_dev = nullptr;  // MFMA path, F stages: tabulated trace offsets (kernels.hpp mfma_trace_offsets)
   // MFMA path, F stages, double, degrees 3 and 4: waves per team of the trace-sharing kernels (0: plain kernels;
   // SEIGEN_HIP_TEAM), and the word those kernels set if a team barrier ever gives up (pinned host memory the device
   // writes through; checked by sg_sync and sg_step)

@@ -62,6 +62,10 @@ struct MfmaConst {
   MfmaClassConst cls[6];
 };
 MfmaConst mfma_const(const MeshDev& md_host);
+// [variant 0: neighbour inside the block, 1: packed remote record, 2: domain boundary (own cell)][class][facet][lane group q][k-step]:
+// offset (in values of the field type, before the component) of the neighbour's node that matches my facet node 4 ks + q -
+// node * ncomp * 16 in a field, position in the facet list * 3 in a remote record; 3 * 6 * 4 * 4 * 4 entries
+void mfma_trace_offsets(const MeshDev& md_host, int ncomp, std::vector<int32_t>& tab);
 // [item = cell group * 6 + class][lane 0..15][facet 0..3] (see StageArgs::nbr_tab); (ncube_pad / 16) * 6 * 64 entries
 void build_nbr_table(const MeshDev& md_host, std::vector<int32_t>& tab);
 
@@ -103,6 +107,7 @@ struct StageArgs {
   const double* Lt;        // [nfaces][nf(b')][nd(a)] transposed facet lifts
   const MeshDev* md;       // device copy
   const MfmaConst* mk;     // MFMA path: device copy of mfma_const(md)
+  const int32_t* ftab;     // MFMA path, F stages: trace offsets per (variant, class, facet, lane group) x 4 k-steps (mfma_trace_offsets)
   // MFMA path: where every cell finds its four facet neighbours, tabulated once per block (mfma_tables.cpp
   // build_nbr_table): nbr_tab[(item * 16 + lane) * 4 + f] = the neighbour's cell slot (cell group * 16 * 6 ... see
   // there), -1 on the domain boundary, -2 - s for slot s of the packed remote trace of that block side.  Replaces

@@ -1255,6 +1255,15 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
   __shared__ R sAV[M::NFRAG_F * 64];
   __shared__ R sAL[M::NFRAG_L * 64];
+  // where a lane finds the nodes of a neighbour's trace: offsets of the four facet k-steps per (variant: interior /
+  // remote record / domain boundary, class, facet, lane group), tabulated on the host (mfma_tables.cpp
+  // mfma_trace_offsets) - one ds_read_b128 per facet instead of three batches of scalar loads, a byte extraction and a
+  // multiplication per k-step, and a dozen SGPRs fewer (the neighbour set-up took 4.6 k of an item's 53 k cycles)
+  __shared__ nbr4 sFt[3 * 6 * 4 * 4];
+  {
+    const nbr4* src = reinterpret_cast<const nbr4*>(A.ftab);
+    for (int i = threadIdx.x; i < 3 * 6 * 4 * 4; i += 256) sFt[i] = src[i];
+  }
   load_tables<M::NFRAG_F, M::NFRAG_L>(sAV, sAL, A);
   const cMfmaConst& mk = *(const cMfmaConst*)(unsigned long long)A.mk;
 
@@ -1280,7 +1289,6 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     const int k = (int)(item - g * 6);
     const LaneGeo L = A.all_active ? lane_geo_all(mk.ncube, g, w) : lane_geo(mk, A, g, w);
     const cMfmaClassConst& kc = mk.cls[k];
-    const int qsh = q * 8;
     const nbr4 nbe = load_nbr4(A, item, w);
     if (!__any(L.active)) continue;
     const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
@@ -1382,12 +1390,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
         gh[f] = GHOST && NR.ghost;
         fax[f] = GHOST ? kc.nb_axis[f] : 0;
         wf[f] = NR.physical ? R(-1) : R(1);
+        const int var = NR.ghost ? 1 : (NR.physical ? 2 : 0);
+        const nbr4 o4 = sFt[((var * 6 + k) * 4 + f) * 4 + q];
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          const int on = word_byte(mk.fw[f][ks], qsh);
-          const int nn = NR.ghost ? word_byte(kc.nfw[f][ks], qsh) : (NR.physical ? on : word_byte(kc.nbw[f][ks], qsh));
-          noff[f][ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
-        }
+        for (int ks = 0; ks < KSF; ++ks) noff[f][ks] = o4[ks];
       }
       R nq[PFL][9];
       STAMP(sta);   // diagnostic builds: end of the neighbour set-up

@@ -370,6 +370,23 @@ MfmaConst mfma_const(const MeshDev& md) {
 }
 
 
+void mfma_trace_offsets(const MeshDev& md, int ncomp, std::vector<int32_t>& tab) {
+  tab.assign((size_t)3 * 6 * 4 * 4 * 4, 0);
+  const int nf = md.nf;
+  for (int var = 0; var < 3; ++var)
+    for (int k = 0; k < 6; ++k)
+      for (int f = 0; f < 4; ++f)
+        for (int q = 0; q < 4; ++q)
+          for (int ks = 0; ks < 4; ++ks) {
+            const int bb = (4 * ks + q < nf) ? 4 * ks + q : 0;      // padded rows repeat facet node 0 (they meet zero lift columns)
+            int v;
+            if (var == 0) v = (int)md.nb_node[k][f][bb] * ncomp * 16;
+            else if (var == 1) v = (int)md.nb_fnode[k][f][bb] * 3;
+            else v = (int)md.fnode[f][bb] * ncomp * 16;
+            tab[(size_t)((((var * 6 + k) * 4 + f) * 4 + q) * 4 + ks)] = v;
+          }
+}
+
 // The neighbour of (cube c, class k) across facet f, exactly as the stage kernels used to derive it per item
 // (kernels_mfma.hip nbr_ref): same cube (axis < 0), the cube one step along `axis`, the domain boundary, or a
 // neighbour block's packed trace.  A cell slot is ((c / 16) * 6 + class) * 16 + c % 16: the position of the cell's

@@ -107,6 +107,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.Lt = h->Lt;
   a.md = h->md_dev;
   a.mk = h->mk_dev;
+  a.ftab = h->ftab_dev;
   a.nbr_tab = h->nbr_tab;
   a.team = (kind == 0) ? h->team : 0;
   a.err = h->err_dev;
