@@ -1313,12 +1313,70 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     // rows 16t + 4reg + q in acc[i][t][reg] (large tiles), row 16*MTF + 4s + q in accs[i][s] (small)
     d4 acc[3][M::MTFA];
     R accs[3][M::NSMA];
+    const long e = (L.valid ? L.c : 0) * 6 + k;
+    const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
+    int qo3 = q * 3 * 16;  // output rows: per-item base + compile-time offsets (see brow)
+    asm volatile("" : "+v"(qo3));
+    const long ub_q = ubase + qo3;
+    // Fused combine u = c_self u + c_aux uh1 + c_new rhs (MODE 1), EARLY form: the old values are requested at the
+    // START of the item, together with the first own rows, and enter the accumulators as (c_self u + c_aux uh1) / c_new;
+    // the matrix products add rhs on top and the epilogue only scales by c_new and stores - no loads, no second
+    // memory latency at the end of the item (the epilogue of F<4,1> took 10 k of an item's 67 k cycles against 2.8 k in
+    // F<4,0>).  Rounding: the sum is formed at the scale of u / c_new, i.e. with the absolute error the final u carries
+    // anyway.  c_new = 0 (dt = 0) keeps the late form.
+#ifndef SG_F1_EARLY
+#define SG_F1_EARLY 1
+#endif
+    const bool early = MODE == 1 && SG_F1_EARLY && uniform_nonzero(c_new);
+    R cs = c_self, ca = c_aux, cn = c_new;
+    if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
+      cs = (R)A.rho2[2 * e];
+      ca *= (R)A.rho2[2 * e + 1];
+      cn *= (R)A.rho2[2 * e + 1];
+    }
+    if (early) {
+      R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+      for (int t = 0; t < MTF; ++t)
 #pragma unroll
-      for (int t = 0; t < MTF; ++t) acc[i][t] = d4{0, 0, 0, 0};
+        for (int reg = 0; reg < 4; ++reg) {
+          const bool row_ok = RT<R>::SMALL || (16 * t + 4 * reg + q < ND);
+          const long o = row_ok ? ub_q + (long)(16 * t + 4 * reg) * 3 * 16 : ubase;
 #pragma unroll
-      for (int t = 0; t < NSM; ++t) accs[i][t] = R(0);
+          for (int i = 0; i < 3; ++i) {
+            po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
+            pa[t][reg][i] = LD_STREAM(&aux[o + i * 16]);
+          }
+        }
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) {
+        const int a = 16 * MTF + 4 * t + q;
+        const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          pos[t][i] = LD_STREAM(&out[o + i * 16]);
+          pas[t][i] = LD_STREAM(&aux[o + i * 16]);
+        }
+      }
+      const R icn = R(1) / cn;
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[i][t][reg] = (cs * po[t][reg][i] + ca * pa[t][reg][i]) * icn;
+#pragma unroll
+      for (int t = 0; t < NSM; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accs[i][t] = (cs * pos[t][i] + ca * pas[t][i]) * icn;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int t = 0; t < MTF; ++t) acc[i][t] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NSM; ++t) accs[i][t] = R(0);
+      }
     }
 
     SG_PRIO(SG_PRIO_VOL);
@@ -1455,11 +1513,6 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
     // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
     // wave runs in program order, so all reads below precede the writes of the epilogue.
-    const long e = (L.valid ? L.c : 0) * 6 + k;
-    const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
-    int qo3 = q * 3 * 16;  // output rows: per-item base + compile-time offsets (see brow)
-    asm volatile("" : "+v"(qo3));
-    const long ub_q = ubase + qo3;
     if (A.sponge_slot != nullptr) {
       const int slot = L.active ? A.sponge_slot[e] : -1;
       if (__any(slot >= 0)) {
@@ -1498,13 +1551,18 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 
     // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345).
     //      All loads first (results built in place in the accumulators), all stores last: see G.
-    if (MODE == 1) {
-      R cs = c_self, ca = c_aux, cn = c_new;
-      if (A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
-        cs = (R)A.rho2[2 * e];
-        ca *= (R)A.rho2[2 * e + 1];
-        cn *= (R)A.rho2[2 * e + 1];
-      }
+    if (MODE == 1 && early) {
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[i][t][reg] = cn * acc[i][t][reg];
+#pragma unroll
+      for (int t = 0; t < NSM; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accs[i][t] = cn * accs[i][t];
+    } else if (MODE == 1) {
       // every old value of the item is requested before the first one is used: one memory latency
       // per item instead of one per row tile (the lifts' registers are free by now)
       R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
