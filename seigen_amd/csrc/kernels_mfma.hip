@@ -1327,7 +1327,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #ifndef SG_F1_EARLY
 #define SG_F1_EARLY 1
 #endif
-    const bool early = MODE == 1 && SG_F1_EARLY && uniform_nonzero(c_new);
+    // (double only: in float u / c_new could leave the exponent range for small dt)
+    const bool early = MODE == 1 && SG_F1_EARLY && sizeof(R) == 8 && uniform_nonzero(c_new);
     R cs = c_self, ca = c_aux, cn = c_new;
     if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
       cs = (R)A.rho2[2 * e];
