@@ -557,3 +557,42 @@ def test_second_region_is_never_empty_for_the_shipped_multi_rank_configurations(
             cubes = sum(buf[6 * i + 3] * buf[6 * i + 4] * buf[6 * i + 5] for i in range(cnt))
             total = int(np.prod(p.n))
             assert cnt >= 1 and cubes >= total // 5, (dim, n, grid, r, cubes, total)
+
+
+def test_node_coordinates_do_not_depend_on_the_partition():
+    """Advisor finding of round 3: coordinates computed from a shifted origin (a block of a partitioned mesh, a slab of
+    a chunked scan, the sub-box of a source's support hint) differed by an ulp from those of the whole mesh, so a source
+    box whose faces lie on node lines could select different nodes under different partitions.  With sg_config::cube0
+    every path adds the integers first: bitwise the coordinates of the whole mesh - for awkward cell sizes, every block
+    of a 1 x 2 x 2 and a 2 x 2 x 1 grid, the slab-by-slab scan, and the support scan restricted to a box."""
+    from seigen_amd.mesh import BoxMesh
+    from seigen_amd import ElasticLF4  # noqa: F401  (the scan helper lives on the solver class)
+    n, L = (7, 5, 6), (300.0 * 7 / 9, 1.3, 0.77)
+    mesh = BoxMesh(n[0], n[1], n[2], *L)
+    V = FunctionSpace(mesh, "DG", 3)
+    full = V.node_coords()
+    chunks = np.concatenate([X for _, X in V.node_coords_chunks(max_nodes=3000)])
+    assert np.array_equal(chunks, full)
+    for grid in ((1, 2, 2), (2, 2, 1)):
+        world = int(np.prod(grid))
+        for r in range(world):
+            m2 = BoxMesh(n[0], n[1], n[2], *L)
+            p = Partition(n, r, world, grid)
+            m2.set_partition(p)
+            Xb = FunctionSpace(m2, "DG", 3).node_coords()
+            ax = [np.arange(p.start[a], p.start[a] + p.n[a]) for a in range(3)]
+            cube = (ax[0][None, None, :] + n[0] * (ax[1][None, :, None] + n[1] * ax[2][:, None, None])).reshape(-1)
+            cells = (cube[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
+            assert np.array_equal(Xb, full[cells]), (grid, r)
+    # the sub-box evaluation of the support scan (sg_config with a cube offset), against the same cubes of the whole mesh
+    cfg = _lib.SgConfig()
+    cfg.dim, cfg.degree = 3, 3
+    sub_o, sub_n = (2, 1, 3), (3, 2, 2)
+    for a in range(3):
+        cfg.n[a], cfg.h[a], cfg.origin[a], cfg.cube0[a] = sub_n[a], L[a] / n[a], 0.0, sub_o[a]
+    X = np.empty((int(np.prod(sub_n)) * 6, V.nd, 3))
+    assert lib().sg_block_node_coords(C.byref(cfg), 3, X.ctypes.data, X.nbytes) == 0
+    ax = [np.arange(sub_o[a], sub_o[a] + sub_n[a]) for a in range(3)]
+    cube = (ax[0][None, None, :] + n[0] * (ax[1][None, :, None] + n[1] * ax[2][:, None, None])).reshape(-1)
+    cells = (cube[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
+    assert np.array_equal(X, full[cells])
