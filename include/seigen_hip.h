@@ -78,9 +78,10 @@ typedef struct sg_config {
   int32_t n[3];      /* squares / cubes per axis in THIS block */
   double h[3];       /* cell size per axis */
   double origin[3];  /* physical coordinate of the block's low corner (of cube -cube0, see below) */
-  int32_t diagonal;  /* 2-D only: 0 = "left" (Firedrake default), 1 = "right": how each square is cut into two
-                        triangles; 2 = not at all: quadrilateral cells with the tensor-product element DQ_k, what
-                        FunctionSpace(mesh, "DG", k) (elastic.py:81-82) is on a quadrilateral mesh */
+  int32_t diagonal;  /* 2-D: 0 = "left" (Firedrake default), 1 = "right": how each square is cut into two triangles;
+                        2 = not at all: quadrilateral cells (dim 2) or hexahedral cells (dim 3, degrees 1 and 2) with
+                        the tensor-product element DQ_k, what FunctionSpace(mesh, "DG", k) (elastic.py:81-82) is on
+                        a quadrilateral / hexahedral mesh.  3-D simplicial blocks ignore 0 / 1 (one Kuhn cut). */
   int32_t nbr_mask;  /* bit (2*axis + side) set: that side touches another block (halo), else free surface */
   int32_t device;    /* HIP device ordinal */
   int32_t dtype;     /* 0: FP64 storage and arithmetic - the reference's precision (elastic.py:442 'double'),
@@ -282,8 +283,8 @@ int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out
 /* phi[p][a]: Lagrange basis of P_degree (degree <= 8) at reference points xi[p][dim] - the
  * tabulation behind Function evaluation / the error functional of eigenmode_2d.py:49-63. */
 int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi);
-/* The same two for a cell type: 0 = simplex (the functions above), 1 = tensor-product cell (2-D: the unit square,
- * (degree+1)^2 equispaced nodes with the first coordinate fastest; facets 0: x = 0, 1: x = 1, 2: y = 0, 3: y = 1) -
+/* The same two for a cell type: 0 = simplex (the functions above), 1 = tensor-product cell (the unit square / cube,
+ * (degree+1)^dim equispaced nodes with the first coordinate fastest; facet 2m: x_m = 0, facet 2m+1: x_m = 1) -
  * the element of sg_config::diagonal = 2. */
 int64_t sg_reference_operator_cell(int cell_type, int dim, int degree, int which, int q, double* out, size_t nbytes);
 int sg_tabulate_cell(int cell_type, int dim, int degree, int64_t npts, const double* xi, double* phi);

@@ -39,18 +39,13 @@ def reference_operators(dim, P, kind="simplex"):
     Minv = np.linalg.inv(np.einsum('q,qa,qb->ab', wq, phi, phi))
     D = np.stack([Minv @ np.einsum('q,qa,qb->ab', wq, dphi[:, :, r], phi) for r in range(dim)])
     nfaces = refelem.el_nfaces(dim, kind)
+    bary, wf, fact = refelem.el_facet_rule(dim, 2 * P, kind)
     if kind == "tensor":
-        nf = P + 1
-        t, wf = refelem.simplex_quadrature(1, 2 * P)
-        bary = np.concatenate([1 - t, t], axis=1)
-        V = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
-        fact = 1.0
+        nf = (P + 1) ** (dim - 1)
+        V = np.array([[(v >> m) & 1 for m in range(dim)] for v in range(1 << dim)], dtype=np.float64)
     else:
         nf = refelem.nnodes(dim - 1, P) if dim > 1 else 1
-        xf, wf = refelem.simplex_quadrature(dim - 1, 2 * P)
-        bary = np.concatenate([1 - xf.sum(1, keepdims=True), xf], axis=1)
         V = np.vstack([np.zeros(dim), np.eye(dim)])
-        fact = float(math.factorial(dim - 1))
     L = np.zeros((nfaces, nd, nf))
     fnode = np.zeros((nfaces, nf), dtype=np.int32)
     for f in range(nfaces):

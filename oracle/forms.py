@@ -73,11 +73,10 @@ class ScalarOperators(object):
         self.K = [blockdiag(Kloc[j]) for j in range(d)]
 
         # ---- facet integrals (dS, ds) ---------------------------------------------
-        xf, wf = refelem.simplex_quadrature(d - 1, 2 * P + qdeg_extra)   # on the unit (d-1)-simplex
+        # facet rule: weights of the facet's vertices at every point (barycentric on simplices, multilinear on the
+        # faces of tensor cells), weights wf, and fact with  sum(wf) * fact = 1
+        baryf, wf, fact = refelem.el_facet_rule(d, 2 * P + qdeg_extra, kind)
         nqf = len(wf)
-        # barycentric coordinates of facet quadrature points wrt the facet's vertices
-        baryf = np.concatenate([1.0 - xf.sum(axis=1, keepdims=True), xf], axis=1)  # [q, d]
-        fact = float(np.prod(np.arange(1, d)))   # (d-1)!  : weights sum to 1/(d-1)!
 
         def trace_table(cells, faces, xphys):
             """phi of `cells` at physical points xphys [n,q,d] -> [n,q,nd]."""
@@ -92,7 +91,7 @@ class ScalarOperators(object):
                 if len(sel) == 0:
                     continue
                 fv = refelem.el_face_vertices(d, ff, kind)
-                V = mesh.vertices[mesh.cells[cells[sel]][:, fv]]      # [n, d, d]
+                V = mesh.vertices[mesh.cells[cells[sel]][:, fv]]      # [n, facet vertices, d]
                 X[sel] = np.einsum('qv,nvi->nqi', baryf, V)
             return X
 

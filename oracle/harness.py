@@ -90,8 +90,8 @@ class Eigenmode2D(object):
 
 
 class Eigenmode3D(object):
-    def __init__(self, N, degree, dt):
-        self.mesh = omesh.UnitCubeMesh(N, N, N)                           # eigenmode_3d.py:11
+    def __init__(self, N, degree, dt, hexahedral=False):
+        self.mesh = omesh.UnitCubeMesh(N, N, N, hexahedral=hexahedral)    # eigenmode_3d.py:11
         self.elastic = OracleLF4(self.mesh, degree)
         self.elastic.density = 1.0                                        # :17-20
         self.elastic.dt = dt

@@ -50,8 +50,8 @@ def class_table(dim, diagonal="left"):
 
 
 class Mesh(object):
-    """vertices [nv, dim]; cells [nc, dim+1] vertex ids (kind "simplex"), or [nc, 4] for the affine quadrilaterals
-    of kind "tensor" (local vertices (0,0), (1,0), (0,1), (1,1): refelem.QUAD_FACE_VERTICES)."""
+    """vertices [nv, dim]; cells [nc, dim+1] vertex ids (kind "simplex"), or [nc, 2^dim] for the affine quadrilaterals
+    / hexahedra of kind "tensor" (local vertex v at the corner whose coordinate m is bit m of v, refelem.py)."""
 
     def __init__(self, vertices, cells, kind="simplex"):
         self.vertices = np.asarray(vertices, dtype=np.float64)
@@ -68,7 +68,10 @@ class Mesh(object):
         X = self.vertices[self.cells]              # [nc, d+1, d]
         self.v0 = X[:, 0, :]
         # J[:, i, m] = d x_i / d xi_m
-        self.J = np.transpose(X[:, 1:d + 1, :] - X[:, :1, :], (0, 2, 1))   # (quadrilaterals: affine, edges 0-1 and 0-2)
+        if self.kind == "tensor":                  # affine: the edges from vertex 0 to the vertices 1, 2 (, 4)
+            self.J = np.transpose(X[:, [1 << m for m in range(d)], :] - X[:, :1, :], (0, 2, 1))
+        else:
+            self.J = np.transpose(X[:, 1:d + 1, :] - X[:, :1, :], (0, 2, 1))
         self.detJ = np.linalg.det(self.J)
         self.Jinv = np.linalg.inv(self.J)          # [nc, m, i] = d xi_m / d x_i
 
@@ -124,7 +127,7 @@ class Mesh(object):
                 t2 = X[:, fv[2], :] - P0
                 cr = np.cross(t1, t2)
                 nrm = np.linalg.norm(cr, axis=1)
-                ar = 0.5 * nrm
+                ar = nrm if self.kind == "tensor" else 0.5 * nrm      # parallelogram / triangle
                 nn = cr / nrm[:, None]
             # orient away from the opposite vertex
             sgn = np.sign(np.einsum('ij,ij->i', nn, P0 - opp))
@@ -139,14 +142,15 @@ class Mesh(object):
 
 
 def structured(dim, n, L, diagonal="left", origin=None, quadrilateral=False):
-    """n = cells per axis (tuple), L = extents (tuple).  quadrilateral (2-D): the squares themselves are the cells
-    ([upstream] ``UnitSquareMesh(N, N, quadrilateral=True)``)."""
+    """n = cells per axis (tuple), L = extents (tuple).  quadrilateral: the squares (2-D) or cubes (3-D, hexahedra)
+    themselves are the cells ([upstream] ``UnitSquareMesh(N, N, quadrilateral=True)``, ``ExtrudedMesh`` of it)."""
     n = tuple(int(x) for x in n)
     L = tuple(float(x) for x in L)
     origin = (0.0,) * dim if origin is None else tuple(origin)
-    if quadrilateral and dim != 2:
-        raise ValueError("tensor-product cells: 2-D only")
-    classes = [[(0, 0), (1, 0), (0, 1), (1, 1)]] if quadrilateral else class_table(dim, diagonal)
+    if quadrilateral and dim == 1:
+        raise ValueError("tensor-product cells: 2-D and 3-D")
+    classes = ([[tuple((v >> m) & 1 for m in range(dim)) for v in range(1 << dim)]] if quadrilateral
+               else class_table(dim, diagonal))
     nvx = [k + 1 for k in n]
     # vertex id with x fastest
     strides = [1]
@@ -176,12 +180,12 @@ def RectangleMesh(nx, ny, Lx, Ly, diagonal="left", quadrilateral=False):
     return structured(2, (nx, ny), (Lx, Ly), diagonal, quadrilateral=quadrilateral)
 
 
-def UnitCubeMesh(nx, ny, nz):
-    return structured(3, (nx, ny, nz), (1.0, 1.0, 1.0))
+def UnitCubeMesh(nx, ny, nz, hexahedral=False):
+    return structured(3, (nx, ny, nz), (1.0, 1.0, 1.0), quadrilateral=hexahedral)
 
 
-def BoxMesh(nx, ny, nz, Lx, Ly, Lz):
-    return structured(3, (nx, ny, nz), (Lx, Ly, Lz))
+def BoxMesh(nx, ny, nz, Lx, Ly, Lz, hexahedral=False):
+    return structured(3, (nx, ny, nz), (Lx, Ly, Lz), quadrilateral=hexahedral)
 
 
 def IntervalMesh(n, L):

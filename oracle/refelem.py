@@ -142,21 +142,26 @@ def node_ref_coords(dim, P):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Tensor-product cells (quadrilaterals).  [upstream] On a quadrilateral mesh ``FunctionSpace(mesh, "DG", k)`` -
-# the call of seigen/elastic.py:81-82, which is family-agnostic - is DQ_k: the tensor product of two interval
-# DiscontinuousLagrange elements, i.e. the Lagrange basis at the (k+1)^2 equispaced lattice points of the unit
-# square.  Node order: first reference coordinate fastest (this build's convention, as for simplices).
-# Local vertices: 0 (0,0), 1 (1,0), 2 (0,1), 3 (1,1); faces: 0 x=0, 1 x=1, 2 y=0, 3 y=1.
+# Tensor-product cells (quadrilaterals, hexahedra).  [upstream] On a quadrilateral or hexahedral mesh
+# ``FunctionSpace(mesh, "DG", k)`` - the call of seigen/elastic.py:81-82, which is family-agnostic - is DQ_k: the
+# tensor product of interval DiscontinuousLagrange elements, i.e. the Lagrange basis at the (k+1)^dim equispaced
+# lattice points of the unit square / cube.  Node order: first reference coordinate fastest (this build's convention,
+# as for simplices).  Local vertex v sits at the corner whose coordinate m is bit m of v (2-D: 0 (0,0), 1 (1,0),
+# 2 (0,1), 3 (1,1)); face 2m is x_m = 0, face 2m + 1 is x_m = 1; a face's vertices in ascending order.
 # The functions below dispatch on `kind` ("simplex" / "tensor"); the simplex ones above are unchanged.
 QUAD_FACE_VERTICES = [[0, 2], [1, 3], [0, 1], [2, 3]]
+
+
+def tensor_face_vertices(dim, f):
+    return [v for v in range(1 << dim) if ((v >> (f // 2)) & 1) == (f % 2)]
 
 
 def el_lattice(dim, P, kind="simplex"):
     if kind == "simplex" or dim == 1:
         return lattice(dim, P)
-    if dim != 2:
-        raise ValueError("tensor-product cells: 2-D only")
-    return np.array([(a1, a2) for a2 in range(P + 1) for a1 in range(P + 1)], dtype=np.int64)
+    if dim == 2:
+        return np.array([(a1, a2) for a2 in range(P + 1) for a1 in range(P + 1)], dtype=np.int64)
+    return np.array([(a1, a2, a3) for a3 in range(P + 1) for a2 in range(P + 1) for a1 in range(P + 1)], dtype=np.int64)
 
 
 def el_nnodes(dim, P, kind="simplex"):
@@ -189,15 +194,34 @@ def el_quadrature(dim, degree, kind="simplex"):
     if kind == "simplex" or dim <= 1:
         return simplex_quadrature(dim, degree)
     t, w = _gj01(max(1, degree // 2 + 1), 0.0)
-    pts = np.array([(ti, tj) for tj in t for ti in t])
-    wts = np.array([wi * wj for wj in w for wi in w])
+    if dim == 2:
+        pts = np.array([(ti, tj) for tj in t for ti in t])
+        wts = np.array([wi * wj for wj in w for wi in w])
+    else:
+        pts = np.array([(ti, tj, tk) for tk in t for tj in t for ti in t])
+        wts = np.array([wi * wj * wk for wk in w for wj in w for wi in w])
     return pts, wts
+
+
+def el_facet_rule(dim, degree, kind="simplex"):
+    """(weights of the facet's vertices at every quadrature point [q, nfv], wf [q], fact): a facet integral is
+    sum_q wf[q] * fact * measure(facet) * g(sum_v bary[q, v] X_v).  Simplices: the rule of the unit (dim-1)-simplex
+    in barycentric form; tensor cells: the Gauss-Legendre product rule of the unit (dim-1)-cube with the multilinear
+    vertex weights (vertices in ascending order, el_face_vertices)."""
+    if kind == "simplex" or dim <= 2:
+        xf, wf = simplex_quadrature(dim - 1, degree)
+        bary = np.concatenate([1.0 - xf.sum(axis=1, keepdims=True), xf], axis=1)
+        return bary, wf, float(np.prod(np.arange(1, dim)))
+    xf, wf = el_quadrature(dim - 1, degree, kind)
+    a, b = xf[:, 0], xf[:, 1]
+    bary = np.stack([(1 - a) * (1 - b), a * (1 - b), (1 - a) * b, a * b], axis=1)
+    return bary, wf, 1.0
 
 
 def el_face_vertices(dim, f, kind="simplex"):
     if kind == "simplex":
         return face_vertices(dim, f)
-    return QUAD_FACE_VERTICES[f]
+    return tensor_face_vertices(dim, f)
 
 
 def el_face_nodes(dim, P, f, kind="simplex"):

@@ -14,6 +14,7 @@ KernelPath choose_kernel_path(const sg_config& cfg) {
     // kernels (host layout); same size threshold and SEIGEN_HIP_PATH overrides as for triangles
     const char* pe = std::getenv("SEIGEN_HIP_PATH");
     const bool fg = pe && std::strcmp(pe, "generic") == 0, ft = pe && std::strcmp(pe, "tile") == 0;
+    // (hexahedra: the table-driven generic kernel, DQ_1 and DQ_2)
     kp.tile = cfg.dim == 2 && tile2d_supported_quad(cfg.degree) && !fg &&
               (ft || (int64_t)cfg.n[0] * cfg.n[1] >= SG_TILE2D_MIN_CELLS / 2);
     kp.gw = kp.tile ? 16 : 1;
@@ -138,6 +139,10 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(h, SG_ERR_ARG, "device ordinal out of range");
   HIPCHECK(h, hipSetDevice(cfg->device));
 
+  if (cfg->diagonal == SG_DIAGONAL_QUAD && cfg->dim == 3 && cfg->degree > 2)
+    return fail(h, SG_ERR_ARG, "hexahedral cells: degrees 1 and 2 (DQ_k on hexahedra runs on the table-driven generic kernel, whose "
+                               "operators must fit the LDS; higher degrees want sum-factorised kernels)");
+  if (cfg->diagonal == SG_DIAGONAL_QUAD && cfg->dim == 1) return fail(h, SG_ERR_ARG, "tensor-product cells need dim 2 or 3");
   try {
     h->re = make_refelem(cfg->dim, cfg->degree, cfg->diagonal == SG_DIAGONAL_QUAD ? KIND_TENSOR : KIND_SIMPLEX);
     std::memset(&h->md, 0, sizeof(MeshDev));
@@ -437,15 +442,14 @@ struct NodeGeom {
     d = c->dim;
     degree = deg;
     const bool quad = c->diagonal == SG_DIAGONAL_QUAD;
-    if (quad && d != 2) return false;
+    if (quad && d != 2 && d != 3) return false;
     const int kind = quad ? KIND_TENSOR : KIND_SIMPLEX;
     lattice_points(d, degree, lat, kind);
     nq = num_nodes(d, degree, kind);
-    if (quad) {   // vertex 0 the low corner, vertex 1 / 2 one cell along x / y: the affine map of refelem.hpp's unit square
+    if (quad) {   // vertex 0 the low corner, vertex 1 / 2 / 3 one cell along x / y / z: the affine map of the unit square / cube
       std::memset(off, 0, sizeof(off));
       ncls = 1;
-      off[0][1][0] = 1;
-      off[0][2][1] = 1;
+      for (int m = 0; m < d; ++m) off[0][m + 1][m] = 1;
     } else {
       class_vertices(d, c->diagonal, ncls, off);
     }
@@ -862,7 +866,7 @@ int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi
 
 int sg_tabulate_cell(int cell_type, int dim, int degree, int64_t npts, const double* xi, double* phi) {
   if (dim < 1 || dim > 3 || degree < 1 || degree > 8 || npts < 0 || !xi || !phi) return SG_ERR_ARG;
-  if (cell_type != KIND_SIMPLEX && !(cell_type == KIND_TENSOR && dim <= 2)) return SG_ERR_ARG;
+  if (cell_type != KIND_SIMPLEX && cell_type != KIND_TENSOR) return SG_ERR_ARG;
   tabulate(dim, degree, (int)npts, xi, phi, cell_type);
   return SG_OK;
 }

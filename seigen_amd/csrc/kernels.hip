@@ -335,7 +335,12 @@ static int launch_d(int kind, int P, const StageArgs& a, hipStream_t s) {
 
 int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.tensor) return dim == 2 ? launch_quad(kind, P, a, s) : -1;
+  if (a.tensor) {
+    if (dim == 2) return launch_quad(kind, P, a, s);
+    if (dim == 3 && P == 1) return launch_dp<3, 1, 1>(kind, a, s);      // hexahedra, DQ_1: 8 nodes, facets of 4
+    if (dim == 3 && P == 2) return launch_dp<3, 2, 1>(kind, a, s);      // DQ_2: 27 nodes, facets of 9
+    return -1;
+  }
   switch (dim) {
     case 1: return launch_d<1>(kind, P, a, s);
     case 2: return launch_d<2>(kind, P, a, s);

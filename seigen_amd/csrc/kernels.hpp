@@ -15,9 +15,9 @@ constexpr int SG_MAX_BOXES = 7;
 // TP = 1: the tensor-product element on quadrilaterals (DIM = 2; generic kernels only).
 template <int DIM, int P, int TP = 0>
 struct ElemDims {
-  static constexpr int ND = TP ? (P + 1) * (P + 1)
+  static constexpr int ND = TP ? (DIM == 3 ? (P + 1) * (P + 1) * (P + 1) : (P + 1) * (P + 1))
                                : (DIM == 1) ? (P + 1) : (DIM == 2) ? (P + 1) * (P + 2) / 2 : (P + 1) * (P + 2) * (P + 3) / 6;
-  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (P + 1) * (P + 2) / 2;
+  static constexpr int NF = (DIM == 1) ? 1 : (DIM == 2) ? (P + 1) : (TP ? (P + 1) * (P + 1) : (P + 1) * (P + 2) / 2);
   static constexpr int NFACES = TP ? 2 * DIM : DIM + 1;
   static constexpr int NCLS = TP ? 1 : (DIM == 1) ? 1 : (DIM == 2) ? 2 : 6;
 };

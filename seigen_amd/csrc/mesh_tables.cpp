@@ -65,21 +65,21 @@ static void invert_small(int d, const double J[3][3], double Ji[3][3], double& d
   }
 }
 
-// Quadrilateral cells (diagonal == SG_DIAGONAL_QUAD): the squares themselves, one class, four facets
-// (0: x = 0, 1: x = 1, 2: y = 0, 3: y = 1, refelem.hpp); facet nodes run along the transverse axis on both
-// sides of a facet, so facet node b meets the neighbour's facet node b.
-static void build_quad_tables(int P, const double h[3], const int* fnode, MeshDev& md) {
-  md.dim = 2;
+// Tensor-product cells (diagonal == SG_DIAGONAL_QUAD): the squares / cubes themselves, one class, 2 dim facets
+// (0: x = 0, 1: x = 1, 2: y = 0, 3: y = 1, 4: z = 0, 5: z = 1, refelem.hpp); facet nodes count the transverse lattice
+// coordinates on both sides of a facet, so facet node b meets the neighbour's facet node b.
+static void build_quad_tables(int dim, int P, const double h[3], const int* fnode, MeshDev& md) {
+  md.dim = dim;
   md.P = P;
   md.ncls = 1;
-  md.nfaces = 4;
+  md.nfaces = 2 * dim;
   md.halo_per_cube = 1;
   const int nf = md.nf;
-  for (int f = 0; f < 4; ++f)
+  for (int f = 0; f < md.nfaces; ++f)
     for (int b = 0; b < nf; ++b) md.fnode[f][b] = (uint8_t)fnode[f * nf + b];
   for (int r = 0; r < 3; ++r)
-    for (int j = 0; j < 3; ++j) md.Jinv[0][r][j] = (r == j && r < 2) ? 1.0 / h[r] : 0.0;
-  for (int f = 0; f < 4; ++f) {
+    for (int j = 0; j < 3; ++j) md.Jinv[0][r][j] = (r == j && r < dim) ? 1.0 / h[r] : 0.0;
+  for (int f = 0; f < md.nfaces; ++f) {
     const int axis = f / 2, dir = (f % 2) ? 1 : -1;
     for (int j = 0; j < 3; ++j) md.cn[0][f][j] = (j == axis) ? dir / h[axis] : 0.0;   // |F| / |K| = 1 / h_axis
     md.nb_axis[0][f] = axis;
@@ -99,8 +99,9 @@ static void build_quad_tables(int P, const double h[3], const int* fnode, MeshDe
 void build_mesh_tables(int dim, int P, int diagonal, const double h[3], const int* fnode, const int* lattice,
                        MeshDev& md) {
   if (diagonal == SG_DIAGONAL_QUAD) {
-    if (dim != 2) throw std::runtime_error("quadrilateral cells: 2-D only");
-    build_quad_tables(P, h, fnode, md);
+    if (dim != 2 && dim != 3) throw std::runtime_error("tensor-product cells: quadrilaterals (2-D) and hexahedra (3-D)");
+    if (md.nf > MAX_NF) throw std::runtime_error("hexahedra: degrees 1 and 2 (a facet of DQ_3 has 16 nodes)");
+    build_quad_tables(dim, P, h, fnode, md);
     return;
   }
   int off[MAX_CLS][4][3];

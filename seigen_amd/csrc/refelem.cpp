@@ -23,12 +23,13 @@ void lattice_points(int dim, int P, std::vector<int>& out, int kind) {
   if (dim == 1) {
     for (int a = 0; a <= P; ++a) out.push_back(a);
   } else if (kind == KIND_TENSOR) {
-    if (dim != 2) throw std::runtime_error("tensor-product cells: 2-D only");
-    for (int a2 = 0; a2 <= P; ++a2)
-      for (int a1 = 0; a1 <= P; ++a1) {
-        out.push_back(a1);
-        out.push_back(a2);
-      }
+    for (int a3 = 0; a3 <= (dim == 3 ? P : 0); ++a3)
+      for (int a2 = 0; a2 <= P; ++a2)
+        for (int a1 = 0; a1 <= P; ++a1) {
+          out.push_back(a1);
+          out.push_back(a2);
+          if (dim == 3) out.push_back(a3);
+        }
   } else if (dim == 2) {
     for (int a2 = 0; a2 <= P; ++a2)
       for (int a1 = 0; a1 <= P - a2; ++a1) {
@@ -170,53 +171,73 @@ static int lattice_index(int dim, int P, const std::vector<int>& lat, const int*
   return -1;
 }
 
-// The tensor-product element from the interval element (Kronecker products: node a = a1 + (P+1) a2):
-//   Mhat = M1(y) x M1(x),  D_0 = I x D1,  D_1 = D1 x I,
-//   L_f[(a2, a1)][b] = M1^-1[a_axis][at] delta(a_transverse, b)   (face f: axis f / 2 at node at = 0 or P),
+// The tensor-product element from the interval element (Kronecker products: node a = a1 + (P+1) (a2 + (P+1) a3)):
+//   Mhat = M1 x M1 (x M1),  D_r = D1 along axis r, the identity along the others,
+//   L_f[a][b] = M1^-1[a_axis][at] delta(transverse(a), b)   (face f: axis f / 2 at node at = 0 or P; facet node b counts
+//   the transverse lattice coordinates, the lower axis fastest),
 // so the conditioning is the interval's (a 25 x 25 Vandermonde matrix of tensor monomials would cost five digits).
+// dim = 2: quadrilaterals (4 faces); dim = 3: hexahedra (6 faces: x = 0, x = 1, y = 0, y = 1, z = 0, z = 1).
 static RefElem make_tensor_refelem(int dim, int P) {
-  if (dim != 2) throw std::runtime_error("tensor-product cells are implemented in 2-D (quadrilaterals) only");
+  if (dim != 2 && dim != 3) throw std::runtime_error("tensor-product cells: quadrilaterals (2-D) and hexahedra (3-D)");
   const RefElem r1 = make_refelem(1, P, KIND_SIMPLEX);
-  const int n1 = P + 1, nd = n1 * n1;
+  const int n1 = P + 1;
+  int nd = 1, nf = 1;
+  for (int i = 0; i < dim; ++i) nd *= n1;
+  for (int i = 0; i < dim - 1; ++i) nf *= n1;
   RefElem re;
   re.dim = dim;
   re.P = P;
   re.kind = KIND_TENSOR;
   re.nd = nd;
-  re.nf = n1;
-  re.nfaces = 4;
+  re.nf = nf;
+  re.nfaces = 2 * dim;
   lattice_points(dim, P, re.lattice, KIND_TENSOR);
   re.Mhat.assign((size_t)nd * nd, 0.0);
   re.Minv.assign((size_t)nd * nd, 0.0);
-  re.D.assign((size_t)2 * nd * nd, 0.0);
-  for (int a2 = 0; a2 < n1; ++a2)
-    for (int a1 = 0; a1 < n1; ++a1)
-      for (int b2 = 0; b2 < n1; ++b2)
-        for (int b1 = 0; b1 < n1; ++b1) {
-          const int a = a1 + n1 * a2, b = b1 + n1 * b2;
-          re.Mhat[(size_t)a * nd + b] = r1.Mhat[a1 * n1 + b1] * r1.Mhat[a2 * n1 + b2];
-          re.Minv[(size_t)a * nd + b] = r1.Minv[a1 * n1 + b1] * r1.Minv[a2 * n1 + b2];
-          if (a2 == b2) re.D[((size_t)0 * nd + a) * nd + b] = r1.D[a1 * n1 + b1];
-          if (a1 == b1) re.D[((size_t)1 * nd + a) * nd + b] = r1.D[a2 * n1 + b2];
-        }
-  re.fnode.assign((size_t)4 * n1, -1);
-  re.L.assign((size_t)4 * nd * n1, 0.0);
-  for (int f = 0; f < 4; ++f) {
-    const int axis = f / 2, at = (f % 2) ? P : 0;
-    for (int b = 0; b < n1; ++b) re.fnode[(size_t)f * n1 + b] = axis == 0 ? at + n1 * b : b + n1 * at;
-    for (int a2 = 0; a2 < n1; ++a2)
-      for (int a1 = 0; a1 < n1; ++a1) {
-        const int a = a1 + n1 * a2, along = axis == 0 ? a1 : a2, across = axis == 0 ? a2 : a1;
-        re.L[((size_t)f * nd + a) * n1 + across] = r1.Minv[along * n1 + at];
+  re.D.assign((size_t)dim * nd * nd, 0.0);
+  auto coord = [&](int a, int axis) { return re.lattice[(size_t)a * dim + axis]; };
+  for (int a = 0; a < nd; ++a)
+    for (int b = 0; b < nd; ++b) {
+      double m = 1.0, mi = 1.0;
+      for (int i = 0; i < dim; ++i) {
+        m *= r1.Mhat[coord(a, i) * n1 + coord(b, i)];
+        mi *= r1.Minv[coord(a, i) * n1 + coord(b, i)];
       }
+      re.Mhat[(size_t)a * nd + b] = m;
+      re.Minv[(size_t)a * nd + b] = mi;
+      for (int r = 0; r < dim; ++r) {
+        bool same = true;
+        for (int i = 0; i < dim; ++i)
+          if (i != r && coord(a, i) != coord(b, i)) same = false;
+        if (same) re.D[((size_t)r * nd + a) * nd + b] = r1.D[coord(a, r) * n1 + coord(b, r)];
+      }
+    }
+  re.fnode.assign((size_t)re.nfaces * nf, -1);
+  re.L.assign((size_t)re.nfaces * nd * nf, 0.0);
+  // position of node a in the node list of a facet across `axis`: its transverse coordinates, the lower axis fastest
+  auto across = [&](int a, int axis) {
+    int idx = 0, mul = 1;
+    for (int i = 0; i < dim; ++i)
+      if (i != axis) {
+        idx += coord(a, i) * mul;
+        mul *= n1;
+      }
+    return idx;
+  };
+  for (int f = 0; f < re.nfaces; ++f) {
+    const int axis = f / 2, at = (f % 2) ? P : 0;
+    for (int a = 0; a < nd; ++a) {
+      if (coord(a, axis) == at) re.fnode[(size_t)f * nf + across(a, axis)] = a;
+      re.L[((size_t)f * nd + a) * nf + across(a, axis)] = r1.Minv[coord(a, axis) * n1 + at];
+    }
   }
   return re;
 }
 
 RefElem make_refelem(int dim, int P, int kind) {
   if (dim < 1 || dim > 3 || P < 1 || P > 4) throw std::runtime_error("dim must be 1..3 and degree 1..4");
-  if (kind != KIND_SIMPLEX && !(kind == KIND_TENSOR && dim == 2))
-    throw std::runtime_error("tensor-product cells are implemented in 2-D (quadrilaterals) only");
+  if (kind != KIND_SIMPLEX && !(kind == KIND_TENSOR && dim >= 2))
+    throw std::runtime_error("tensor-product cells: quadrilaterals (2-D) and hexahedra (3-D)");
   if (kind == KIND_TENSOR) return make_tensor_refelem(dim, P);
   RefElem re;
   re.dim = dim;
@@ -322,18 +343,26 @@ RefElem make_refelem(int dim, int P, int kind) {
 }
 
 void tabulate(int dim, int P, int npts, const double* xi, double* phi, int kind) {
-  if (kind == KIND_TENSOR && dim == 2) {
+  if (kind == KIND_TENSOR && dim >= 2) {
     const int n1 = P + 1;
-    std::vector<double> x(npts), y(npts), px((size_t)npts * n1), py((size_t)npts * n1);
-    for (int p = 0; p < npts; ++p) {
-      x[p] = xi[2 * p];
-      y[p] = xi[2 * p + 1];
+    int nd = 1;
+    for (int i = 0; i < dim; ++i) nd *= n1;
+    std::vector<double> x(npts);
+    std::vector<std::vector<double>> p1((size_t)dim, std::vector<double>((size_t)npts * n1));
+    for (int i = 0; i < dim; ++i) {
+      for (int p = 0; p < npts; ++p) x[p] = xi[(size_t)dim * p + i];
+      tabulate(1, P, npts, x.data(), p1[(size_t)i].data(), KIND_SIMPLEX);
     }
-    tabulate(1, P, npts, x.data(), px.data(), KIND_SIMPLEX);
-    tabulate(1, P, npts, y.data(), py.data(), KIND_SIMPLEX);
     for (int p = 0; p < npts; ++p)
-      for (int a2 = 0; a2 < n1; ++a2)
-        for (int a1 = 0; a1 < n1; ++a1) phi[(size_t)p * n1 * n1 + a1 + n1 * a2] = px[(size_t)p * n1 + a1] * py[(size_t)p * n1 + a2];
+      for (int a = 0; a < nd; ++a) {
+        double v = 1.0;
+        int rest = a;
+        for (int i = 0; i < dim; ++i) {
+          v *= p1[(size_t)i][(size_t)p * n1 + rest % n1];
+          rest /= n1;
+        }
+        phi[(size_t)p * nd + a] = v;
+      }
     return;
   }
   int nd = num_nodes(dim, P, kind);
@@ -357,18 +386,28 @@ void tabulate(int dim, int P, int npts, const double* xi, double* phi, int kind)
 }
 
 std::vector<double> sponge_tensor(int dim, int P, int q, int kind) {
-  if (kind == KIND_TENSOR && dim == 2) {   // A[(a2,a1)][(c2,c1)][(b2,b1)] = A1[a1][c1][b1] A1[a2][c2][b2]
+  if (kind == KIND_TENSOR && dim >= 2) {   // A[a][c][b] = prod over the axes of A1[a_i][c_i][b_i]
     const std::vector<double> A1 = sponge_tensor(1, P, q, KIND_SIMPLEX);
-    const int n1 = P + 1, q1 = q + 1, nd2 = n1 * n1, nq2 = q1 * q1;
-    std::vector<double> A((size_t)nd2 * nq2 * nd2);
-    for (int a2 = 0; a2 < n1; ++a2)
-      for (int a1 = 0; a1 < n1; ++a1)
-        for (int c2 = 0; c2 < q1; ++c2)
-          for (int c1 = 0; c1 < q1; ++c1)
-            for (int b2 = 0; b2 < n1; ++b2)
-              for (int b1 = 0; b1 < n1; ++b1)
-                A[((size_t)(a1 + n1 * a2) * nq2 + (c1 + q1 * c2)) * nd2 + (b1 + n1 * b2)] =
-                    A1[((size_t)a1 * q1 + c1) * n1 + b1] * A1[((size_t)a2 * q1 + c2) * n1 + b2];
+    const int n1 = P + 1, q1 = q + 1;
+    int ndt = 1, nqt = 1;
+    for (int i = 0; i < dim; ++i) {
+      ndt *= n1;
+      nqt *= q1;
+    }
+    std::vector<double> A((size_t)ndt * nqt * ndt);
+    for (int a = 0; a < ndt; ++a)
+      for (int c = 0; c < nqt; ++c)
+        for (int b = 0; b < ndt; ++b) {
+          double v = 1.0;
+          int ra = a, rc = c, rb = b;
+          for (int i = 0; i < dim; ++i) {
+            v *= A1[((size_t)(ra % n1) * q1 + rc % q1) * n1 + rb % n1];
+            ra /= n1;
+            rc /= q1;
+            rb /= n1;
+          }
+          A[((size_t)a * nqt + c) * ndt + b] = v;
+        }
     return A;
   }
   int nd = num_nodes(dim, P, kind), nq = num_nodes(dim, q, kind);

@@ -255,7 +255,8 @@ def locate(space, point):
     # lattice corners: nodes (0,..), (P,0,..), (0,P,..), (0,0,P)
     corner = {1: [0, P], 2: [0, P, space.nd - 1], 3: [0, P, (P + 1) * (P + 2) // 2 - 1, space.nd - 1]}[dim]
     if mesh.quadrilateral:
-        corner = [0, P, P * (P + 1)]              # (0,0), (1,0), (0,1) of the unit square
+        # (0,0), (1,0), (0,1) of the unit square; (0,0,0), (1,0,0), (0,1,0), (0,0,1) of the unit cube
+        corner = [0, P, P * (P + 1)] + ([P * (P + 1) ** 2] if dim == 3 else [])
     lins = []
     for cube in cands:
         lin, mul = 0, 1

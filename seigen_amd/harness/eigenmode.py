@@ -56,9 +56,10 @@ class Eigenmode2DLF4():
 
 class Eigenmode3DLF4():
 
-    def __init__(self, N, degree, dt, solver='explicit', output=True):
+    def __init__(self, N, degree, dt, solver='explicit', output=True, hexahedral=False):
         with timed_region('mesh generation'):
-            self.mesh = UnitCubeMesh(N, N, N)
+            # hexahedral=True: the same script on cubes - create() is family-agnostic (seigen/elastic.py:81-82)
+            self.mesh = UnitCubeMesh(N, N, N, hexahedral=hexahedral)
 
         self.elastic = ElasticLF4.create(self.mesh, "DG", degree, dimension=3,
                                          solver=solver, output=output)

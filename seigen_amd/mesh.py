@@ -116,11 +116,12 @@ class Mesh(object):
         self.L = tuple(float(x) for x in L)
         if diagonal not in ("left", "right"):
             raise ValueError("diagonal must be 'left' or 'right'")
-        if quadrilateral and self.dim != 2:
-            raise NotImplementedError("tensor-product cells are implemented in 2-D (quadrilateral=True) only")
+        if quadrilateral and self.dim == 1:
+            raise ValueError("tensor-product cells need a 2-D (quadrilateral=True) or 3-D (hexahedral=True) mesh")
         self.diagonal = diagonal
-        # [upstream] RectangleMesh / UnitSquareMesh(..., quadrilateral=True): the squares are the cells and
-        # FunctionSpace(mesh, "DG", k) (seigen/elastic.py:81-82) becomes the tensor-product element DQ_k
+        # [upstream] RectangleMesh / UnitSquareMesh(..., quadrilateral=True), and the hexahedral meshes extruded from
+        # them: the squares / cubes are the cells and FunctionSpace(mesh, "DG", k) (seigen/elastic.py:81-82) becomes
+        # the tensor-product element DQ_k.  `quadrilateral` is True for either (the flag means "tensor-product cells").
         self.quadrilateral = bool(quadrilateral)
         self.h = tuple(l / k for l, k in zip(self.L, self.n))
         self.origin = (0.0,) * self.dim
@@ -170,9 +171,9 @@ def UnitSquareMesh(nx, ny, diagonal="left", quadrilateral=False):
     return Mesh((nx, ny), (1.0, 1.0), diagonal, quadrilateral)
 
 
-def BoxMesh(nx, ny, nz, Lx, Ly, Lz):
-    return Mesh((nx, ny, nz), (Lx, Ly, Lz))
+def BoxMesh(nx, ny, nz, Lx, Ly, Lz, hexahedral=False):
+    return Mesh((nx, ny, nz), (Lx, Ly, Lz), quadrilateral=hexahedral)
 
 
-def UnitCubeMesh(nx, ny, nz):
-    return Mesh((nx, ny, nz), (1.0, 1.0, 1.0))
+def UnitCubeMesh(nx, ny, nz, hexahedral=False):
+    return Mesh((nx, ny, nz), (1.0, 1.0, 1.0), quadrilateral=hexahedral)

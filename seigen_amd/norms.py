@@ -40,12 +40,15 @@ def simplex_rule(dim, degree):
 
 def cell_rule(dim, degree, kind=0):
     """Quadrature on the reference cell: the simplex rule, or (kind 1, tensor-product cells) the Gauss-Legendre
-    product rule exact to `degree` PER VARIABLE on the unit square."""
+    product rule exact to `degree` PER VARIABLE on the unit square / cube."""
     if kind == 0 or dim == 1:
         return simplex_rule(dim, degree)
     t, w = _gj01(max(1, degree // 2 + 1), 0.0)
-    pts = np.array([(a, b) for b in t for a in t])
-    return pts, np.array([x * y for y in w for x in w])
+    if dim == 2:
+        pts = np.array([(a, b) for b in t for a in t])
+        return pts, np.array([x * y for y in w for x in w])
+    pts = np.array([(a, b, c) for c in t for b in t for a in t])
+    return pts, np.array([x * y * z for z in w for y in w for x in w])
 
 
 def tabulate(dim, degree, xi, kind=0):

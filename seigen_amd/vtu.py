@@ -17,8 +17,12 @@ _VTK_CELL = {1: 3, 2: 5, 3: 10}   # VTK_LINE, VTK_TRIANGLE, VTK_TETRA
 
 def vertex_nodes(dim, degree, quadrilateral=False):
     """Indices of the cell's vertices among its lattice nodes (first reference coordinate fastest); for a
-    quadrilateral in VTK_QUAD order (counter-clockwise)."""
+    quadrilateral in VTK_QUAD order (counter-clockwise), for a hexahedron in VTK_HEXAHEDRON order (the bottom face
+    counter-clockwise, then the top face)."""
     k = int(degree)
+    if quadrilateral and dim == 3:
+        bottom = [0, k, (k + 1) * (k + 1) - 1, k * (k + 1)]
+        return bottom + [b + k * (k + 1) ** 2 for b in bottom]
     if quadrilateral:
         return [0, k, (k + 1) * (k + 1) - 1, k * (k + 1)]
     if dim == 1:
@@ -51,7 +55,8 @@ def write_vtu(path, points, point_data):
         f.write('\n</DataArray>\n<DataArray type="Int64" Name="offsets" format="ascii">\n')
         f.write(" ".join("%d" % ((c + 1) * nv) for c in range(ncells)))
         f.write('\n</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n')
-        f.write(" ".join([str(9 if (dim == 2 and nv == 4) else _VTK_CELL[dim])] * ncells))   # 9: VTK_QUAD
+        # 9: VTK_QUAD, 12: VTK_HEXAHEDRON
+        f.write(" ".join([str(9 if (dim == 2 and nv == 4) else 12 if (dim == 3 and nv == 8) else _VTK_CELL[dim])] * ncells))
         f.write('\n</DataArray>\n</Cells>\n<PointData>\n')
         for name, arr in point_data.items():
             a = np.asarray(arr, dtype=np.float64)
@@ -124,13 +129,15 @@ def probe(path, name, xs):
     piece = ET.parse(path).getroot().find("UnstructuredGrid").find("Piece")
     types = [da for da in piece.find("Cells").findall("DataArray") if da.get("Name") == "types"][0].text.split()
     quad = dim == 2 and len(types) > 0 and types[0] == "9"           # VTK_QUAD: vertices counter-clockwise from the low corner
-    nv = 4 if quad else dim + 1
+    hexa = dim == 3 and len(types) > 0 and types[0] == "12"          # VTK_HEXAHEDRON: bottom face, then top face
+    nv = 4 if quad else 8 if hexa else dim + 1
     P = pts[:, :dim].reshape(-1, nv, dim)
     V = data[name].reshape(P.shape[0], nv, -1)
     out = np.empty((xs.shape[0], V.shape[2]))
-    if quad:
-        # affine quadrilaterals: reference coordinates from the edges 0-1 and 0-3, bilinear interpolation of the corners
-        T = np.stack([P[:, 1, :] - P[:, 0, :], P[:, 3, :] - P[:, 0, :]], axis=2)      # [cells, dim, 2]
+    if quad or hexa:
+        # affine cells: reference coordinates from the edges 0-1 and 0-3 (and 0-4), multilinear interpolation of the corners
+        T = np.stack([P[:, 1, :] - P[:, 0, :], P[:, 3, :] - P[:, 0, :]] + ([P[:, 4, :] - P[:, 0, :]] if hexa else []),
+                     axis=2)                                                           # [cells, dim, dim]
         Tinv = np.linalg.inv(T)
         for k, x in enumerate(xs):
             st = np.einsum("cij,cj->ci", Tinv, x[None, :] - P[:, 0, :])
@@ -138,8 +145,10 @@ def probe(path, name, xs):
             if not inside.any():
                 raise ValueError("point %r is outside the mesh" % (tuple(x),))
             c = int(np.nonzero(inside)[0][0])
-            a, b = st[c]
+            a, b = st[c][:2]
             w = np.array([(1 - a) * (1 - b), a * (1 - b), a * b, (1 - a) * b])
+            if hexa:
+                w = np.concatenate([(1 - st[c][2]) * w, st[c][2] * w])
             out[k] = w @ V[c]
         return out
     # barycentric coordinates of every query point in every cell

@@ -58,7 +58,7 @@ def test_library_tables_of_the_tensor_product_element(P):
     # a simplex call with the tensor entry points, and an unsupported cell type
     assert lib.sg_tabulate_cell(0, 2, P, 17, xi.ctypes.data, np.empty((17, (P + 1) * (P + 2) // 2)).ctypes.data) == 0
     assert lib.sg_tabulate_cell(2, 2, P, 17, xi.ctypes.data, phi.ctypes.data) < 0
-    assert lib.sg_reference_operator_cell(1, 3, P, 0, 0, None, 0) < 0     # hexahedra are not built
+    assert lib.sg_reference_operator_cell(1, 1, P, 0, 0, None, 0) < 0     # no tensor cells in 1-D
 
 
 def test_node_coordinates_and_neighbour_tables_of_a_quadrilateral_block():
