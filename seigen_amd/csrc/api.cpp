@@ -14,10 +14,15 @@ KernelPath choose_kernel_path(const sg_config& cfg) {
     // kernels (host layout); same size threshold and SEIGEN_HIP_PATH overrides as for triangles
     const char* pe = std::getenv("SEIGEN_HIP_PATH");
     const bool fg = pe && std::strcmp(pe, "generic") == 0, ft = pe && std::strcmp(pe, "tile") == 0;
-    // (hexahedra: the table-driven generic kernel, DQ_1 and DQ_2)
     kp.tile = cfg.dim == 2 && tile2d_supported_quad(cfg.degree) && !fg &&
               (ft || (int64_t)cfg.n[0] * cfg.n[1] >= SG_TILE2D_MIN_CELLS / 2);
-    kp.gw = kp.tile ? 16 : 1;
+    // hexahedra (DQ_1, DQ_2): the sum-factorised lane-per-cell kernels (kernels_lane.hip hex_stage) from
+    // SG_HEX_LANE_MIN_CELLS cubes up (below that the thread-per-node generic kernel has more parallelism);
+    // SEIGEN_HIP_PATH=lane / generic forces one or the other
+    const bool fl = pe && std::strcmp(pe, "lane") == 0;
+    kp.lane = cfg.dim == 3 && lane_supported_hex(cfg.dim, cfg.degree) && !fg &&
+              (fl || (int64_t)cfg.n[0] * cfg.n[1] * cfg.n[2] >= SG_HEX_LANE_MIN_CELLS);
+    kp.gw = kp.tile ? 16 : (kp.lane ? 64 : 1);
     return kp;
   }
   const int ncls = cfg.dim == 1 ? 1 : (cfg.dim == 2 ? 2 : 6);
@@ -182,7 +187,47 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   for (int f = 0; f < nfaces; ++f)
     for (int a = 0; a < nd; ++a)
       for (int b = 0; b < nf; ++b) Lt[((size_t)f * nf + b) * nd + a] = h->re.L[((size_t)f * nd + a) * nf + b];
-  if (h->use_lane) {
+  if (h->use_lane && h->re.kind == KIND_TENSOR) {
+    // hexahedral lane path (kernels_lane.hip hex_stage): the 1-D factors D1 [n1][n1] and lift1 [2][n1] of the
+    // tensor-product operators, read off the full tables along the first axis and checked against ALL of D_r, L_f
+    const int n1 = cfg->degree + 1;
+    auto node = [&](int a0, int a1, int a2) { return a0 + n1 * (a1 + n1 * a2); };
+    Dt.assign((size_t)n1 * n1 + 2 * n1, 0.0);
+    for (int m = 0; m < n1; ++m) {
+      for (int n = 0; n < n1; ++n) Dt[(size_t)m * n1 + n] = h->re.D[((size_t)0 * nd + node(m, 0, 0)) * nd + node(n, 0, 0)];
+      for (int s = 0; s < 2; ++s) Dt[(size_t)n1 * n1 + s * n1 + m] = h->re.L[((size_t)s * nd + node(m, 0, 0)) * nf + 0];
+    }
+    double worst = 0.0;
+    for (int a = 0; a < nd; ++a) {
+      const int ai[3] = {a % n1, (a / n1) % n1, a / (n1 * n1)};
+      for (int r = 0; r < 3; ++r) {
+        for (int b = 0; b < nd; ++b) {
+          const int bi[3] = {b % n1, (b / n1) % n1, b / (n1 * n1)};
+          const bool line = ai[(r + 1) % 3] == bi[(r + 1) % 3] && ai[(r + 2) % 3] == bi[(r + 2) % 3];
+          const double want = line ? Dt[(size_t)ai[r] * n1 + bi[r]] : 0.0;
+          worst = std::max(worst, std::fabs(h->re.D[((size_t)r * nd + a) * nd + b] - want));
+        }
+        for (int s = 0; s < 2; ++s)
+          for (int bp = 0; bp < nf; ++bp) {
+            const int b = h->re.fnode[(size_t)(2 * r + s) * nf + bp];
+            const int bi[3] = {b % n1, (b / n1) % n1, b / (n1 * n1)};
+            // facet nodes in ascending order: bp = lower transverse index + n1 * the upper one
+            const int lo = r == 0 ? 1 : 0, hi = r == 2 ? 1 : 2;
+            // ... and the neighbour's matching node is the one across the cube, at the same place of its facet list
+            int ni[3] = {bi[0], bi[1], bi[2]};
+            ni[r] = s ? 0 : n1 - 1;
+            if (bp != bi[lo] + n1 * bi[hi] || bi[r] != (s ? n1 - 1 : 0) || h->md.fnode[2 * r + s][bp] != b ||
+                h->md.nb_node[0][2 * r + s][bp] != node(ni[0], ni[1], ni[2]) || h->md.nb_fnode[0][2 * r + s][bp] != bp ||
+                h->md.nb_face[0][2 * r + s] != 2 * r + (1 - s) || h->md.nb_axis[0][2 * r + s] != r)
+              return fail(h, SG_ERR_ARG, "hexahedral element: unexpected facet node order");
+            const bool same = ai[lo] == bi[lo] && ai[hi] == bi[hi];
+            const double want = same ? Dt[(size_t)n1 * n1 + s * n1 + ai[r]] : 0.0;
+            worst = std::max(worst, std::fabs(h->re.L[((size_t)(2 * r + s) * nd + a) * nf + bp] - want));
+          }
+      }
+    }
+    if (worst > 1e-11) return fail(h, SG_ERR_ARG, "hexahedral element: the operator tables do not factorise");
+  } else if (h->use_lane) {
     // lane path: E_r = D_r - (L_0 R_0 - L_{r+1} R_{r+1}) / (2 (d-1)!) row-major (own-trace half of the
     // central flux folded into the volume operator, see mfma_tables.cpp), and L_f row-major
     double fact = 1.0;

@@ -174,6 +174,10 @@ int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream);
 // lane-per-cell path (1-D / 2-D; fields in the gw = 64 interleaved layout; a.Dt = E[r][a][b],
 // a.Lt = L[f][a][b'] row-major)
 bool lane_supported(int dim, int P);
+#ifndef SG_HEX_LANE_MIN_CELLS
+#define SG_HEX_LANE_MIN_CELLS 4096
+#endif
+bool lane_supported_hex(int dim, int P);   // a.tensor: hexahedra (sum-factorised; a.Dt = {D1, lift1})
 int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream);
 
 // 2-D MFMA tile path (P1..P4; fields in the gw = 16 interleaved layout; a.fragV / a.fragL = tile2d_frags_*).

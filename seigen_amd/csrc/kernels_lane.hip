@@ -363,6 +363,286 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
   }
 }
 
+// ---- hexahedral cells: sum-factorised lane-per-cell kernels (DQ_1, DQ_2) --------------------------------------------------
+// On the cubes of a structured block the tensor-product element factorises completely:
+//   D_r = I x .. x D1 x .. x I   (D1 = M1^-1 S1 of the interval element, along axis r only),
+//   L_f (facet 2m + s) = lift1[s][a_m] on the facet node with the same transverse indices,
+//   Jinv = diag(1 / h), (c n)_f has the single component -+ 1 / h_m,
+// so a node's right-hand side takes (P + 1) FMAs per direction and one per facet instead of a dense row of nd + 6 nf
+// entries: per 64 bytes moved the stage needs ~15 FMAs, and the path is bound by HBM alone.  Lane l owns cube
+// 64 g + l as in lane_stage; the fields use the same gw = 64 layout.  The work is ordered so that at most one component's
+// 27 nodal values, the two opposite facet traces it meets and one set of 27 accumulators are live at a time
+// (register budget of two waves per SIMD); a velocity component that several results need is re-read (L2 hits).
+//   a.Dt = { D1 [P+1][P+1] row-major, lift1 [2][P+1] }  (api.cpp, checked there against the full D_r, L_f)
+#ifndef SG_HEX_WAVES
+#define SG_HEX_WAVES 2
+#endif
+#ifndef SG_HEX_WAVES_G2
+#define SG_HEX_WAVES_G2 2      // the G stages of DQ_2
+#endif
+#define SG_HEX_WPE(P, KIND) (((P) == 2 && (KIND) == 1) ? SG_HEX_WAVES_G2 : SG_HEX_WAVES)
+template <int P, int KIND, int MODE, int SYM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(P, KIND), SG_HEX_WPE(P, KIND)))) void hex_stage(StageArgs A) {
+  constexpr int DIM = 3, N1 = P + 1, ND = N1 * N1 * N1, NF = N1 * N1, NFACES = 6;
+  constexpr int NC = (KIND == 0) ? 9 : 3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const MeshDev* md = A.md;
+  typedef __attribute__((address_space(4))) const double cdouble;
+  const cdouble* D1 = (const cdouble*)(unsigned long long)A.Dt;
+  const cdouble* lift1 = D1 + N1 * N1;
+  const double* __restrict__ in = A.in;
+  const double* __restrict__ aux = A.aux;
+  double* __restrict__ out = A.out;
+
+  const long ngroups = md->ncube_pad >> 6;
+  const bool listed = A.item_list != nullptr;
+  const long nitems = listed ? (long)A.nlist : ngroups;
+  const long nblk = gridDim.x, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const long blocks_here = (nblk - xcd + 7) / 8, ipx = (nitems + 7) / 8;
+  const long lo = xcd * ipx, hi = (xcd + 1) * ipx < nitems ? (xcd + 1) * ipx : nitems;
+  const long i0 = A.spread ? (long)blockIdx.x * 4 + wave : lo + slot * 4 + wave;
+  const long i1 = A.spread ? nitems : hi;
+  const long istep = A.spread ? (long)gridDim.x * 4 : blocks_here * 4;
+
+  // node of a line: axis m, transverse indices (t0, t1) with the lower axis first - also the facet-node index bp
+  auto node_of = [](int m, int t0, int t1, int am) -> int {
+    return m == 0 ? am + N1 * (t0 + N1 * t1) : m == 1 ? t0 + N1 * (am + N1 * t1) : t0 + N1 * (t1 + N1 * am);
+  };
+
+  for (long it = i0; it < i1; it += istep) {
+    const long g = listed ? (long)A.item_list[it] : it;
+    const LaneCell L = lane_cell(md, A, g, lane);
+    if (!__any(L.active)) continue;
+    const double* own = in + (g * (long)ND) * NC * 64 + lane;
+    const long e = L.valid ? L.c : 0;
+
+    double ih[DIM], cnf[NFACES];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) ih[r] = md->Jinv[0][r][r];
+#pragma unroll
+    for (int f = 0; f < NFACES; ++f) cnf[f] = md->cn[0][f][f / 2];
+
+    const double* np[NFACES];
+    bool gh[NFACES], ph[NFACES];
+#pragma unroll
+    for (int f = 0; f < NFACES; ++f) {
+      const LaneNbr R = lane_nbr<DIM, ND, NF, NC, 1>(md, A, L, g, 0, f, lane, own);
+      np[f] = R.p;
+      gh[f] = R.ghost;
+      ph[f] = R.physical;
+    }
+    // offset of facet node bp = t0 + N1 t1 of facet f, component c, in that facet's source: a packed remote trace
+    // ([slot][bp][DIM]), the own cell (domain boundary) or the neighbour cell, whose matching node is the one across
+    // the cube (the tables MeshDev::fnode / nb_node / nb_fnode say the same: checked at create, api.cpp)
+    auto noff = [&](int f, int t0, int t1, int cfield, int cghost) -> int {
+      const int ngh = (t0 + N1 * t1) * DIM + cghost;
+      const int nph = (node_of(f / 2, t0, t1, (f & 1) ? P : 0) * NC + cfield) * 64;
+      const int nin = (node_of(f / 2, t0, t1, (f & 1) ? 0 : P) * NC + cfield) * 64;
+      return gh[f] ? ngh : (ph[f] ? nph : nin);
+    };
+
+    if (KIND == 0) {
+      int sslot = -1;
+      if (A.sponge_slot != nullptr && L.active) sslot = A.sponge_slot[e];
+      const bool any_sponge = __any(sslot >= 0);
+      const long ubase = (g * (long)ND) * DIM * 64 + lane;
+      double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      if (MODE == 1 && A.rho2 != nullptr) {
+        cs = A.rho2[2 * e];
+        ca *= A.rho2[2 * e + 1];
+        cn *= A.rho2[2 * e + 1];
+      }
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        double acc[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[a] = 0.0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          // T_ij at the cell's nodes and on the two facets across axis j
+          double q[ND], tn[2][NF];
+#pragma unroll
+          for (int b = 0; b < ND; ++b) q[b] = own[(b * NC + cidx<DIM, SYM>(i, j)) * 64];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int bp = 0; bp < NF; ++bp)
+              tn[s2][bp] = np[2 * j + s2][noff(2 * j + s2, bp % N1, bp / N1, cidx<DIM, SYM>(i, j), i)];
+          // {T} = 1/2 (own + neighbour) on interior facets, no facet term on the domain boundary (elastic.py:204-206)
+          const double w0 = ph[2 * j] ? 0.0 : 0.5 * cnf[2 * j], w1 = ph[2 * j + 1] ? 0.0 : 0.5 * cnf[2 * j + 1];
+#pragma unroll
+          for (int t1 = 0; t1 < N1; ++t1)
+#pragma unroll
+            for (int t0 = 0; t0 < N1; ++t0) {
+              const int bp = t0 + N1 * t1;
+              const double f0 = w0 * (q[node_of(j, t0, t1, 0)] + tn[0][bp]);
+              const double f1 = w1 * (q[node_of(j, t0, t1, P)] + tn[1][bp]);
+#pragma unroll
+              for (int am = 0; am < N1; ++am) {
+                double v = 0.0;
+#pragma unroll
+                for (int m = 0; m < N1; ++m) v += D1[am * N1 + m] * q[node_of(j, t0, t1, m)];
+                acc[node_of(j, t0, t1, am)] += lift1[am] * f0 + lift1[N1 + am] * f1 - ih[j] * v;
+              }
+            }
+        }
+        if (any_sponge) {
+          double ua[ND];
+#pragma unroll
+          for (int b = 0; b < ND; ++b) ua[b] = A.uabs[ubase + (b * DIM + i) * 64];
+          if (sslot >= 0) {
+            const double* B = A.sponge_B + (long)sslot * ND * ND;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              double sacc = 0.0;
+#pragma unroll
+              for (int b = 0; b < ND; ++b) sacc += B[a * ND + b] * ua[b];
+              acc[a] -= sacc;
+            }
+          }
+        }
+        if (MODE == 1) {
+          double po[ND], pa[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            po[a] = out[ubase + (a * DIM + i) * 64];
+            pa[a] = aux[ubase + (a * DIM + i) * 64];
+          }
+#pragma unroll
+          for (int a = 0; a < ND; ++a) acc[a] = cs * po[a] + ca * pa[a] + cn * acc[a];
+        }
+        if (L.active) {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) out[ubase + (a * DIM + i) * 64] = acc[a];
+        }
+      }
+    } else {
+      const double lam = A.per_cell ? A.lam[e] : A.lam0;
+      const double mu = A.per_cell ? A.mu[e] : A.mu0;
+      const long sbase = (g * (long)ND) * DIM * DIM * 64 + lane;
+      // acc[a] += W_ik(a) = -(1/h_k) (D1 u_i along k) + sum_s (c n)_{2k+s} lift1[s] u^_i:  u^ = 1/2 (own + neighbour),
+      // the own trace on the domain boundary (a boundary lane's "neighbour" is its own cell: elastic.py:214-216)
+      auto add_W = [&](int i, int k, double (&acc)[ND]) {
+        // every pass re-reads its operands (L2 hits): the pointers are made opaque so that the compiler does not
+        // keep an earlier pass's values alive instead (three sets of nd values: spills), and passes stay in order
+        __builtin_amdgcn_sched_barrier(0);
+        const double* o2 = own;
+        const double* n0 = np[2 * k];
+        const double* n1 = np[2 * k + 1];
+        asm volatile("" : "+v"(o2), "+v"(n0), "+v"(n1));
+        double q[ND], tn[2][NF];
+#pragma unroll
+        for (int b = 0; b < ND; ++b) q[b] = o2[(b * NC + i) * 64];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int bp = 0; bp < NF; ++bp) tn[s2][bp] = (s2 ? n1 : n0)[noff(2 * k + s2, bp % N1, bp / N1, i, i)];
+        const double w0 = 0.5 * cnf[2 * k], w1 = 0.5 * cnf[2 * k + 1];
+#pragma unroll
+        for (int t1 = 0; t1 < N1; ++t1)
+#pragma unroll
+          for (int t0 = 0; t0 < N1; ++t0) {
+            const int bp = t0 + N1 * t1;
+            const double f0 = w0 * (q[node_of(k, t0, t1, 0)] + tn[0][bp]);
+            const double f1 = w1 * (q[node_of(k, t0, t1, P)] + tn[1][bp]);
+#pragma unroll
+            for (int am = 0; am < N1; ++am) {
+              double v = 0.0;
+#pragma unroll
+              for (int m = 0; m < N1; ++m) v += D1[am * N1 + m] * q[node_of(k, t0, t1, m)];
+              acc[node_of(k, t0, t1, am)] += lift1[am] * f0 + lift1[N1 + am] * f1 - ih[k] * v;
+            }
+          }
+      };
+      auto combine_store = [&](int c, double (&v)[ND]) {
+        if (MODE == 1) {
+          double po[ND], pa[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            po[a] = out[sbase + (a * DIM * DIM + c) * 64];
+            pa[a] = aux[sbase + (a * DIM * DIM + c) * 64];
+          }
+#pragma unroll
+          for (int a = 0; a < ND; ++a) v[a] = A.c_self * po[a] + A.c_aux * pa[a] + A.c_new * v[a];
+        }
+        if (L.active) {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) out[sbase + (a * DIM * DIM + c) * 64] = v[a];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // trace of W first, then the diagonal entries (their W_kk recomputed: cheaper than holding three sets of nd values)
+      double tr[ND];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) tr[a] = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) add_W(k, k, tr);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        double w[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) w[a] = 0.0;
+        add_W(k, k, w);
+#pragma unroll
+        for (int a = 0; a < ND; ++a) w[a] = 2.0 * mu * w[a] + lam * tr[a];
+        combine_store(k * DIM + k, w);
+      }
+      // sh_ij = sh_ji = mu (W_ij + W_ji)
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+#pragma unroll
+        for (int j = i + 1; j < DIM; ++j) {
+          double w[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) w[a] = 0.0;
+          add_W(i, j, w);
+          add_W(j, i, w);
+#pragma unroll
+          for (int a = 0; a < ND; ++a) w[a] = mu * w[a];
+          if (!SYM) {
+            double w2[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) w2[a] = w[a];
+            combine_store(j * DIM + i, w2);
+          }
+          combine_store(i * DIM + j, w);
+        }
+    }
+  }
+}
+
+#ifndef SG_HEX_BLOCKS
+#define SG_HEX_BLOCKS 2048
+#endif
+template <int P>
+static int launch_hex_p(int kind, const StageArgs& a, long nitems, hipStream_t s) {
+  long blocks = (nitems + 3) / 4;
+  if (blocks > SG_HEX_BLOCKS) blocks = SG_HEX_BLOCKS;
+  blocks = (blocks + 7) / 8 * 8;
+  const dim3 grid((unsigned)blocks), block(256);
+#define SG_HEX_LAUNCH(K, M)                                                        \
+  do {                                                                             \
+    if (a.sym)                                                                     \
+      hipLaunchKernelGGL((hex_stage<P, K, M, 1>), grid, block, 0, s, a);           \
+    else                                                                           \
+      hipLaunchKernelGGL((hex_stage<P, K, M, 0>), grid, block, 0, s, a);           \
+  } while (0)
+  if (kind == 0) {
+    if (a.mode == 0)
+      SG_HEX_LAUNCH(0, 0);
+    else
+      SG_HEX_LAUNCH(0, 1);
+  } else {
+    if (a.mode == 0)
+      SG_HEX_LAUNCH(1, 0);
+    else
+      SG_HEX_LAUNCH(1, 1);
+  }
+#undef SG_HEX_LAUNCH
+  return (int)hipGetLastError();
+}
+
 template <int DIM, int P>
 static int launch_lane_dp(int kind, const StageArgs& a, long nitems, hipStream_t s) {
   long blocks = (nitems + 3) / 4;
@@ -405,8 +685,16 @@ static int launch_lane_d(int kind, int P, const StageArgs& a, long nitems, hipSt
 // 3-D: only P1/P2 fit a lane's registers (P3/P4 take the MFMA path)
 bool lane_supported(int dim, int P) { return ((dim == 1 || dim == 2) && P >= 1 && P <= 4) || (dim == 3 && (P == 1 || P == 2)); }
 
+// hexahedra: DQ_1 and DQ_2 (27 nodes) fit a lane's registers one component at a time
+bool lane_supported_hex(int dim, int P) { return dim == 3 && (P == 1 || P == 2); }
+
 int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.tensor) {
+    if (dim == 3 && P == 1) return launch_hex_p<1>(kind, a, nitems, s);
+    if (dim == 3 && P == 2) return launch_hex_p<2>(kind, a, nitems, s);
+    return -1;
+  }
   if (dim == 1) return launch_lane_d<1>(kind, P, a, nitems, s);
   if (dim == 2) return launch_lane_d<2>(kind, P, a, nitems, s);
   if (dim == 3 && P == 1) return launch_lane_dp<3, 1>(kind, a, nitems, s);

@@ -66,11 +66,13 @@ def test_eigenmode_on_hexahedra_converges(gpu):
         assert math.log2(errs[0][k] / errs[1][k]) > 1.8 and math.log2(errs[1][k] / errs[2][k]) > 2.0, errs
 
 
+@pytest.mark.parametrize("path", ["generic", "lane"])
 @pytest.mark.parametrize("P", [1, 2])
-def test_sponge_source_and_material_on_hexahedra(gpu, P):
+def test_sponge_source_and_material_on_hexahedra(gpu, monkeypatch, P, path):
     """The extras of the explosive-source set-up on hexahedral cells: DG4 sponge (elastic.py:207-208; 125 nodal values
-    per cube), a nodal source table (:217-218), per-cell lambda / mu and per-cell physical density, twelve steps
-    against the oracle."""
+    per cube), a nodal source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle - on the
+    table-driven generic kernels (what a block this small runs by default) and on the sum-factorised lane kernels."""
+    monkeypatch.setenv("SEIGEN_HIP_PATH", path)
     from seigen_amd import _lib
     from seigen_amd.backend import HipBlock
     n, L = (4, 3, 3), (2.0, 1.5, 1.2)
@@ -111,6 +113,76 @@ def test_sponge_source_and_material_on_hexahedra(gpu, P):
         orc.step((k + 1) * orc.dt)
     assert rel_err(blk.get_field(_lib.FIELD_U), orc.u1) < 1e-10
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 1e-10
+
+
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("n", [(7, 5, 3), (70, 3, 2), (1, 1, 1), (64, 2, 1), (3, 9, 11)])
+def test_hexahedral_lane_kernels_agree_with_the_generic_kernels(gpu, monkeypatch, P, n):
+    """Ragged blocks (cell groups of 64 straddling rows and layers, a single cube, a row of exactly one group): the
+    sum-factorised lane kernels against the table-driven generic kernels, with sponge, source, per-cell material and
+    per-cell physical density, non-symmetric stress included (the lane kernels' symmetric-stress mode is left)."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(P * 100 + n[0])
+    h = [0.7, 1.3, 0.9]
+    for symmetric in (True, False):
+        res = {}
+        for path in ("generic", "lane"):
+            monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+            blk = HipBlock(3, P, n, h, [0.0] * 3, "quadrilateral")
+            nc, nd = blk.ncells, blk.nd
+            if path == "generic":
+                lam, mu, rho = rng.uniform(0.4, 0.8, nc), rng.uniform(0.2, 0.4, nc), rng.uniform(0.8, 1.6, nc)
+                sigma = np.where(rng.uniform(size=(nc, 125)) > 0.7, 20.0, 0.0)
+                nodes = np.unique(rng.integers(0, nc * nd, size=min(30, nc * nd)))
+                vals = rng.uniform(-1, 1, (5, len(nodes), 3, 3))
+                u0 = seeded(blk.field_shape(_lib.FIELD_U), 1)
+                s0 = seeded(blk.field_shape(_lib.FIELD_S), 2)
+                if symmetric:
+                    vals = 0.5 * (vals + np.swapaxes(vals, -1, -2))
+                    s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+            blk.set_params(1.0, 0.01 * min(h) / P ** 2, lam, mu)
+            blk.set_density(rho, physical=True)
+            blk.set_absorption(sigma, 4)
+            blk.set_source(nodes, vals)
+            blk.set_field(_lib.FIELD_U, u0)
+            blk.set_field(_lib.FIELD_S, s0)
+            blk.step(5)
+            res[path] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S), blk.get_field(_lib.FIELD_UH),
+                         blk.get_field(_lib.FIELD_SH))
+            blk.close()
+        for a, b in zip(res["lane"], res["generic"]):
+            assert rel_err(a, b) < 1e-12
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_hexahedral_lane_kernels_stage_parity_with_the_oracle(gpu, monkeypatch, P):
+    """apply_F / apply_G (un-fused stage entry points) of the lane kernels against the oracle's assembled operators."""
+    monkeypatch.setenv("SEIGEN_HIP_PATH", "lane")
+    from oracle.forms import ElasticOperators
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    n, L = (3, 2, 4), (1.0, 1.5, 0.8)
+    blk = HipBlock(3, P, n, [L[a] / n[a] for a in range(3)], [0.0] * 3, "quadrilateral")
+    E = ElasticOperators(omesh.structured(3, n, L, quadrilateral=True), P)
+    T = seeded(blk.field_shape(_lib.FIELD_S), 0)
+    u = seeded(blk.field_shape(_lib.FIELD_U), 1)
+    blk.set_params(1.0, 0.01, 0.7, 0.3)
+    blk.set_field(_lib.FIELD_S, T)
+    blk.set_field(_lib.FIELD_U, u)
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    assert rel_err(blk.get_field(_lib.FIELD_UH), E.apply_F(T, u)) < 1e-12
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, 0.7, 0.3)) < 1e-12
+
+
+def test_hexahedral_blocks_equal_the_single_block_on_the_lane_kernels(gpu, monkeypatch):
+    monkeypatch.setenv("SEIGEN_HIP_PATH", "lane")
+    from tests.test_harness_gpu import _multiblock_case
+    for pipelined in (True, False):
+        _multiblock_case(3, 2, (4, 4, 4), (2, 2, 2), pipelined, extras=True, diagonal="quadrilateral")
+        _multiblock_case(3, 1, (6, 3, 5), (3, 1, 2), pipelined, extras=True, diagonal="quadrilateral")
+    _multiblock_case(3, 2, (130, 6, 2), (2, 3, 1), True, extras=True, separable=True, diagonal="quadrilateral")   # x sides, wide rows
 
 
 def test_hexahedral_blocks_equal_the_single_block(gpu):

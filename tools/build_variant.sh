@@ -1,11 +1,13 @@
 #!/bin/bash
 # Build a variant of libseigen_hip.so with extra -D flags for kernels_mfma.hip (timing experiments):
 #   tools/build_variant.sh <name> [-DSG_FLA=6 ...]   ->  build_tools/libseigen_hip_<name>.so   (use with SEIGEN_HIP_LIB=...)
+# SRC=kernels_lane tools/build_variant.sh ... rebuilds that kernel file instead.
 set -e
 NAME=$1; shift
+SRC=${SRC:-kernels_mfma}
 cd "$(dirname "$0")/../seigen_amd/csrc"
 mkdir -p ../../build_tools
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c kernels_mfma.hip -o /tmp/kernels_mfma_$NAME.o
-OBJS=$(ls *.o | grep -v kernels_mfma.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $SRC.hip -o /tmp/kernels_mfma_$NAME.o
+OBJS=$(ls *.o | grep -v $SRC.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_tools/libseigen_hip_$NAME.so $OBJS /tmp/kernels_mfma_$NAME.o -L/opt/rocm/lib -lrccl
 echo built build_tools/libseigen_hip_$NAME.so

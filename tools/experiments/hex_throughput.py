@@ -33,6 +33,10 @@ def run(P, N, diagonal, steps=20):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) >= 4:          # one case: P N diagonal
+        print("P%d N=%d %-13s cells %9d nd %2d  %8.3f ms/step  %6.2f G DoF-updates/s  (%.2f TB/s algorithmic)"
+              % run(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]))
+        sys.exit(0)
     for P, N in ((1, 96), (2, 64), (2, 96)):
         for diagonal in ("quadrilateral", "left"):
             print("P%d N=%d %-13s cells %9d nd %2d  %8.3f ms/step  %6.2f G DoF-updates/s  (%.2f TB/s algorithmic)" % run(P, N, diagonal))

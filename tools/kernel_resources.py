@@ -6,7 +6,7 @@ import sys
 
 src = sys.argv[1]
 filters = sys.argv[2:]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + __import__("os").environ.get("SG_EXTRA_FLAGS", "").split() + [
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
 if "tile2d" in src:
     cmd[5:5] = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
