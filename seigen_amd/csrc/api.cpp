@@ -17,11 +17,11 @@ KernelPath choose_kernel_path(const sg_config& cfg) {
     kp.tile = cfg.dim == 2 && tile2d_supported_quad(cfg.degree) && !fg &&
               (ft || (int64_t)cfg.n[0] * cfg.n[1] >= SG_TILE2D_MIN_CELLS / 2);
     // hexahedra (DQ_1, DQ_2): the sum-factorised lane-per-cell kernels (kernels_lane.hip hex_stage) from
-    // SG_HEX_LANE_MIN_CELLS cubes up (below that the thread-per-node generic kernel has more parallelism);
+    // SG_HEX_LANE_MIN_CELLS(degree) cubes up (below that the thread-per-node generic kernel has more parallelism);
     // SEIGEN_HIP_PATH=lane / generic forces one or the other
     const bool fl = pe && std::strcmp(pe, "lane") == 0;
     kp.lane = cfg.dim == 3 && lane_supported_hex(cfg.dim, cfg.degree) && !fg &&
-              (fl || (int64_t)cfg.n[0] * cfg.n[1] * cfg.n[2] >= SG_HEX_LANE_MIN_CELLS);
+              (fl || (int64_t)cfg.n[0] * cfg.n[1] * cfg.n[2] >= SG_HEX_LANE_MIN_CELLS(cfg.degree));
     kp.gw = kp.tile ? 16 : (kp.lane ? 64 : 1);
     return kp;
   }

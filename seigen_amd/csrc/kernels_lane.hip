@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
 #define SG_HEX_WAVES 2
 #endif
 #ifndef SG_HEX_WAVES_G2
-#define SG_HEX_WAVES_G2 2      // the G stages of DQ_2
+#define SG_HEX_WAVES_G2 1      // the G stages of DQ_2: three sets of nd results and the next operands live together
 #endif
 #define SG_HEX_WPE(P, KIND) (((P) == 2 && (KIND) == 1) ? SG_HEX_WAVES_G2 : SG_HEX_WAVES)
 template <int P, int KIND, int MODE, int SYM>
@@ -521,24 +521,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
       const long sbase = (g * (long)ND) * DIM * DIM * 64 + lane;
-      // acc[a] += W_ik(a) = -(1/h_k) (D1 u_i along k) + sum_s (c n)_{2k+s} lift1[s] u^_i:  u^ = 1/2 (own + neighbour),
-      // the own trace on the domain boundary (a boundary lane's "neighbour" is its own cell: elastic.py:214-216)
-      auto add_W = [&](int i, int k, double (&acc)[ND]) {
-        // every pass re-reads its operands (L2 hits): the pointers are made opaque so that the compiler does not
-        // keep an earlier pass's values alive instead (three sets of nd values: spills), and passes stay in order
-        __builtin_amdgcn_sched_barrier(0);
+      // Two sweeps over the velocity, so that each component is read twice and not once per result that needs it
+      // (four times: re-reads of a 41 KB cell group miss the L2 with 2000 waves in flight):
+      //   A: W_kk of the three components -> trace and the diagonal entries;
+      //   B: component i gives W_ij and W_ik along the other two axes, summed into the three pair accumulators.
+      // The operands of sweep B's first component are requested before sweep A's results are stored (a load requested
+      // behind a store waits for the store's acknowledgement).
+      auto load_comp = [&](int i, double (&q)[ND]) __attribute__((always_inline)) {
         const double* o2 = own;
-        const double* n0 = np[2 * k];
-        const double* n1 = np[2 * k + 1];
-        asm volatile("" : "+v"(o2), "+v"(n0), "+v"(n1));
-        double q[ND], tn[2][NF];
+        asm volatile("" : "+v"(o2));        // a second read of the same component really is one (see above)
 #pragma unroll
         for (int b = 0; b < ND; ++b) q[b] = o2[(b * NC + i) * 64];
+      };
+      auto load_trace = [&](int i, int k, double (&tn)[2][NF]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int bp = 0; bp < NF; ++bp) tn[s2][bp] = (s2 ? n1 : n0)[noff(2 * k + s2, bp % N1, bp / N1, i, i)];
-        const double w0 = 0.5 * cnf[2 * k], w1 = 0.5 * cnf[2 * k + 1];
+          for (int bp = 0; bp < NF; ++bp) tn[s2][bp] = np[2 * k + s2][noff(2 * k + s2, bp % N1, bp / N1, i, i)];
+      };
+      // acc[a] += sc W_ik(a),  W_ik = -(1/h_k) (D1 u_i along k) + sum_s (c n)_{2k+s} lift1[s] u^_i:  u^ = 1/2 (own + neighbour),
+      // the own trace on the domain boundary (a boundary lane's "neighbour" is its own cell: elastic.py:214-216)
+      auto add_W = [&](const double (&q)[ND], const double (&tn)[2][NF], int k, double sc, double (&acc)[ND]) __attribute__((always_inline)) {
+        const double w0 = 0.5 * sc * cnf[2 * k], w1 = 0.5 * sc * cnf[2 * k + 1], hk = sc * ih[k];
 #pragma unroll
         for (int t1 = 0; t1 < N1; ++t1)
 #pragma unroll
@@ -551,63 +555,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
               double v = 0.0;
 #pragma unroll
               for (int m = 0; m < N1; ++m) v += D1[am * N1 + m] * q[node_of(k, t0, t1, m)];
-              acc[node_of(k, t0, t1, am)] += lift1[am] * f0 + lift1[N1 + am] * f1 - ih[k] * v;
+              acc[node_of(k, t0, t1, am)] += lift1[am] * f0 + lift1[N1 + am] * f1 - hk * v;
             }
           }
       };
-      auto combine_store = [&](int c, double (&v)[ND]) {
-        if (MODE == 1) {
-          double po[ND], pa[ND];
+      auto load_old = [&](int c, double (&po)[ND], double (&pa)[ND]) __attribute__((always_inline)) {
 #pragma unroll
-          for (int a = 0; a < ND; ++a) {
-            po[a] = out[sbase + (a * DIM * DIM + c) * 64];
-            pa[a] = aux[sbase + (a * DIM * DIM + c) * 64];
-          }
-#pragma unroll
-          for (int a = 0; a < ND; ++a) v[a] = A.c_self * po[a] + A.c_aux * pa[a] + A.c_new * v[a];
+        for (int a = 0; a < ND; ++a) {
+          po[a] = out[sbase + (a * DIM * DIM + c) * 64];
+          pa[a] = aux[sbase + (a * DIM * DIM + c) * 64];
         }
+      };
+      auto combine = [&](double (&v)[ND], const double (&po)[ND], const double (&pa)[ND]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a) v[a] = A.c_self * po[a] + A.c_aux * pa[a] + A.c_new * v[a];
+      };
+      auto store = [&](int c, const double (&v)[ND]) __attribute__((always_inline)) {
         if (L.active) {
 #pragma unroll
           for (int a = 0; a < ND; ++a) out[sbase + (a * DIM * DIM + c) * 64] = v[a];
         }
+      };
+      // the arithmetic that produced v is complete HERE: sched_barrier orders the machine scheduler only, and the
+      // optimiser would otherwise sink pure arithmetic to its first use, past the requests that follow (everything
+      // requested so far then stays live until that point)
+      auto pin = [&](double (&v)[ND]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(v[a]));
+      };
+      // Three finished results -> components c0, c1, c2 of a fused stage: the old values of two results are read first
+      // and combined, the third's are requested before those two are stored (no load behind a store): two exposed
+      // load latencies instead of three.
+      auto combine3 = [&](int c0, int c1, int c2, double (&v0)[ND], double (&v1)[ND], double (&v2)[ND]) __attribute__((always_inline)) {
+        double po[ND], pa[ND], po1[ND], pa1[ND];
+        load_old(c0, po, pa);
+        load_old(c1, po1, pa1);
+        combine(v0, po, pa);
+        combine(v1, po1, pa1);
+        pin(v0);
+        pin(v1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_old(c2, po, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        store(c0, v0);
+        store(c1, v1);
+        combine(v2, po, pa);
+        store(c2, v2);
         __builtin_amdgcn_sched_barrier(0);
       };
-      // trace of W first, then the diagonal entries (their W_kk recomputed: cheaper than holding three sets of nd values)
-      double tr[ND];
+      auto store3 = [&](int c0, int c1, int c2, const double (&v0)[ND], const double (&v1)[ND], const double (&v2)[ND]) __attribute__((always_inline)) {
+        store(c0, v0);
+        store(c1, v1);
+        store(c2, v2);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+
+      // ---- sweep A
+      double w[DIM][ND];
+      {
+        double q[DIM][ND], tn[DIM][2][NF];
 #pragma unroll
-      for (int a = 0; a < ND; ++a) tr[a] = 0.0;
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) add_W(k, k, tr);
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) {
-        double w[ND];
-#pragma unroll
-        for (int a = 0; a < ND; ++a) w[a] = 0.0;
-        add_W(k, k, w);
-#pragma unroll
-        for (int a = 0; a < ND; ++a) w[a] = 2.0 * mu * w[a] + lam * tr[a];
-        combine_store(k * DIM + k, w);
-      }
-      // sh_ij = sh_ji = mu (W_ij + W_ji)
-#pragma unroll
-      for (int i = 0; i < DIM; ++i)
-#pragma unroll
-        for (int j = i + 1; j < DIM; ++j) {
-          double w[ND];
-#pragma unroll
-          for (int a = 0; a < ND; ++a) w[a] = 0.0;
-          add_W(i, j, w);
-          add_W(j, i, w);
-#pragma unroll
-          for (int a = 0; a < ND; ++a) w[a] = mu * w[a];
-          if (!SYM) {
-            double w2[ND];
-#pragma unroll
-            for (int a = 0; a < ND; ++a) w2[a] = w[a];
-            combine_store(j * DIM + i, w2);
-          }
-          combine_store(i * DIM + j, w);
+        for (int k = 0; k < DIM; ++k) {
+          load_comp(k, q[k]);
+          load_trace(k, k, tn[k]);
         }
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) w[k][a] = 0.0;
+          add_W(q[k], tn[k], k, 1.0, w[k]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        const double tr = lam * (w[0][a] + w[1][a] + w[2][a]);
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) w[k][a] = 2.0 * mu * w[k][a] + tr;
+      }
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) pin(w[k]);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- sweep B: component i's operands are requested while component i - 1 is evaluated (the first one ahead of
+      //      sweep A's stores where the stage is not fused)
+      double qb[2][ND], tb[2][2][2][NF];
+      if (MODE == 1) combine3(0, DIM + 1, 2 * DIM + 2, w[0], w[1], w[2]);     // (registers: the old values instead of the operands)
+      load_comp(0, qb[0]);
+      load_trace(0, 1, tb[0][0]);
+      load_trace(0, 2, tb[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE == 0) store3(0, DIM + 1, 2 * DIM + 2, w[0], w[1], w[2]);
+      double pr[DIM][ND];     // the pairs (0,1), (0,2), (1,2): sh_ij = sh_ji = mu (W_ij + W_ji)
+#pragma unroll
+      for (int p = 0; p < DIM; ++p)
+#pragma unroll
+        for (int a = 0; a < ND; ++a) pr[p][a] = 0.0;
+      load_comp(1, qb[1]);
+      load_trace(1, 0, tb[1][0]);
+      load_trace(1, 2, tb[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      add_W(qb[0], tb[0][0], 1, mu, pr[0]);       // W_01
+      add_W(qb[0], tb[0][1], 2, mu, pr[1]);       // W_02
+      pin(pr[0]);
+      pin(pr[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_comp(2, qb[0]);
+      load_trace(2, 0, tb[0][0]);
+      load_trace(2, 1, tb[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      add_W(qb[1], tb[1][0], 0, mu, pr[0]);       // W_10
+      add_W(qb[1], tb[1][1], 2, mu, pr[2]);       // W_12
+      pin(pr[0]);
+      pin(pr[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      add_W(qb[0], tb[0][0], 0, mu, pr[1]);       // W_20
+      add_W(qb[0], tb[0][1], 1, mu, pr[2]);       // W_21
+      pin(pr[1]);
+      pin(pr[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!SYM) {                                   // the mirror entries have their own old values (the rare path)
+#pragma unroll
+        for (int p = 0; p < DIM; ++p) {
+          const int i = p == 2 ? 1 : 0, j = p == 0 ? 1 : 2;
+          double w2[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) w2[a] = pr[p][a];
+          if (MODE == 1) {
+            double po[ND], pa[ND];
+            load_old(j * DIM + i, po, pa);
+            combine(w2, po, pa);
+          }
+          store(j * DIM + i, w2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (MODE == 1)
+        combine3(1, 2, DIM + 2, pr[0], pr[1], pr[2]);
+      else
+        store3(1, 2, DIM + 2, pr[0], pr[1], pr[2]);
     }
   }
 }
