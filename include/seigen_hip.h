@@ -79,7 +79,7 @@ typedef struct sg_config {
   double h[3];       /* cell size per axis */
   double origin[3];  /* physical coordinate of the block's low corner (of cube -cube0, see below) */
   int32_t diagonal;  /* 2-D: 0 = "left" (Firedrake default), 1 = "right": how each square is cut into two triangles;
-                        2 = not at all: quadrilateral cells (dim 2) or hexahedral cells (dim 3, degrees 1 and 2) with
+                        2 = not at all: quadrilateral cells (dim 2) or hexahedral cells (dim 3) with
                         the tensor-product element DQ_k, what FunctionSpace(mesh, "DG", k) (elastic.py:81-82) is on
                         a quadrilateral / hexahedral mesh.  3-D simplicial blocks ignore 0 / 1 (one Kuhn cut). */
   int32_t nbr_mask;  /* bit (2*axis + side) set: that side touches another block (halo), else free surface */

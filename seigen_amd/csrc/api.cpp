@@ -144,9 +144,6 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(h, SG_ERR_ARG, "device ordinal out of range");
   HIPCHECK(h, hipSetDevice(cfg->device));
 
-  if (cfg->diagonal == SG_DIAGONAL_QUAD && cfg->dim == 3 && cfg->degree > 2)
-    return fail(h, SG_ERR_ARG, "hexahedral cells: degrees 1 and 2 (DQ_k on hexahedra runs on the table-driven generic kernel, whose "
-                               "operators must fit the LDS; higher degrees want sum-factorised kernels)");
   if (cfg->diagonal == SG_DIAGONAL_QUAD && cfg->dim == 1) return fail(h, SG_ERR_ARG, "tensor-product cells need dim 2 or 3");
   try {
     h->re = make_refelem(cfg->dim, cfg->degree, cfg->diagonal == SG_DIAGONAL_QUAD ? KIND_TENSOR : KIND_SIMPLEX);
@@ -187,8 +184,8 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   for (int f = 0; f < nfaces; ++f)
     for (int a = 0; a < nd; ++a)
       for (int b = 0; b < nf; ++b) Lt[((size_t)f * nf + b) * nd + a] = h->re.L[((size_t)f * nd + a) * nf + b];
-  if (h->use_lane && h->re.kind == KIND_TENSOR) {
-    // hexahedral lane path (kernels_lane.hip hex_stage): the 1-D factors D1 [n1][n1] and lift1 [2][n1] of the
+  if (h->re.kind == KIND_TENSOR && cfg->dim == 3) {
+    // hexahedra, both kernel families (kernels_lane.hip hex_stage, kernels.hip stage_kernel TP = 2): the 1-D factors D1 [n1][n1] and lift1 [2][n1] of the
     // tensor-product operators, read off the full tables along the first axis and checked against ALL of D_r, L_f
     const int n1 = cfg->degree + 1;
     auto node = [&](int a0, int a1, int a2) { return a0 + n1 * (a1 + n1 * a2); };

@@ -12,6 +12,10 @@
 // Generic path: a 256-thread workgroup owns EB consecutive cells; thread
 // (cell, node) accumulates all components of its node.  Cell data, numerical
 // fluxes, the transposed reference operators and the mesh tables live in LDS.
+// TP = 2 (hexahedra, DQ_1..4): the operators are applied SUM-FACTORISED - D_r = I x D1 x I acts along the node's
+// line in direction r, L_f is one 1-D lift factor on the facet node with the node's transverse indices - so a
+// node costs 3 (P + 1) + 6 terms instead of 3 nd + 6 nf, and the tables in LDS are D1 and lift1 (the dense D_r of
+// DQ_4, 3 x 125 x 125 doubles, would not fit).  A.Dt = { D1 [P+1][P+1] row-major, lift1 [2][P+1] } (api.cpp).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -49,16 +53,19 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
   constexpr int NC = (KIND == 0) ? DIM * DIM : DIM;  // input components per node
   constexpr int NT = 256;
 
-  __shared__ double sDt[DIM * ND * ND];
-  __shared__ double sLt[NFACES * NF * ND];
+  constexpr bool SF = TP == 2;                     // sum-factorised hexahedra
+  constexpr int N1 = P + 1;
+  __shared__ double sDt[SF ? N1 * N1 + 2 * N1 : DIM * ND * ND];
+  __shared__ double sLt[SF ? 1 : NFACES * NF * ND];
   __shared__ double sQ[EB * ND * NC];
   __shared__ double sFlux[EB * NFACES * NF * DIM];
   __shared__ long sElem[EB];
   __shared__ MeshDev sMd;
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < DIM * ND * ND; i += NT) sDt[i] = A.Dt[i];
-  for (int i = tid; i < NFACES * NF * ND; i += NT) sLt[i] = A.Lt[i];
+  for (int i = tid; i < (SF ? N1 * N1 + 2 * N1 : DIM * ND * ND); i += NT) sDt[i] = A.Dt[i];
+  if (!SF)
+    for (int i = tid; i < NFACES * NF * ND; i += NT) sLt[i] = A.Lt[i];
   {
     const int* src = reinterpret_cast<const int*>(A.md);
     int* dst = reinterpret_cast<int*>(&sMd);
@@ -160,6 +167,13 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
     const bool active = (el < EB) && (sElem[el < EB ? el : 0] >= 0);
     const long g = active ? sElem[el] : 0;
     const int cls = (int)(g % NCLS);
+    // sum-factorised hexahedra: the node's lattice indices; its line along axis r starts at a - ai[r] * st[r]; on facet
+    // 2 r + s it meets the facet node with its two transverse indices (lower axis first: the order of MeshDev::fnode,
+    // checked at create)
+    const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
+    constexpr int st[3] = {1, N1, N1 * N1};
+    (void)ai;
+    (void)st;
 
     if (KIND == 0) {
       // T~_ir = sum_j Jinv[r][j] T_ij, in place (each thread owns its node)
@@ -182,7 +196,28 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
       double acc[DIM];
 #pragma unroll
       for (int i = 0; i < DIM; ++i) acc[i] = 0.0;
+      if (active && SF) {
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+          const int b0 = a - ai[r] * st[r];
+          for (int m = 0; m < N1; ++m) {
+            const double d = sDt[ai[r] * N1 + m];
+            const double* t = &sQ[(el * ND + b0 + m * st[r]) * NC];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) acc[i] -= d * t[i * DIM + r];
+          }
+          const int bp = r == 0 ? ai[1] + N1 * ai[2] : r == 1 ? ai[0] + N1 * ai[2] : ai[0] + N1 * ai[1];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const double l = sDt[N1 * N1 + s2 * N1 + ai[r]];
+            const double* fl = &sFlux[((el * NFACES + 2 * r + s2) * NF + bp) * DIM];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) acc[i] += l * fl[i];
+          }
+        }
+      }
       if (active) {
+        if (!SF) {
         for (int b = 0; b < ND; ++b) {
           double d[DIM];
 #pragma unroll
@@ -201,6 +236,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
 #pragma unroll
             for (int i = 0; i < DIM; ++i) acc[i] += l * fl[i];
           }
+        }
         if (A.sponge_slot != nullptr) {
           int slot = A.sponge_slot[g];
           if (slot >= 0) {
@@ -240,6 +276,18 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
         for (int i = 0; i < DIM; ++i)
 #pragma unroll
           for (int r = 0; r < DIM; ++r) R[i][r] = 0.0;
+        if (SF) {
+#pragma unroll
+          for (int r = 0; r < DIM; ++r) {
+            const int b0 = a - ai[r] * st[r];
+            for (int m = 0; m < N1; ++m) {
+              const double d = sDt[ai[r] * N1 + m];
+              const double* u = &sQ[(el * ND + b0 + m * st[r]) * NC];
+#pragma unroll
+              for (int i = 0; i < DIM; ++i) R[i][r] += d * u[i];
+            }
+          }
+        } else {
         for (int b = 0; b < ND; ++b) {
           double d[DIM];
 #pragma unroll
@@ -249,6 +297,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
           for (int i = 0; i < DIM; ++i)
 #pragma unroll
             for (int r = 0; r < DIM; ++r) R[i][r] += d[r] * u[i];
+        }
         }
         double W[DIM][DIM];  // W[i][k] = weak d u_i / d x_k
 #pragma unroll
@@ -265,11 +314,20 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
           double lu[DIM];
 #pragma unroll
           for (int i = 0; i < DIM; ++i) lu[i] = 0.0;
+          if (SF) {
+            const int r = f / 2;
+            const int bp = r == 0 ? ai[1] + N1 * ai[2] : r == 1 ? ai[0] + N1 * ai[2] : ai[0] + N1 * ai[1];
+            const double l = sDt[N1 * N1 + (f & 1) * N1 + ai[r]];
+            const double* fl = &sFlux[((el * NFACES + f) * NF + bp) * DIM];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) lu[i] = l * fl[i];
+          } else {
           for (int b = 0; b < NF; ++b) {
             double l = sLt[(f * NF + b) * ND + a];
             const double* fl = &sFlux[((el * NFACES + f) * NF + b) * DIM];
 #pragma unroll
             for (int i = 0; i < DIM; ++i) lu[i] += l * fl[i];
+          }
           }
 #pragma unroll
           for (int i = 0; i < DIM; ++i)
@@ -337,8 +395,13 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.tensor) {
     if (dim == 2) return launch_quad(kind, P, a, s);
-    if (dim == 3 && P == 1) return launch_dp<3, 1, 1>(kind, a, s);      // hexahedra, DQ_1: 8 nodes, facets of 4
-    if (dim == 3 && P == 2) return launch_dp<3, 2, 1>(kind, a, s);      // DQ_2: 27 nodes, facets of 9
+    if (dim != 3) return -1;
+    switch (P) {                                                        // hexahedra, sum-factorised (TP = 2)
+      case 1: return launch_dp<3, 1, 2>(kind, a, s);                    // 8 nodes, facets of 4
+      case 2: return launch_dp<3, 2, 2>(kind, a, s);                    // 27 / 9
+      case 3: return launch_dp<3, 3, 2>(kind, a, s);                    // 64 / 16
+      case 4: return launch_dp<3, 4, 2>(kind, a, s);                    // 125 / 25
+    }
     return -1;
   }
   switch (dim) {

@@ -174,10 +174,10 @@ int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream);
 // lane-per-cell path (1-D / 2-D; fields in the gw = 64 interleaved layout; a.Dt = E[r][a][b],
 // a.Lt = L[f][a][b'] row-major)
 bool lane_supported(int dim, int P);
-// measured crossover of the generic and the lane kernels on hexahedra (tools/experiments/hex_crossover.py,
-// profiles/r04/hexahedra.txt): between 24^3 and 32^3 cubes at degree 1, between 20^3 and 24^3 at degree 2
+// measured crossover of the (sum-factorised) generic and the lane kernels on hexahedra (tools/experiments/
+// hex_crossover.py, profiles/r04/hexahedra.txt): between 24^3 and 32^3 cubes at both degrees
 #ifndef SG_HEX_LANE_MIN_CELLS
-#define SG_HEX_LANE_MIN_CELLS(degree) ((degree) == 1 ? 20000 : 10000)
+#define SG_HEX_LANE_MIN_CELLS(degree) 24000
 #endif
 bool lane_supported_hex(int dim, int P);   // a.tensor: hexahedra (sum-factorised; a.Dt = {D1, lift1})
 int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream);

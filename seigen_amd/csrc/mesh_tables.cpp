@@ -100,7 +100,7 @@ void build_mesh_tables(int dim, int P, int diagonal, const double h[3], const in
                        MeshDev& md) {
   if (diagonal == SG_DIAGONAL_QUAD) {
     if (dim != 2 && dim != 3) throw std::runtime_error("tensor-product cells: quadrilaterals (2-D) and hexahedra (3-D)");
-    if (md.nf > MAX_NF) throw std::runtime_error("hexahedra: degrees 1 and 2 (a facet of DQ_3 has 16 nodes)");
+    if (md.nf > MAX_NF) throw std::runtime_error("tensor-product cells: too many facet nodes for the mesh tables");
     build_quad_tables(dim, P, h, fnode, md);
     return;
   }

@@ -15,7 +15,7 @@ namespace sg {
 constexpr int SG_DIAGONAL_QUAD = 2;   // sg_config::diagonal: the squares are the cells (tensor-product element)
 constexpr int MAX_CLS = 6;
 constexpr int MAX_FACES = 6;     // hexahedra; simplices use dim + 1, quadrilaterals 4
-constexpr int MAX_NF = 15;
+constexpr int MAX_NF = 27;     // facet nodes: 15 on a P4 triangle, 25 on a DQ_4 square (hexahedra); tables hold MAX_NF + 1
 
 // POD mirrored in device memory (copied to LDS at workgroup start).
 struct MeshDev {

@@ -346,8 +346,8 @@ def test_multiblock_random_grids(gpu, seed):
     if int(np.prod(grid)) == 1:
         grid = grid[:-1] + (2,)
     n = tuple(int(g * rng.integers(1, 4) + rng.integers(0, 2)) for g in grid)
-    # every fourth case on tensor-product cells where they are built (quadrilaterals; hexahedra of degree 1 and 2)
-    diagonal = "quadrilateral" if ((dim == 2 or (dim == 3 and degree <= 2)) and seed % 4 == 3) else "left"
+    # every fourth case on tensor-product cells (quadrilaterals, hexahedra)
+    diagonal = "quadrilateral" if (dim >= 2 and seed % 4 == 3) else "left"
     # every fifth case in the float mode, where an MFMA kernel family runs the blocks
     f32_ok = ((dim == 3 and degree >= 2) or dim == 2) and not (dim == 3 and diagonal == "quadrilateral")
     dtype = "f32" if (seed % 5 == 4 and f32_ok) else "f64"

@@ -1,5 +1,6 @@
-"""Hexahedral meshes (tensor-product element DQ_1 / DQ_2 on cubes) on the HIP path - SURVEY 8(f), the last
-"next" row.
+"""Hexahedral meshes (tensor-product element DQ_1..4 on cubes) on the HIP path - SURVEY 8(f), the last "next" row.
+Degrees 1 and 2 have two kernel families (sum-factorised lane-per-cell kernels for large blocks, the sum-factorised
+thread-per-node generic kernel for small ones), degrees 3 and 4 the generic kernel only.
 
 ``ElasticLF4.create(mesh, family, degree, dimension)`` (seigen/elastic.py:27-64) builds its spaces with
 ``FunctionSpace(mesh, family, degree)`` (:81-82); on a hexahedral mesh that is [upstream] the tensor product of three
@@ -29,7 +30,7 @@ def _quiet():
     he.log = lambda s: None
 
 
-@pytest.mark.parametrize("P,N", [(1, 4), (2, 4)])
+@pytest.mark.parametrize("P,N", [(1, 4), (2, 4), (3, 2), (4, 2)])
 def test_eigenmode_on_hexahedra_matches_oracle(gpu, P, N):
     """tests/eigenmode/eigenmode_3d.py on UnitCubeMesh(N, N, N, hexahedral=True): the error functional of :42-69
     through the harness equals the oracle's to 1e-9 (north star: 1e-6), the fields to 1e-9 relative."""
@@ -66,8 +67,7 @@ def test_eigenmode_on_hexahedra_converges(gpu):
         assert math.log2(errs[0][k] / errs[1][k]) > 1.8 and math.log2(errs[1][k] / errs[2][k]) > 2.0, errs
 
 
-@pytest.mark.parametrize("path", ["generic", "lane"])
-@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("P,path", [(1, "generic"), (1, "lane"), (2, "generic"), (2, "lane"), (3, "generic"), (4, "generic")])
 def test_sponge_source_and_material_on_hexahedra(gpu, monkeypatch, P, path):
     """The extras of the explosive-source set-up on hexahedral cells: DG4 sponge (elastic.py:207-208; 125 nodal values
     per cube), a nodal source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle - on the
@@ -194,6 +194,8 @@ def test_hexahedral_blocks_equal_the_single_block(gpu):
         _multiblock_case(3, 1, (6, 3, 5), (3, 1, 2), pipelined, extras=True, diagonal="quadrilateral")
     _multiblock_case(3, 2, (5, 6, 2), (1, 3, 1), True, diagonal="quadrilateral")
     _multiblock_case(3, 2, (6, 2, 3), (2, 1, 1), True, extras=True, separable=True, diagonal="quadrilateral")
+    _multiblock_case(3, 3, (4, 2, 3), (2, 1, 3), True, extras=True, diagonal="quadrilateral")
+    _multiblock_case(3, 4, (2, 4, 2), (1, 2, 2), False, extras=True, diagonal="quadrilateral")
 
 
 def test_graph_replay_and_repeated_calls_on_hexahedra(gpu, monkeypatch):
@@ -223,7 +225,7 @@ def test_graph_replay_and_repeated_calls_on_hexahedra(gpu, monkeypatch):
 
 def test_unsupported_hexahedral_configurations_are_refused(gpu):
     from seigen_amd.backend import HipBlock
-    with pytest.raises(Exception, match="hexahedral"):
-        HipBlock(3, 3, (2, 2, 2), [0.5] * 3, [0.0] * 3, "quadrilateral")
+    with pytest.raises(Exception, match="degree"):
+        HipBlock(3, 5, (2, 2, 2), [0.5] * 3, [0.0] * 3, "quadrilateral")
     with pytest.raises(Exception, match="f32"):
         HipBlock(3, 2, (2, 2, 2), [0.5] * 3, [0.0] * 3, "quadrilateral", dtype="f32")

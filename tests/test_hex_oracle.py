@@ -38,7 +38,7 @@ def _ops(P):
     return M, D, np.stack(L), np.stack(fn)
 
 
-@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
 def test_library_tables_of_the_hexahedral_element(P):
     from seigen_amd import _lib
     lib = _lib.load()
@@ -182,16 +182,24 @@ def test_vtu_output_of_a_hexahedral_mesh(tmp_path):
     np.testing.assert_allclose(got[:, 1], xq[:, 0] * xq[:, 1] * xq[:, 2], atol=1e-13)      # trilinear: exact too
 
 
-def test_unsupported_hexahedral_configurations_are_refused():
-    """Hexahedra are built for degrees 1 and 2 (27 nodes, 9 per face); higher degrees exceed the generic kernel's
-    node limits and are refused at create time, not silently mis-run."""
-    from seigen_amd import _lib
-    lib = _lib.load()
-    assert lib.sg_reference_operator_cell(1, 3, 2, 0, 0, None, 0) == 3 * 27 * 27
-    cfg = _lib.SgConfig()
-    cfg.dim, cfg.degree, cfg.diagonal = 3, 3, 2
-    for a in range(3):
-        cfg.n[a], cfg.h[a] = 2, 0.5
-    out = C.c_void_p()
-    rc = lib.sg_create(C.byref(cfg), C.byref(out))
-    assert rc < 0
+def test_hexahedral_operator_tables_factorise():
+    """What the sum-factorised kernels rely on (csrc/api.cpp checks the same at create): D_r acts along the lines of
+    direction r only, with one 1-D matrix; L_f touches the facet node with the node's transverse indices only."""
+    for P in (1, 2, 3, 4):
+        n1 = P + 1
+        M, D, L, fn = _ops(P)
+        node = lambda a0, a1, a2: a0 + n1 * (a1 + n1 * a2)
+        D1 = np.array([[D[0][node(m, 0, 0), node(n, 0, 0)] for n in range(n1)] for m in range(n1)])
+        I = np.eye(n1)
+        np.testing.assert_allclose(D[0], np.kron(I, np.kron(I, D1)), atol=1e-9 * np.abs(D1).max())
+        np.testing.assert_allclose(D[1], np.kron(I, np.kron(D1, I)), atol=1e-9 * np.abs(D1).max())
+        np.testing.assert_allclose(D[2], np.kron(D1, np.kron(I, I)), atol=1e-9 * np.abs(D1).max())
+        for f in range(6):
+            r, side = f // 2, f % 2
+            lift = np.array([L[side][node(m, 0, 0), 0] for m in range(n1)])
+            for a in range(n1 ** 3):
+                ai = (a % n1, (a // n1) % n1, a // (n1 * n1))
+                tr = [ai[m] for m in range(3) if m != r]
+                want = np.zeros(n1 * n1)
+                want[tr[0] + n1 * tr[1]] = lift[ai[r]]
+                np.testing.assert_allclose(L[f][a], want, atol=1e-9 * np.abs(lift).max())

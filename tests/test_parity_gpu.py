@@ -43,10 +43,12 @@ CASES = [
     (2, 2, (5, 4), (2.0, 1.0), "quadrilateral"),
     (2, 3, (3, 3), (1.0, 1.0), "quadrilateral"),
     (2, 4, (4, 5), (1.0, 1.0), "quadrilateral"),
-    # hexahedral cells, DQ_1 and DQ_2 (dim 3 with sg_config::diagonal = 2)
+    # hexahedral cells, DQ_1..4 (dim 3 with sg_config::diagonal = 2)
     (3, 1, (3, 2, 4), (1.0, 1.5, 0.8), "quadrilateral"),
     (3, 2, (2, 3, 2), (1.0, 0.9, 0.5), "quadrilateral"),
     (3, 2, (5, 1, 3), (1.0, 0.3, 0.9), "quadrilateral"),
+    (3, 3, (2, 2, 3), (1.0, 0.8, 0.9), "quadrilateral"),
+    (3, 4, (2, 1, 2), (0.6, 0.4, 0.5), "quadrilateral"),
 ]
 
 

@@ -37,6 +37,9 @@ if __name__ == "__main__":
         print("P%d N=%d %-13s cells %9d nd %2d  %8.3f ms/step  %6.2f G DoF-updates/s  (%.2f TB/s algorithmic)"
               % run(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]))
         sys.exit(0)
+    for P, N in ((3, 48), (4, 40)):          # DQ_3, DQ_4: the sum-factorised generic kernel (no lane kernel)
+        print("P%d N=%d %-13s cells %9d nd %2d  %8.3f ms/step  %6.2f G DoF-updates/s  (%.2f TB/s algorithmic)" % run(P, N, "quadrilateral"))
+        sys.stdout.flush()
     for P, N in ((1, 96), (2, 64), (2, 96)):
         for diagonal in ("quadrilateral", "left"):
             print("P%d N=%d %-13s cells %9d nd %2d  %8.3f ms/step  %6.2f G DoF-updates/s  (%.2f TB/s algorithmic)" % run(P, N, diagonal))
