@@ -369,10 +369,11 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
 //   L_f (facet 2m + s) = lift1[s][a_m] on the facet node with the same transverse indices,
 //   Jinv = diag(1 / h), (c n)_f has the single component -+ 1 / h_m,
 // so a node's right-hand side takes (P + 1) FMAs per direction and one per facet instead of a dense row of nd + 6 nf
-// entries: per 64 bytes moved the stage needs ~15 FMAs, and the path is bound by HBM alone.  Lane l owns cube
-// 64 g + l as in lane_stage; the fields use the same gw = 64 layout.  The work is ordered so that at most one component's
-// 27 nodal values, the two opposite facet traces it meets and one set of 27 accumulators are live at a time
-// (register budget of two waves per SIMD); a velocity component that several results need is re-read (L2 hits).
+// entries: per 64 bytes moved the stage needs ~15 FMAs, and the path is bound by the memory system alone (measured:
+// 5.5 - 6.1 TB/s of fabric traffic, profiles/r04/hexahedra.txt).  Lane l owns cube 64 g + l as in lane_stage; the fields
+// use the same gw = 64 layout.  F works one stress component (i, j) at a time: its 27 nodal values, the two opposite
+// facet traces across axis j and one set of 27 accumulators are live together (two waves per SIMD).  G reads every velocity
+// component twice (two sweeps, see there) with one wave per SIMD at DQ_2.
 //   a.Dt = { D1 [P+1][P+1] row-major, lift1 [2][P+1] }  (api.cpp, checked there against the full D_r, L_f)
 #ifndef SG_HEX_WAVES
 #define SG_HEX_WAVES 2
