@@ -48,8 +48,8 @@ typedef struct {
 } so_extra;
 
 #define MAXD 3
-#define MAXND 35
-#define MAXNF 15
+#define MAXND 125  /* nodes per cell: 35 on a P4 tetrahedron, 125 on a DQ_4 hexahedron */
+#define MAXNF 25   /* facet nodes: 15 on a P4 triangle, 25 on a DQ_4 square (hexahedra) */
 
 void so_apply_F_ex(const so_mesh* m, const double* T, const double* u_abs, const so_extra* ex, double* out) {
   const int d = m->dim, nd = m->nd, nf = m->nf, nfaces = m->nfaces, nc = d * d;

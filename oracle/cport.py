@@ -92,6 +92,8 @@ class CPort(object):
         d = self.dim = mesh.dim
         D, L, fnode = reference_operators(d, P, getattr(mesh, "kind", "simplex"))
         nd, nf, nfaces, nc = D.shape[1], L.shape[2], L.shape[0], mesh.ncells
+        if nd > 125 or nf > 25:         # MAXND / MAXNF of seigen_oracle.c (its per-cell work arrays live on the stack)
+            raise ValueError("oracle C port: at most 125 nodes per cell and 25 per facet")
         self.nd = nd
         X = mesh.node_coords(P)
         nbr = -np.ones((nc, nfaces), dtype=np.int64)

@@ -9,7 +9,8 @@ from oracle.lf4 import OracleLF4
 
 
 @pytest.mark.parametrize("dim,n,P,quad", [(1, (6,), 2, False), (2, (3, 4), 3, False), (3, (2, 2, 2), 2, False),
-                                          (3, (2, 1, 2), 4, False), (2, (4, 3), 2, True), (2, (3, 3), 4, True)])
+                                          (3, (2, 1, 2), 4, False), (2, (4, 3), 2, True), (2, (3, 3), 4, True),
+                                          (3, (3, 2, 2), 2, True), (3, (2, 2, 1), 3, True), (3, (1, 2, 2), 4, True)])
 def test_cport_matches_numpy_oracle(dim, n, P, quad):
     m = omesh.structured(dim, n, tuple(1.0 + 0.25 * a for a in range(dim)), quadrilateral=quad)
     orc = OracleLF4(m, P)
@@ -34,7 +35,7 @@ def test_cport_extras_match_numpy_oracle():
     """so_step_ex: sponge (DG4 sigma), time-dependent stress source, per-cell lambda / mu / density in both
     update rules - the ingredients of BASELINE configs 2, 4 and 5 - against the numpy oracle, 4 steps."""
     for dim, n, P, physical, quad in ((2, (6, 5), 2, False, False), (2, (5, 4), 3, True, False), (3, (3, 2, 2), 4, False, False),
-                                      (2, (6, 5), 2, True, True)):
+                                      (2, (6, 5), 2, True, True), (3, (3, 2, 2), 2, False, True), (3, (2, 1, 2), 3, True, True)):
         m = omesh.structured(dim, n, tuple(2.0 + 0.5 * a for a in range(dim)), quadrilateral=quad)
         orc = OracleLF4(m, P)
         cp = CPort(m, P)
