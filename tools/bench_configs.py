@@ -5,6 +5,7 @@
   c1: 2-D eigenmode 40x40, P1 (launch-overhead bound)
   c4s: one rank's share of config 4 (3-D explosive source 256^3 on 8 GPUs): a 128^3-cube block, P4,
        box-Ricker stress source, zero initial state - 85 GB resident on one device
+  c3h1..c3h4: config 3's eigenmode on HEXAHEDRA, DQ_1 / DQ_2 (96^3 cubes), DQ_3 (48^3), DQ_4 (40^3)
 Prints one JSON line per config: M DoF-updates/s and ms/step (device time, hipEvents)."""
 import argparse
 import json
@@ -132,6 +133,19 @@ def config4_share(steps, warmup, n=128):
     return r
 
 
+def config3_hex(steps, warmup, P):
+    """tests/eigenmode/eigenmode_3d.py on UnitCubeMesh(N, N, N, hexahedral=True): the analytic mode as initial state"""
+    from seigen_amd.harness.eigenmode import Eigenmode3DLF4
+    N = {1: 96, 2: 96, 3: 48, 4: 40}[P]
+    em = Eigenmode3DLF4(N, P, 0.5 * (1.0 / N) / 2.0 ** (P - 1), output=False, hexahedral=True)
+    el = em.elastic
+    el.u0.assign(Function(el.U).interpolate(em._u(0)))
+    el.s0.assign(Function(el.S).interpolate(em._s(el.dt / 2)))
+    r = timed(el, steps, warmup)
+    r["config"] = "c3h%d: 3D eigenmode on %d^3 hexahedra, DQ_%d" % (P, N, P)
+    return r
+
+
 def config1(steps, warmup):
     em = Eigenmode2DLF4(40, 1, 0.0125, output=False)
     el = em.elastic
@@ -153,6 +167,8 @@ if __name__ == "__main__":
     for c in args.configs:
         r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share,
              "c2q": config2_quad,
+             "c3h1": lambda st, w: config3_hex(st, w, 1), "c3h2": lambda st, w: config3_hex(st, w, 2),
+             "c3h3": lambda st, w: config3_hex(st, w, 3), "c3h4": lambda st, w: config3_hex(st, w, 4),
              "c2f32": lambda st, w: config2(st, w, dtype="f32"),
              "c2qf32": lambda st, w: config2(st, w, quadrilateral=True, dtype="f32")}[c](args.steps, args.warmup)
         r["algorithmic_GBps"] = r["value"] * 1e6 * r.get("bytes_per_dof_update", 64) / 1e9
