@@ -378,6 +378,9 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
 #ifndef SG_HEX_WAVES
 #define SG_HEX_WAVES 2
 #endif
+#ifndef SG_HEX_HOLD
+#define SG_HEX_HOLD 1
+#endif
 #ifndef SG_HEX_WAVES_G2
 #define SG_HEX_WAVES_G2 1      // the G stages of DQ_2: three sets of nd results and the next operands live together
 #endif
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
       //   B: component i gives W_ij and W_ik along the other two axes, summed into the three pair accumulators.
       // The operands of sweep B's first component are requested before sweep A's results are stored (a load requested
       // behind a store waits for the store's acknowledgement).
-      auto load_comp = [&](int i, double (&q)[ND]) __attribute__((always_inline)) {
+      auto load_comp = [&](int i, double* q) __attribute__((always_inline)) {
         const double* o2 = own;
         asm volatile("" : "+v"(o2));        // a second read of the same component really is one (see above)
 #pragma unroll
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
       };
       // acc[a] += sc W_ik(a),  W_ik = -(1/h_k) (D1 u_i along k) + sum_s (c n)_{2k+s} lift1[s] u^_i:  u^ = 1/2 (own + neighbour),
       // the own trace on the domain boundary (a boundary lane's "neighbour" is its own cell: elastic.py:214-216)
-      auto add_W = [&](const double (&q)[ND], const double (&tn)[2][NF], int k, double sc, double (&acc)[ND]) __attribute__((always_inline)) {
+      auto add_W = [&](const double* q, const double (&tn)[2][NF], int k, double sc, double (&acc)[ND]) __attribute__((always_inline)) {
         const double w0 = 0.5 * sc * cnf[2 * k], w1 = 0.5 * sc * cnf[2 * k + 1], hk = sc * ih[k];
 #pragma unroll
         for (int t1 = 0; t1 < N1; ++t1)
@@ -613,8 +616,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
 
       // ---- sweep A
       double w[DIM][ND];
+      // a stage that is not fused keeps the three components for sweep B (HOLD): one read of the velocity instead of two;
+      // a fused stage needs those registers for the old values and reads the components again
+      constexpr bool HOLD = MODE == 0 && SG_HEX_HOLD;
+      double q[DIM][ND];
       {
-        double q[DIM][ND], tn[DIM][2][NF];
+        double tn[DIM][2][NF];
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
           load_comp(k, q[k]);
@@ -638,38 +645,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
       __builtin_amdgcn_sched_barrier(0);
       // ---- sweep B: component i's operands are requested while component i - 1 is evaluated (the first one ahead of
       //      sweep A's stores where the stage is not fused)
-      double qb[2][ND], tb[2][2][2][NF];
+      double qb[HOLD ? 1 : 2][HOLD ? 1 : ND], tb[2][2][2][NF];
       if (MODE == 1) combine3(0, DIM + 1, 2 * DIM + 2, w[0], w[1], w[2]);     // (registers: the old values instead of the operands)
-      load_comp(0, qb[0]);
+      if (!HOLD) load_comp(0, qb[0]);
       load_trace(0, 1, tb[0][0]);
       load_trace(0, 2, tb[0][1]);
       __builtin_amdgcn_sched_barrier(0);
       if (MODE == 0) store3(0, DIM + 1, 2 * DIM + 2, w[0], w[1], w[2]);
       double pr[DIM][ND];     // the pairs (0,1), (0,2), (1,2): sh_ij = sh_ji = mu (W_ij + W_ji)
 #pragma unroll
-      for (int p = 0; p < DIM; ++p)
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int a = 0; a < ND; ++a) pr[p][a] = 0.0;
-      load_comp(1, qb[1]);
+      if (!HOLD) load_comp(1, qb[HOLD ? 0 : 1]);
       load_trace(1, 0, tb[1][0]);
       load_trace(1, 2, tb[1][1]);
       __builtin_amdgcn_sched_barrier(0);
-      add_W(qb[0], tb[0][0], 1, mu, pr[0]);       // W_01
-      add_W(qb[0], tb[0][1], 2, mu, pr[1]);       // W_02
+      add_W(HOLD ? q[0] : qb[0], tb[0][0], 1, mu, pr[0]);       // W_01
+      add_W(HOLD ? q[0] : qb[0], tb[0][1], 2, mu, pr[1]);       // W_02
       pin(pr[0]);
       pin(pr[1]);
       __builtin_amdgcn_sched_barrier(0);
-      load_comp(2, qb[0]);
+      if (!HOLD) load_comp(2, qb[0]);
       load_trace(2, 0, tb[0][0]);
       load_trace(2, 1, tb[0][1]);
       __builtin_amdgcn_sched_barrier(0);
-      add_W(qb[1], tb[1][0], 0, mu, pr[0]);       // W_10
-      add_W(qb[1], tb[1][1], 2, mu, pr[2]);       // W_12
+#pragma unroll
+      for (int a = 0; a < ND; ++a) pr[2][a] = 0.0;
+      add_W(HOLD ? q[1] : qb[HOLD ? 0 : 1], tb[1][0], 0, mu, pr[0]);       // W_10
+      add_W(HOLD ? q[1] : qb[HOLD ? 0 : 1], tb[1][1], 2, mu, pr[2]);       // W_12
       pin(pr[0]);
       pin(pr[2]);
       __builtin_amdgcn_sched_barrier(0);
-      add_W(qb[0], tb[0][0], 0, mu, pr[1]);       // W_20
-      add_W(qb[0], tb[0][1], 1, mu, pr[2]);       // W_21
+      add_W(HOLD ? q[2] : qb[0], tb[0][0], 0, mu, pr[1]);       // W_20
+      add_W(HOLD ? q[2] : qb[0], tb[0][1], 1, mu, pr[2]);       // W_21
       pin(pr[1]);
       pin(pr[2]);
       __builtin_amdgcn_sched_barrier(0);
