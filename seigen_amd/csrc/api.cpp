@@ -162,10 +162,6 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->use_mfma = kp.mfma;
   h->use_lane = kp.lane;
   h->use_tile = kp.tile;
-  {
-    const char* hw = std::getenv("SEIGEN_HIP_HEXWAVE");
-    h->hexwave = (cfg->diagonal == SG_DIAGONAL_QUAD && cfg->dim == 3 && cfg->degree >= 3) ? (hw ? std::max(0, std::min(2, std::atoi(hw))) : 1) : 0;
-  }
   if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
   h->f32 = cfg->dtype;
   if (h->f32 && !h->use_mfma && !h->use_tile)

@@ -37,7 +37,6 @@ struct sg_handle {
   size_t field_alloc[4] = {0, 0, 0, 0};  // doubles allocated on the device (layout padding included)
   bool use_mfma = false;
   bool use_lane = false;
-  int hexwave = 0;           // hexahedra of degree 3 and 4: 1 = G stages on the cube-per-wave kernel (default), 2 = F stages too, 0 = neither (SEIGEN_HIP_HEXWAVE)
   bool use_tile = false;    // 2-D MFMA tile kernels (kernels_tile2d.hip), gw = 16
   int f32 = 0;              // sg_config.dtype = 1: fields, halo buffers, operator tiles and arithmetic are float (MFMA path)
   bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines

@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
   constexpr int N1 = P + 1;
   __shared__ double sDt[SF ? N1 * N1 + 2 * N1 : DIM * ND * ND];
   __shared__ double sLt[SF ? 1 : NFACES * NF * ND];
+  // sum-factorised hexahedra: results in the field's [cell][node][comp] order, written back by consecutive threads (a
+  // thread's own 3 or 9 components sit 24 / 72 bytes from its neighbour's: a third / a ninth of every line per store)
+  constexpr int NCO = (KIND == 0) ? DIM : DIM * DIM;
+  __shared__ double sOut[SF ? EB * ND * NCO : 1];
   __shared__ double sQ[EB * ND * NC];
   __shared__ double sFlux[EB * NFACES * NF * DIM];
   __shared__ long sElem[EB];
@@ -73,6 +77,26 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
   }
   __syncthreads();
 
+  auto write_back = [&]() {
+    __syncthreads();
+    for (int idx = tid; idx < EB * ND * NCO; idx += NT) {
+      const int el2 = idx / (ND * NCO);
+      const long g2 = sElem[el2];
+      if (g2 < 0) continue;
+      const long o = g2 * (ND * NCO) + (idx - el2 * (ND * NCO));
+      if (A.mode == 0) {
+        A.out[o] = sOut[idx];
+      } else {
+        double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+        if (KIND == 0 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
+          cs = A.rho2[2 * g2];
+          ca *= A.rho2[2 * g2 + 1];
+          cn *= A.rho2[2 * g2 + 1];
+        }
+        A.out[o] = cs * A.out[o] + ca * A.aux[o] + cn * sOut[idx];
+      }
+    }
+  };
   const long ncube_box = (long)A.box_n[0] * A.box_n[1] * A.box_n[2];
   const long nelem_box = ncube_box * NCLS;
   const long nbatch = (nelem_box + EB - 1) / EB;
@@ -252,6 +276,14 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
       }
       // the fused combine writes `out` in place, and `uabs` may be that same buffer:
       // every sponge read of this cell must land before any of its nodes is overwritten
+      if (SF) {
+        if (active) {
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) sOut[(el * ND + a) * DIM + i] = acc[i];
+        }
+        write_back();       // (its barrier also orders every sponge read of the batch before the in-place writes)
+        continue;
+      }
       if (A.sponge_slot != nullptr && A.mode != 0) __syncthreads();
       if (active) {
         long o = (g * ND + a) * DIM;
@@ -345,197 +377,17 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
 #pragma unroll
           for (int j = 0; j < DIM; ++j) {
             double v = mu * (W[i][j] + W[j][i]) + ((i == j) ? lam * tr : 0.0);
-            if (A.mode == 0)
+            if (SF)
+              sOut[(el * ND + a) * (DIM * DIM) + i * DIM + j] = v;
+            else if (A.mode == 0)
               A.out[o + i * DIM + j] = v;
             else
               A.out[o + i * DIM + j] = A.c_self * A.out[o + i * DIM + j] + A.c_aux * A.aux[o + i * DIM + j] + A.c_new * v;
           }
       }
+      if (SF) write_back();
     }
   }
-}
-
-// ---- hexahedra of degree 3 and 4: one cube per wave ---------------------------------------------------------------
-// 64 and 125 nodes per cube: too many for a lane (kernels_lane.hip hex_stage), and the thread-per-node kernel above pays
-// four block-wide barriers per batch and per-thread cube decoding.  Here a WAVE owns a cube: its nodal values go to a
-// wave-private piece of LDS with full-width loads, the facet fluxes are formed there, then every lane evaluates one or two
-// nodes sum-factorised (a line of P + 1 values per axis, one lift factor per facet).  Everything per cube - neighbour
-// pointers, ghost slots, material - is wave-uniform; only wave-level ordering is needed between the phases.  Fields in the
-// host layout (gw = 1), as for the generic kernel.  A.Dt = { D1, lift1 } (api.cpp).
-template <int P, int KIND>
-__global__ __launch_bounds__(256) void hex_wave_stage(StageArgs A) {
-  constexpr int DIM = 3, N1 = P + 1, ND = N1 * N1 * N1, NF = N1 * N1, NFACES = 6, NW = 4;
-  constexpr int NC = (KIND == 0) ? 9 : 3;
-  __shared__ double sD[N1 * N1 + 2 * N1];
-  __shared__ double sQ[NW][ND * NC];
-  __shared__ double sFlux[NW][NFACES * NF * DIM];
-  __shared__ double sUa[KIND == 0 ? NW : 1][KIND == 0 ? ND * DIM : 1];      // F, sponge cells: the velocity the sponge multiplies
-  constexpr int NCO = (KIND == 0) ? 3 : 9;
-  __shared__ double sOut[NW][ND * NCO];     // results in the field's [node][comp] order: written back with full-width accesses
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < N1 * N1 + 2 * N1; i += 256) sD[i] = A.Dt[i];
-  __syncthreads();
-  const MeshDev* md = A.md;
-  double* q = sQ[wave];
-  double* fx = sFlux[wave];
-  const long ncube_box = (long)A.box_n[0] * A.box_n[1] * A.box_n[2];
-  const int n0 = md->n[0], n1 = md->n[1], n2 = md->n[2];
-  double ih[DIM], cnf[NFACES];
-#pragma unroll
-  for (int r = 0; r < DIM; ++r) ih[r] = md->Jinv[0][r][r];
-#pragma unroll
-  for (int f = 0; f < NFACES; ++f) cnf[f] = md->cn[0][f][f / 2];
-  auto wave_sync = []() __attribute__((always_inline)) {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto node_of = [](int m, int t0, int t1, int am) -> int {
-    return m == 0 ? am + N1 * (t0 + N1 * t1) : m == 1 ? t0 + N1 * (am + N1 * t1) : t0 + N1 * (t1 + N1 * am);
-  };
-
-  for (long cb = (long)blockIdx.x * NW + wave; cb < ncube_box; cb += (long)gridDim.x * NW) {
-    // the cube (wave-uniform)
-    int c[3];
-    c[0] = (int)(cb % A.box_n[0]) + A.box_o[0];
-    const long t_ = cb / A.box_n[0];
-    c[1] = (int)(t_ % A.box_n[1]) + A.box_o[1];
-    c[2] = (int)(t_ / A.box_n[1]) + A.box_o[2];
-    const long g = c[0] + (long)n0 * (c[1] + (long)n1 * c[2]);
-    wave_sync();      // the previous cube's LDS reads are done
-    // ---- own values
-    const double* own = A.in + g * (ND * NC);
-    for (int idx = lane; idx < ND * NC; idx += 64) q[idx] = own[idx];
-    wave_sync();
-    // ---- facet fluxes: F  (c n)_j {T_ij} with {T} = 1/2 (own + neighbour), nothing on the domain boundary
-    //                    G  u^_i = 1/2 (own + neighbour), the own trace on the domain boundary   (elastic.py:204-216)
-#pragma unroll
-    for (int f = 0; f < NFACES; ++f) {
-      const int axis = f / 2, dir = (f & 1) ? 1 : -1;
-      const int cn_ = c[axis] + dir;
-      const int nax = axis == 0 ? n0 : axis == 1 ? n1 : n2;
-      const bool inside = cn_ >= 0 && cn_ < nax;
-      const long stride = axis == 0 ? 1 : axis == 1 ? n0 : (long)n0 * n1;
-      const int side = 2 * axis + (dir > 0 ? 1 : 0);
-      const bool ghost = !inside && md->has_nbr[side];
-      const bool physical = !inside && !ghost;
-      const double* nb = own;
-      if (inside) nb = A.in + (g + dir * stride) * (ND * NC);
-      if (ghost) nb = A.ghost[side] + (cube2d(axis, c, md->n) * md->halo_per_cube + md->face_ord[0][md->nb_face[0][f]]) * (long)(NF * DIM);
-      for (int bp = lane; bp < NF; bp += 64) {
-        const int t0 = bp % N1, t1 = bp / N1;
-        const int on = node_of(axis, t0, t1, (f & 1) ? P : 0);       // my facet node, and the one across the cube
-        const int nn = node_of(axis, t0, t1, (f & 1) ? 0 : P);
-#pragma unroll
-        for (int i = 0; i < DIM; ++i) {
-          double v;
-          if (KIND == 0) {
-            const double o = q[on * NC + i * DIM + axis];
-            const double nv = ghost ? nb[bp * DIM + i] : (physical ? o : nb[nn * NC + i * DIM + axis]);
-            v = physical ? 0.0 : 0.5 * (o + nv) * cnf[f];
-          } else {
-            const double o = q[on * NC + i];
-            const double nv = ghost ? nb[bp * DIM + i] : (physical ? o : nb[nn * NC + i]);
-            v = 0.5 * (o + nv) * cnf[f];
-          }
-          fx[(f * NF + bp) * DIM + i] = v;
-        }
-      }
-    }
-    wave_sync();
-    // ---- the nodes
-    double cs = A.c_self, ca = A.c_aux, cnw = A.c_new;
-    if (KIND == 0 && A.mode != 0 && A.rho2 != nullptr) {
-      cs = A.rho2[2 * g];
-      ca *= A.rho2[2 * g + 1];
-      cnw *= A.rho2[2 * g + 1];
-    }
-    const double lam = (KIND == 1) ? (A.per_cell ? A.lam[g] : A.lam0) : 0.0;
-    const double mu = (KIND == 1) ? (A.per_cell ? A.mu[g] : A.mu0) : 0.0;
-    const int sslot = (KIND == 0 && A.sponge_slot != nullptr) ? A.sponge_slot[g] : -1;
-    if (KIND == 0 && sslot >= 0) {
-      // a fused stage writes `out` in place and `uabs` may be that buffer: the whole cube's values are taken before any
-      // of its nodes is overwritten
-      const double* ua = A.uabs + g * (ND * DIM);
-      for (int idx = lane; idx < ND * DIM; idx += 64) sUa[KIND == 0 ? wave : 0][idx] = ua[idx];
-      wave_sync();
-    }
-    for (int a = lane; a < ND; a += 64) {
-      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
-      constexpr int st[3] = {1, N1, N1 * N1};
-      double W[DIM][DIM];      // F: W[i][0] accumulates uh_i;  G: W[i][k] = weak d u_i / d x_k
-#pragma unroll
-      for (int i = 0; i < DIM; ++i)
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) W[i][k] = 0.0;
-#pragma unroll
-      for (int r = 0; r < DIM; ++r) {
-        const int b0 = a - ai[r] * st[r];
-        const int bp = r == 0 ? ai[1] + N1 * ai[2] : r == 1 ? ai[0] + N1 * ai[2] : ai[0] + N1 * ai[1];
-        double d[DIM] = {0.0, 0.0, 0.0};
-        for (int m = 0; m < N1; ++m) {
-          const double dm = sD[ai[r] * N1 + m];
-          const double* t = &q[(b0 + m * st[r]) * NC];
-#pragma unroll
-          for (int i = 0; i < DIM; ++i) d[i] += dm * (KIND == 0 ? t[i * DIM + r] : t[i]);
-        }
-        const double l0 = sD[N1 * N1 + ai[r]], l1 = sD[N1 * N1 + N1 + ai[r]];
-        const double* f0 = &fx[((2 * r) * NF + bp) * DIM];
-        const double* f1 = &fx[((2 * r + 1) * NF + bp) * DIM];
-#pragma unroll
-        for (int i = 0; i < DIM; ++i) {
-          const double v = l0 * f0[i] + l1 * f1[i] - ih[r] * d[i];
-          if (KIND == 0)
-            W[i][0] += v;
-          else
-            W[i][r] = v;
-        }
-      }
-      if (KIND == 0) {
-        if (sslot >= 0) {
-          const double* B = A.sponge_B + ((long)sslot * ND + a) * ND;
-          const double* ua = sUa[KIND == 0 ? wave : 0];
-          for (int b = 0; b < ND; ++b) {
-            const double bb = B[b];
-#pragma unroll
-            for (int i = 0; i < DIM; ++i) W[i][0] -= bb * ua[b * DIM + i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < DIM; ++i) sOut[wave][a * DIM + i] = W[i][0];
-      } else {
-        const double tr = W[0][0] + W[1][1] + W[2][2];
-#pragma unroll
-        for (int i = 0; i < DIM; ++i)
-#pragma unroll
-          for (int j = 0; j < DIM; ++j) sOut[wave][a * (DIM * DIM) + i * DIM + j] = mu * (W[i][j] + W[j][i]) + ((i == j) ? lam * tr : 0.0);
-      }
-    }
-    wave_sync();
-    // ---- results (and the fused combine, elastic.py:340-352) with consecutive lanes on consecutive words
-    {
-      double* o = A.out + g * (ND * NCO);
-      const double* x = A.aux + g * (ND * NCO);
-      if (A.mode == 0) {
-        for (int idx = lane; idx < ND * NCO; idx += 64) o[idx] = sOut[wave][idx];
-      } else {
-        for (int idx = lane; idx < ND * NCO; idx += 64) o[idx] = cs * o[idx] + ca * x[idx] + cnw * sOut[wave][idx];
-      }
-    }
-  }
-}
-
-template <int P>
-static int launch_hex_wave(int kind, const StageArgs& a, hipStream_t s) {
-  const long ncube = (long)a.box_n[0] * a.box_n[1] * a.box_n[2];
-  if (ncube <= 0) return 0;
-  long grid = (ncube + 3) / 4;
-  if (grid > 256L * 8) grid = 256L * 8;
-  if (kind == 0)
-    hipLaunchKernelGGL((hex_wave_stage<P, 0>), dim3((unsigned)grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((hex_wave_stage<P, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
-  return (int)hipGetLastError();
 }
 
 template <int DIM, int P, int TP = 0>
@@ -582,12 +434,8 @@ int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream) {
     switch (P) {                                                        // hexahedra, sum-factorised (TP = 2)
       case 1: return launch_dp<3, 1, 2>(kind, a, s);                    // 8 nodes, facets of 4
       case 2: return launch_dp<3, 2, 2>(kind, a, s);                    // 27 / 9
-      // 64 / 16 and 125 / 25: the G stages on the cube-per-wave kernel (396 against 560 us at DQ_3 48^3, 528 against 660 at
-      // DQ_4 40^3: nine result components per node leave through LDS in field order), the F stages on the thread-per-node
-      // kernel (407 against 424, 480 against 623: three components, and the wave kernel's LDS footprint halves the
-      // occupancy) - profiles/r04/hexahedra.txt.  SEIGEN_HIP_HEXWAVE=0 / 2: the thread-per-node / the wave kernel for both.
-      case 3: return (a.hexwave > 1 || (a.hexwave && kind == 1)) ? launch_hex_wave<3>(kind, a, s) : launch_dp<3, 3, 2>(kind, a, s);
-      case 4: return (a.hexwave > 1 || (a.hexwave && kind == 1)) ? launch_hex_wave<4>(kind, a, s) : launch_dp<3, 4, 2>(kind, a, s);
+      case 3: return launch_dp<3, 3, 2>(kind, a, s);                    // 64 / 16
+      case 4: return launch_dp<3, 4, 2>(kind, a, s);                    // 125 / 25
     }
     return -1;
   }

@@ -116,7 +116,6 @@ struct StageArgs {
   const int32_t* nbr_tab;
   int32_t all_active;      // the launch covers the whole block (no region boxes to test)
   int32_t tensor;          // generic path: quadrilateral cells (ElemDims<2, P, 1>) / hexahedra
-  int32_t hexwave;         // generic path, hexahedra of degree 3 and 4: the cube-per-wave kernel (kernels.hip hex_wave_stage)
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
   const double* fragQ;     // MFMA path, G stages with the factorised volume term (mfma_stage_GQ): the Q tiles; fragV = the P_r tiles

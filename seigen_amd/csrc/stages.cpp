@@ -113,7 +113,6 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.err = h->err_dev;
   a.all_active = region == SG_REGION_ALL ? 1 : 0;
   a.tensor = h->re.kind == KIND_TENSOR ? 1 : 0;
-  a.hexwave = h->hexwave;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
   a.fragL = h->fragL;
   if (kind == 1 && h->fragQ) {      // G stages with the factorised volume term

@@ -176,43 +176,6 @@ def test_hexahedral_lane_kernels_stage_parity_with_the_oracle(gpu, monkeypatch, 
     assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, 0.7, 0.3)) < 1e-12
 
 
-@pytest.mark.parametrize("P,n", [(3, (5, 3, 4)), (4, (3, 2, 3)), (4, (1, 1, 1))])
-def test_cube_per_wave_kernel_agrees_with_the_thread_per_node_kernel(gpu, monkeypatch, P, n):
-    """DQ_3 / DQ_4: SEIGEN_HIP_HEXWAVE = 0 (thread-per-node kernel for every stage), 1 (the default: G stages on the
-    cube-per-wave kernel) and 2 (F stages too), with sponge, source, per-cell material and per-cell physical density;
-    blocks with neighbours on the wave kernel: bitwise equal to the single block."""
-    from seigen_amd import _lib
-    from seigen_amd.backend import HipBlock
-    rng = np.random.default_rng(P * 10 + n[0])
-    h = [0.7, 1.3, 0.9]
-    nd = (P + 1) ** 3
-    nc = n[0] * n[1] * n[2]
-    lam, mu, rho = rng.uniform(0.4, 0.8, nc), rng.uniform(0.2, 0.4, nc), rng.uniform(0.8, 1.6, nc)
-    sigma = np.where(rng.uniform(size=(nc, 125)) > 0.7, 20.0, 0.0)
-    nodes = np.unique(rng.integers(0, nc * nd, size=min(30, nc * nd)))
-    vals = rng.uniform(-1, 1, (5, len(nodes), 3, 3))
-    res = {}
-    for mode in ("0", "1", "2"):
-        monkeypatch.setenv("SEIGEN_HIP_HEXWAVE", mode)
-        blk = HipBlock(3, P, n, h, [0.0] * 3, "quadrilateral")
-        blk.set_params(1.0, 0.01 * min(h) / P ** 2, lam, mu)
-        blk.set_density(rho, physical=True)
-        blk.set_absorption(sigma, 4)
-        blk.set_source(nodes, vals)
-        blk.set_field(_lib.FIELD_U, seeded(blk.field_shape(_lib.FIELD_U), 1))
-        blk.set_field(_lib.FIELD_S, seeded(blk.field_shape(_lib.FIELD_S), 2))
-        blk.step(5)
-        res[mode] = [blk.get_field(f) for f in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH)]
-        blk.close()
-    for mode in ("1", "2"):
-        for a, b in zip(res[mode], res["0"]):
-            assert rel_err(a, b) < 1e-12
-    monkeypatch.setenv("SEIGEN_HIP_HEXWAVE", "2")
-    from tests.test_harness_gpu import _multiblock_case
-    _multiblock_case(3, P, (4, 2, 3), (2, 1, 3), True, extras=True, diagonal="quadrilateral")
-    _multiblock_case(3, P, (2, 4, 2), (1, 2, 2), False, extras=True, diagonal="quadrilateral")
-
-
 def test_hexahedral_blocks_equal_the_single_block_on_the_lane_kernels(gpu, monkeypatch):
     monkeypatch.setenv("SEIGEN_HIP_PATH", "lane")
     from tests.test_harness_gpu import _multiblock_case
