@@ -134,65 +134,13 @@ def self_launch(ngpus, timeout_s):
     sys.exit(0)
 
 
-def cpu_baseline(degree, budget_s=15.0):
+def cpu_baseline(degree, budget_s=12.0):
     """The oracle's plain-C/OpenMP restatement of the reference path (oracle/c/seigen_oracle.c,
     kind "port") timed on this host's cores: 3-D eigenmode, N=16 (24 576 tets), same P, FP64.
-    A bounded sample (~10-20 s of CPU work); baseline only."""
-    from oracle import mesh as omesh
-    from oracle import cport
-    try:
-        cport.build(arch="native", force=True)      # rebuild for this host's ISA
-    except Exception:
-        cport.build(force=True)
-    N = 16
-    m = omesh.UnitCubeMesh(N, N, N)
-    cp = cport.CPort(m, degree)
-    X = m.node_coords(degree)
-    dt = 0.5 / N / 2 ** (degree - 1)
-    u, T = eigenmode3d_fields(X, 0.0, dt / 2.0)
-    cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)           # warm-up
-    dofs = m.ncells * cp.nd * 12
-    # thread count: the visible CPUs may exceed what the job can really use (cgroup quota, SMT);
-    # probe powers of two up to the affinity mask and keep the fastest
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    best = (float("inf"), 1)
-    tcount = 1
-    one_core = None
-    while tcount <= ncpu:
-        cp.set_threads(tcount)
-        cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)
-        t0 = time.perf_counter()
-        cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)
-        el = time.perf_counter() - t0
-        if tcount == 1:
-            # the 1-core figure of SURVEY 8d: a few more steps on one thread (about 3 s)
-            t0 = time.perf_counter()
-            k1 = 0
-            while time.perf_counter() - t0 < 3.0 and k1 < 50:
-                cp.step(u, T, 1.0, dt, 0.5, 0.25, 1)
-                k1 += 1
-            one_core = dofs * k1 / (time.perf_counter() - t0) / 1e6
-        if el < best[0]:
-            best = (el, tcount)
-        if el > 4.0 * best[0]:
-            break
-        tcount *= 2
-    cp.set_threads(best[1])
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        u, T = cp.step(u, T, 1.0, dt, 0.5, 0.25, 2)
-        n += 2
-        if time.perf_counter() - t0 > budget_s or n >= 2000:
-            break
-    el = time.perf_counter() - t0
-    return {"value": dofs * n / el / 1e6, "unit": "M DoF-updates/s", "cores": cp.threads(), "value_1core": one_core,
-            "kind": "port",
-            "sample": "oracle/c/seigen_oracle.c (plain C + OpenMP) 3D eigenmode N=%d P=%d, %d tets, %d steps in %.1f s, "
-                      "%d threads" % (N, degree, m.ncells, n, el, cp.threads())}
+    A bounded sample (~15 s of CPU work); baseline only.  (oracle/baselines.py holds the set-ups.)"""
+    from oracle import baselines
+    baselines._native_build()
+    return baselines.config3(degree, budget_s)
 
 
 def csrc_digest():
@@ -340,6 +288,44 @@ def measure(elastic, args, comm, steps, warmup):
                 ranks=int(round(sum(comm.gather(1.0)))))
 
 
+def stage_accounting(dim, sym):
+    """Words per node and STAGE (UH1 STEMP U1 SH1 UTEMP S1): algorithmic (every input read once, every output
+    written once, d x d stress = the metric's 64 B per DoF-update in FP64) and what the kernels physically move when the
+    stress is stored symmetric (d (d + 1) / 2 of the d^2 lines)."""
+    d, sw = dim, dim * dim
+    words = [sw + d, d + sw, sw + 3 * d, d + sw, sw + d, 3 * sw + d]
+    sw6 = d * (d + 1) // 2
+    phys = [sw6 + d, d + sw6, sw6 + 3 * d, d + sw6, sw6 + d, 3 * sw6 + d] if sym else list(words)
+    return words, phys
+
+
+def kernel_table(blk, c0, c1, esz, region=0):
+    """Per rocprofv3 kernel name - asked of the LIBRARY (sg_stage_kernel_name: the stage's own dispatch code names the
+    instantiation it launches), not re-derived from switches - the device time of the timed region (hipEvent pairs
+    around every launch), launches, algorithmic / physical bytes and rates.  Returns (kern, stage_ms, nst)."""
+    from collections import OrderedDict
+    nodes = blk.ncells * blk.nd
+    ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
+    nl = [c1["launches"][i] - c0["launches"][i] for i in range(6)]
+    nst = c1["steps"] - c0["steps"]
+    words, words_phys = stage_accounting(blk.dim, blk.is_sym())
+    groups = OrderedDict()
+    for st in range(6):
+        groups.setdefault(blk.stage_kernel_name(st, region), []).append(st)
+    kern = OrderedDict()
+    for name, stages in groups.items():
+        tot_ms = sum(ms[i] for i in stages)
+        # bytes per STEP, not per launch: a split stage (multi-GPU: FIRST + SECOND) covers the block once, and its
+        # device time is counted once (the longer of the two concurrent launches)
+        byts = sum(words[i] for i in stages) * nst * nodes * float(esz)
+        byts_phys = sum(words_phys[i] for i in stages) * nst * nodes * float(esz)
+        per = len(stages) * nst           # stage executions of this kernel in the timed region
+        kern[name] = dict(ms=tot_ms, launches=sum(nl[i] for i in stages), avg_ms=tot_ms / max(per, 1), stages=stages,
+                          gbs=byts / max(tot_ms, 1e-12) / 1e6, gbs_phys=byts_phys / max(tot_ms, 1e-12) / 1e6,
+                          bytes_per_launch=byts / max(per, 1), bytes_phys_per_launch=byts_phys / max(per, 1))
+    return kern, ms, nst
+
+
 def halo_block(elastic, m, comm, backend):
     ex, c0, c1, nst = elastic._exchanger, m["c0"], m["c1"], m["steps"]
     st = ex.stats()
@@ -359,6 +345,73 @@ def halo_block(elastic, m, comm, backend):
             # split stages count once, with the longer of their two concurrent launches (sg_get_counters)
             "kernel_ms_per_step": comm.gather(sum(ms) / nst),
             "grid_blocks": os.environ.get("SEIGEN_HIP_GRID_BLOCKS", "default (15/16 of the block slots while exchanging)")}
+
+
+def secondary_config(key, with_cpu=True, threads=None):
+    """One entry of the bench line's "configs" object: a BASELINE configuration other than the headline (or the
+    reference's own benchmark protocol) through the solver class on this GPU - W untimed + K timed steps between
+    synchronisations, per-kernel device times in a second pass - and, for c1 / c2 / c5, the oracle's C port on the host
+    cores beside it (C1 in full, C2 20 steps, C5 50 steps)."""
+    from seigen_amd.harness import baseline_configs as bc
+    if key == "ref_strong_2d_N256_P4_T2":
+        rec = bc.reference_strong_2d(256, 4, 2.0)
+        t = rec["timestepping_s"] or rec["run_wall_s"]
+        value = rec["dofs"] * rec["steps"] / t / 1e6
+        frac = value * 1e6 * 64.0 / 1e9 / HBM_PEAK_GBS
+        rec.update({"workload": "the reference's strong-scaling protocol on one device (tests/eigenmode/README.md:7-13): 2D eigenmode "
+                                "N=256, P4, T=2.0, explicit; one warm-up run as pybench's warmups = 1, whole run(T) through the solver class",
+                    "value": value, "unit": "M DoF-updates/s", "ms_per_step": t / rec["steps"] * 1e3,
+                    "roofline": {"bound": "hbm", "frac": frac, "frac_physical": frac * 5.0 / 6.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "note": "whole run: 64 B per DoF-update x value / peak; physical = symmetric stress storage (5 of 6 words)"}})
+        return rec
+    steps, warm = {"c1": (20000, 1000), "c2": (2000, 50), "c5": (5000, 100), "c4_share": (20, 3)}[key]
+    build = {"c1": bc.config1, "c2": bc.config2, "c5": bc.config5, "c4_share": bc.config4_share}[key]
+    t0 = time.perf_counter()
+    el, label = build(2 * steps + warm)
+    blk = el.block
+    setup_s = time.perf_counter() - t0
+    el._advance(warm)
+    blk.sync()
+    t0 = time.perf_counter()
+    el._advance(steps)
+    blk.sync()
+    elapsed = time.perf_counter() - t0
+    dev_ms = blk.last_step_ms()
+    dofs = blk.u_dofs + blk.s_dofs
+    value = dofs * steps / elapsed / 1e6
+    probe = blk.get_field_range(0, 0, 4)
+    assert np.isfinite(probe).all(), "non-finite solution"
+    # per-kernel device times: a second pass with an event pair around every launch (no graph replay there; the
+    # headline figures above come from the untimed pass)
+    words, words_phys = stage_accounting(blk.dim, blk.is_sym())
+    blk.enable_timing(True)
+    c0 = blk.counters()
+    nt = max(min(steps, 200), 1)
+    el._advance(nt)
+    blk.sync()
+    c1 = blk.counters()
+    blk.enable_timing(False)
+    kern, stage_ms, nst = kernel_table(blk, c0, c1, 8)
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    phys_ratio = sum(words_phys) / float(sum(words))
+    out = {"workload": label, "value": value, "unit": "M DoF-updates/s", "ms_per_step": elapsed / steps * 1e3,
+           "device_ms_per_step": dev_ms / steps, "steps": steps, "warmup": warm, "dofs": int(dofs), "cells": int(blk.ncells),
+           "dt": el.dt, "setup_s": setup_s,
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        # whole step: 64 B per DoF-update (8 words of 8 B, SURVEY 8d) x value
+                        "achieved": value * 1e6 * 64.0 / 1e9, "frac": value * 1e6 * 64.0 / 1e9 / HBM_PEAK_GBS,
+                        "frac_physical": value * 1e6 * 64.0 / 1e9 / HBM_PEAK_GBS * phys_ratio,
+                        "dominant_kernel": dom, "dominant_kernel_frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
+                        "dominant_kernel_frac_physical": kern[dom]["gbs_phys"] / HBM_PEAK_GBS,
+                        "kernels": {kk: {"avg_us": v["avg_ms"] * 1e3, "launches": v["launches"], "algorithmic_GBps": v["gbs"],
+                                         "physical_GBps": v["gbs_phys"]} for kk, v in kern.items()},
+                        "stage_avg_us_event_timed": [stage_ms[i] / max(nst, 1) * 1e3 for i in range(6)]}}
+    blk.close()
+    del el, blk
+    if with_cpu and key in ("c1", "c2", "c5"):
+        from oracle import baselines
+        out["cpu_baseline"] = {"c1": baselines.config1, "c2": baselines.config2, "c5": baselines.config5}[key](threads=threads)
+    return out
 
 
 def main():
@@ -382,6 +435,10 @@ def main():
                     help="multi-GPU weak-scaling runs: persistent-grid sizes (SEIGEN_HIP_GRID_BLOCKS) of the launches that "
                          "overlap an exchange to time after the main measurement, reported as halo.grid_blocks_sweep "
                          "(empty string: none)")
+    ap.add_argument("--configs", default="c1,c2,c5,c4_share,ref_strong_2d_N256_P4_T2",
+                    help="one GPU, default headline: the other single-GPU configurations of BASELINE.json and the reference's "
+                         "own benchmark protocol, measured after the headline and reported as \"configs\" (\"none\": skip)")
+    ap.add_argument("--config-timeout", type=float, default=75.0, help="deadline of each entry of --configs, seconds")
     ap.add_argument("--timeout", type=float, default=900.0,
                     help="seconds after which a rank that has not finished dumps its stacks and exits non-zero")
     args = ap.parse_args()
@@ -450,51 +507,10 @@ def main():
     total_dofs = int(round(sum(comm.gather(dofs_per_gpu))))
     value = total_dofs * args.steps / elapsed / 1e6
 
-    # kernels as rocprofv3 names them: <P, 0> plain store (stages uh1/utemp, stemp/sh1),
-    # <P, 1> fused LF4 combine (stage u1, stage s1)
-    ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
-    nl = [c1["launches"][i] - c0["launches"][i] for i in range(6)]
-    nst = c1["steps"] - c0["steps"]
+    # kernels as rocprofv3 names them, from the library; per kernel the device time of the timed region
+    kern, ms, nst = kernel_table(blk, c0, c1, esz, region=3 if world > 1 else 0)      # 3 = SG_REGION_FIRST
     assert nst == args.steps, (nst, args.steps)
-    # algorithmic words per node and STAGE (every input read once, every output written
-    # once, 9-component stress = the metric's 64 B per DoF-update) ...
-    sw = d * d
-    words = [sw + d, d + sw, sw + 3 * d, d + sw, sw + d, 3 * sw + d]
-    # ... and what the kernels physically move in symmetric-stress mode (6 of the 9 lines)
-    sw6 = d * (d + 1) // 2
-    words_phys = [sw6 + d, d + sw6, sw6 + 3 * d, d + sw6, sw6 + d, 3 * sw6 + d]
-    mfma = os.environ.get("SEIGEN_HIP_PATH", "") not in ("generic", "lane") and (P >= 2 or blk.ncells >= 65536)
-    sym = 1 if blk.is_sym() else 0      # symmetric-stress storage (default; SEIGEN_HIP_SYM=0 switches it off)
-    if mfma:
-        # template arguments: <field type, degree, fused combine, symmetric storage(, reads packed remote traces)>
-        ty, gh = ("float" if args.dtype == "f32" else "double"), (1 if world > 1 else 0)
-        # G stages: the kernel with the factorised volume term (D_r = P_r Q) at degree 4 in double, or where
-        # SEIGEN_HIP_GQ forces it (csrc/api.cpp)
-        gq_env = os.environ.get("SEIGEN_HIP_GQ")
-        gq = ty == "double" and P >= 3 and ((int(gq_env) != 0) if gq_env is not None else P >= 4)
-        gname = "sg::mfma_stage_GQ" if gq else "sg::mfma_stage_G"
-        team = os.environ.get("SEIGEN_HIP_TEAM", "0")      # the trace-sharing F kernels, if someone switches them on
-        fname, ftail = ("sg::mfma_stage_FT", ", %s>" % team) if (team in ("4", "8") and ty == "double" and P >= 3) else ("sg::mfma_stage_F", ">")
-        names = (("%s<%s, %d, 0, %d, %d%s" % (fname, ty, P, sym, gh, ftail), (0, 4)),
-                 ("%s<%s, %d, 1, %d, %d%s" % (fname, ty, P, sym, gh, ftail), (2,)),
-                 ("%s<%s, %d, 0, %d>" % (gname, ty, P, sym), (1, 3)),
-                 ("%s<%s, %d, 1, %d>" % (gname, ty, P, sym), (5,)))
-    else:
-        names = (("sg::stage_kernel<3, %d, 0>" % P, (0, 2, 4)), ("sg::stage_kernel<3, %d, 1>" % P, (1, 3, 5)))
-    if not sym:
-        words_phys = words
-    kern = {}
-    for name, stages in names:
-        tot_ms = sum(ms[i] for i in stages)
-        launches = sum(nl[i] for i in stages)
-        # bytes per STEP, not per launch: a split stage (multi-GPU: FIRST + SECOND) covers the block once, and its
-        # device time is counted once (the longer of the two concurrent launches)
-        byts = sum(words[i] for i in stages) * nst * nodes * float(esz)
-        byts_phys = sum(words_phys[i] for i in stages) * nst * nodes * float(esz)
-        per = len(stages) * nst           # stage executions of this kernel in the timed region
-        kern[name] = dict(ms=tot_ms, launches=launches, avg_ms=tot_ms / max(per, 1),
-                          gbs=byts / max(tot_ms, 1e-12) / 1e6, gbs_phys=byts_phys / max(tot_ms, 1e-12) / 1e6,
-                          bytes_per_launch=byts / max(per, 1), bytes_phys_per_launch=byts_phys / max(per, 1))
+    mfma = any("mfma_stage" in kname for kname in kern)
     dom = max(kern, key=lambda k: kern[k]["ms"])
     # HBM-side bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated with
     # tools/calib_fetch.hip) - measured separately (tools/profile_config3.sh -> profiles/<round>/config3_traffic.json)
@@ -562,57 +578,91 @@ def main():
     if halo is not None:
         out["halo"] = halo
 
-    # ---- extras of a multi-GPU job (grid-size sweep, config 4 in the same processes).  The headline record above is
-    # complete; nothing below may lose it.  Each extra runs under its own deadline: a rank that is still inside the
-    # extra when it expires (a hang in an exchange, a slow build) ends the job THERE - rank 0 prints the headline with
-    # an error note in place of the extra, every rank leaves with exit code 0 - and an exception inside an extra
-    # degrades to the same note.  The job-wide watchdog (stacks + exit 1) stays armed for the headline phases only.
+    # ---- extras.  The headline record above is complete; nothing below may lose it.  Each extra runs under its own
+    # deadline: when it expires with a rank still inside the extra, rank 0 prints the headline with an error note in place
+    # of the extra and the job ends THERE.  Multi-GPU extras that time out mean a hang in an exchange: stacks are dumped
+    # and the exit code is 3 so that the driver sees it; a single-GPU extra that is merely slow (host-side set-up, the CPU
+    # baselines) ends the job with the headline and exit code 0.  An exception inside an extra degrades to the same note.
+    import threading
+    print_lock = threading.Lock()
+    printed = [False]
+
     def finish(record):
-        if rank == 0:
-            if world == 1 and not args.no_cpu_baseline:
-                record["cpu_baseline"] = cpu_baseline(P)
-            print(json.dumps(record))
-            sys.stdout.flush()
+        with print_lock:
+            if printed[0]:
+                return
+            printed[0] = True
+            if rank == 0:
+                print(json.dumps(record))
+                sys.stdout.flush()
 
     class ExtraDeadline(object):
-        def __init__(self, key, seconds):
-            import threading
-            self.key = key
+        def __init__(self, key, seconds, holder):
+            self.key, self.holder = key, holder
             self.timer = threading.Timer(seconds, self.expire)
             self.timer.daemon = True
+            self.done = self.expired = False
 
         def expire(self):
-            note = dict(out)
-            note[self.key] = {"error": "timed out after the headline measurement; headline unaffected"}
+            with print_lock:
+                if self.done:       # the extra finished while the timer was firing
+                    return
+                self.expired = True
+                note = json.loads(json.dumps(out, default=str))     # a snapshot the main thread cannot change under us
+            target = note if self.holder is None else note.setdefault(self.holder, {})
+            target[self.key] = {"error": "timed out after the headline measurement; headline unaffected"}
             try:
+                if world > 1:
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 finish(note)
             finally:
-                os._exit(0)
+                os._exit(3 if world > 1 else 0)
 
         def __enter__(self):
             self.timer.start()
             return self
 
         def __exit__(self, *exc):
+            with print_lock:
+                self.done = True
+                late = self.expired
             self.timer.cancel()
+            if late:                # the deadline fired first: its thread prints the record and ends the process
+                time.sleep(1e6)
             return False
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(P)
     extra_budget = max(60.0, min(420.0, 0.4 * args.timeout))
     want_sweep = world > 1 and workload == "c3" and args.grid_sweep and "SEIGEN_HIP_GRID_BLOCKS" not in os.environ
     want_c4 = args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4")
-    if want_sweep or want_c4:
+    # one GPU, the default headline: every other single-GPU configuration of BASELINE.json and the reference's own
+    # benchmark protocol, driver-timed in the same job (--configs none: skip)
+    want_configs = (world == 1 and args.workload is None and n == 64 and P == 4 and args.dtype == "f64" and
+                    args.configs != "none")
+    if want_sweep or want_c4 or want_configs:
         faulthandler.cancel_dump_traceback_later()
         elastic._exchanger = None
         blk.close()
         del elastic, blk
         elastic = blk = None
 
+    if want_configs:
+        out["configs"] = {}
+        threads = (out.get("cpu_baseline") or {}).get("cores")
+        for key in [c.strip() for c in args.configs.split(",") if c.strip()]:
+            try:
+                with ExtraDeadline(key, args.config_timeout, "configs"):
+                    out["configs"][key] = secondary_config(key, with_cpu=not args.no_cpu_baseline, threads=threads)
+            except Exception as e:      # noqa: BLE001 - anything here must not cost the headline
+                out["configs"][key] = {"error": repr(e)}
+
     # multi-GPU, weak-scaling workload: how the step time depends on the share of block slots the launches that run
     # beside an exchange leave to RCCL's kernels (default 15/16; it was tuned on ONE device against a self-send)
     if want_sweep:
         sweep = {}
         try:
-            with ExtraDeadline("grid_blocks_sweep", extra_budget):
+            with ExtraDeadline("grid_blocks_sweep_ms_per_step", extra_budget, "halo"):
                 for gb in [v for v in args.grid_sweep.split(",") if v.strip()]:
                     os.environ["SEIGEN_HIP_GRID_BLOCKS"] = gb.strip()
                     el_s, _, _, _, _ = build_config3(args, rank, world)
@@ -629,7 +679,7 @@ def main():
     # 8 ranks, no explicit workload: BASELINE config 4 in the same job (its own mesh, its own barriers)
     if want_c4:
         try:
-            with ExtraDeadline("config4", extra_budget):
+            with ExtraDeadline("config4", extra_budget, None):
                 el4, grid4, gn4, wname4, _ = build_config4(args, rank, world, args.c4_steps + 3 + 1)
                 m4 = measure(el4, args, comm, args.c4_steps, 3)
                 dofs4 = int(round(sum(comm.gather(el4.block.u_dofs + el4.block.s_dofs))))

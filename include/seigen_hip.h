@@ -270,6 +270,13 @@ int sg_enable_timing(sg_handle* h, int on);
 int sg_get_counters(sg_handle* h, sg_counters_t* out);
 /* ms of the last sg_step call measured with hipEvents on the launch stream */
 int sg_last_step_ms(sg_handle* h, double* ms);
+/* Name of the kernel a launch of `stage` over `region` runs on this handle, as rocprofv3 --kernel-trace prints it
+ * (e.g. "void sg::mfma_stage_G<double, 4, 0, 1, 1>(sg::StageArgs)"), NUL-terminated into buf[n] (truncated if longer).
+ * Launches nothing: the stage's own dispatch code runs and reports the instantiation it selected, so profiles and
+ * bench.py's `roofline.kernel` name what actually runs - the role of PyOP2's per-parloop kernel names in the reference's
+ * timing summaries (tests/tiling/utils.py:143-144 [upstream get_timers]).  Blocks with neighbours: after sg_halo_attach /
+ * sg_comm_init (the choice depends on the attached halo buffers). */
+int sg_stage_kernel_name(sg_handle* h, int stage, int region, char* buf, size_t n);
 
 /* ---- device-free setup queries (host logic; usable without a GPU) ------------------------ */
 /* Reference-element operators of equispaced Lagrange P_degree on the dim-simplex

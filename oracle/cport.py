@@ -171,13 +171,21 @@ class CPort(object):
         if not inplace:
             u = np.ascontiguousarray(u, dtype=np.float64).copy()
             s = np.ascontiguousarray(s, dtype=np.float64).copy()
-        w = [np.empty_like(u), np.empty_like(s), np.empty_like(u), np.empty_like(s)]
+        w = self._work_arrays(u, s)
         self.work = w          # after the call: w[0] = utemp, w[1] = sh1 of the last step (the product's UH / SH buffers)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         ex = C.byref(self.extra) if self.extra is not None else None
         self.lib.so_step_ex(C.byref(self.m), ex, p(u), p(s), p(w[0]), p(w[1]), p(w[2]), p(w[3]), C.c_double(rho),
                             C.c_double(dt), C.c_double(lam), C.c_double(mu), C.c_long(step0), C.c_int(nsteps))
         return u, s
+
+    def _work_arrays(self, u, s):
+        """the four stage buffers of so_step / so_step_ex, kept between calls (a timed loop of one-step calls would
+        otherwise page in 4 fresh arrays per call)"""
+        w = getattr(self, "_work", None)
+        if w is None or w[0].shape != u.shape or w[1].shape != s.shape:
+            w = self._work = [np.empty_like(u), np.empty_like(s), np.empty_like(u), np.empty_like(s)]
+        return w
 
     def threads(self):
         return int(self.lib.so_max_threads())
@@ -201,7 +209,7 @@ class CPort(object):
     def step(self, u, s, rho, dt, lam, mu, nsteps):
         u = np.ascontiguousarray(u, dtype=np.float64).copy()
         s = np.ascontiguousarray(s, dtype=np.float64).copy()
-        w = [np.empty_like(u), np.empty_like(s), np.empty_like(u), np.empty_like(s)]
+        w = self._work_arrays(u, s)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self.lib.so_step(C.byref(self.m), p(u), p(s), p(w[0]), p(w[1]), p(w[2]), p(w[3]), C.c_double(rho),
                          C.c_double(dt), C.c_double(lam), C.c_double(mu), C.c_int(nsteps))

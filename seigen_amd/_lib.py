@@ -84,6 +84,7 @@ SYMBOLS = {
     "sg_get_counters": (C.c_int, [_P, C.POINTER(SgCounters)]),
     "sg_last_step_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "sg_reference_operator": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
+    "sg_stage_kernel_name": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "sg_region_boxes": (C.c_int, [C.POINTER(SgConfig), C.c_int, _P, C.c_int]),
     "sg_tabulate": (C.c_int, [C.c_int, C.c_int, C.c_int64, _P, _P]),
     "sg_tabulate_cell": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P]),

@@ -217,6 +217,19 @@ class HipBlock(object):
                     halo_pack_ms=float(c.halo_pack_ms), halo_pack_launches=int(c.halo_pack_launches),
                     halo_bytes_packed=int(c.halo_bytes_packed))
 
+    def stage_kernel_name(self, stage, region=0, short=True):
+        """The kernel a launch of `stage` over `region` runs, named by the library itself (sg_stage_kernel_name): as
+        rocprofv3 prints it, or (short) without the `void ` in front and the argument list behind."""
+        buf = C.create_string_buffer(512)
+        check(self.lib.sg_stage_kernel_name(self.h, int(stage), int(region), buf, len(buf)), self.h)
+        name = buf.value.decode()
+        if short:
+            if name.startswith("void "):
+                name = name[5:]
+            if name.endswith(")") and "(" in name:
+                name = name[:name.rindex("(")]
+        return name
+
     # ---- halo ---------------------------------------------------------------------------
     def halo_bytes(self, field, side):
         nb = C.c_size_t()

@@ -68,7 +68,6 @@ void sg_destroy(sg_handle* h) {
   comm_release(h);
   if (h->mk_dev) (void)hipFree(h->mk_dev);
   if (h->ftab_dev) (void)hipFree(h->ftab_dev);
-  if (h->err_word) (void)hipHostFree(h->err_word);
   if (h->fragQ) (void)hipFree(h->fragQ);
   if (h->fragP) (void)hipFree(h->fragP);
   if (h->nbr_tab) (void)hipFree(h->nbr_tab);
@@ -258,18 +257,6 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
       HIPCHECK(h, hipMalloc((void**)&h->ftab_dev, ft.size() * sizeof(int32_t)));
       HIPCHECK(h, hipMemcpy(h->ftab_dev, ft.data(), ft.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    // trace-sharing F kernels (kernels_mfma.hip mfma_stage_FT): double, degrees 3 and 4, Kuhn split
-    h->team = 0;
-    if (mk.team_ok && !h->f32 && cfg->degree >= 3) {
-      h->team = SG_TEAM_DEFAULT;
-      if (const char* te = std::getenv("SEIGEN_HIP_TEAM")) {
-        const int t = std::atoi(te);
-        h->team = (t == 4 || t == 8) ? t : 0;
-      }
-      HIPCHECK(h, hipHostMalloc((void**)&h->err_word, sizeof(int32_t), hipHostMallocMapped));
-      *h->err_word = 0;
-      HIPCHECK(h, hipHostGetDevicePointer((void**)&h->err_dev, h->err_word, 0));
-    }
     if ((h->md.ncube_pad / 16) * 6 * 16 >= ((int64_t)1 << 31))     // cell slots are int32 (288 GB hold far fewer cells)
       return fail(h, SG_ERR_ARG, "block too large for the MFMA path's neighbour table");
     {
@@ -376,6 +363,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
       if (cfg->n[2] >= 16) h->order_chunk = (int)std::max<int64_t>(6, (per_layer + 7) / 8);
     }
     if (const char* oc = std::getenv("SEIGEN_HIP_ORDER_CHUNK")) h->order_chunk = std::max(0, std::atoi(oc));
+    h->no_whole = std::getenv("SEIGEN_HIP_NO_WHOLE") != nullptr;
     // 251 blocks per XCD label: with an odd (prime) stride of 4 * 251 items a wave's items do not keep falling on
     // the same column of the mesh, e.g. on the sponge strips at both ends of every row (config 2: 0.240 -> 0.232 ms)
     h->tile_grid = 2008;
@@ -469,7 +457,7 @@ int sg_sync(sg_handle* h) {
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   if (int rc = join_second(h)) return rc;
   HIPCHECK(h, sync_all(h));
-  return check_kernel_error(h);
+  return SG_OK;
 }
 
 // Node coordinates of a block: the affine image of the reference lattice under every cell's vertex map (one

@@ -139,7 +139,7 @@ int comm_step(sg_handle* h, int64_t nsteps) {
   float ms = 0;
   HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  return check_kernel_error(h);
+  return SG_OK;
 }
 
 void comm_release(sg_handle* h) {

@@ -108,12 +108,6 @@ struct sg_handle {
   int32_t* nbr_tab = nullptr;   // MFMA path: per-item neighbour table (StageArgs::nbr_tab)
   MfmaConst* mk_dev = nullptr;  // MFMA path: scalar-load copy of the mesh constants (kernels.hpp MfmaConst)
   int32_t* ftab_dev = nullptr;  // MFMA path, F stages: tabulated trace offsets (kernels.hpp mfma_trace_offsets)
-  // MFMA path, F stages, double, degrees 3 and 4: waves per team of the trace-sharing kernels (0: plain kernels;
-  // SEIGEN_HIP_TEAM), and the word those kernels set if a team barrier ever gives up (pinned host memory the device
-  // writes through; checked by sg_sync and sg_step)
-  int team = 0;
-  int32_t* err_word = nullptr;   // host address
-  int32_t* err_dev = nullptr;    // the same word as the device sees it
   int grid_blocks = 0;  // persistent grid of the MFMA stage kernels: while an exchange is in flight ...
   int order_chunk = 0;  // MFMA path: items per XCD chunk of whole-block launches (StageArgs::order_chunk)
   int grid_full = 0;    // ... and otherwise (every block slot of the device)
@@ -134,6 +128,8 @@ struct sg_handle {
   double first_ms_pending[6] = {-1, -1, -1, -1, -1, -1};
   int first_recorded_stage = -1;         // stage whose FIRST launch recorded ev_stage last (SECOND must follow it)
   sg_counters_t counters;
+  std::string* name_out = nullptr;   // sg_stage_kernel_name: stage launches only name their kernel (StageArgs::name_out)
+  bool no_whole = false;             // SEIGEN_HIP_NO_WHOLE (diagnostic): region launches always test the boxes
   std::string err;
 };
 
@@ -177,13 +173,6 @@ inline hipError_t sync_all(sg_handle* h) {
     h->second_pending = false;
   }
   return hipStreamSynchronize(h->stream);
-}
-
-// a stage kernel reported a failure of its own (StageArgs::err); call after a synchronisation
-inline int check_kernel_error(sg_handle* h) {
-  if (h->err_word && *(volatile int32_t*)h->err_word != 0)
-    return fail(h, SG_ERR_DEVICE, "a team barrier of the trace-sharing F kernel timed out: results are invalid");
-  return SG_OK;
 }
 
 // transfer.cpp: make the (i > j) lines of both stress buffers valid again and continue with the full-tensor kernels

@@ -18,11 +18,28 @@
 // DQ_4, 3 x 125 x 125 doubles, would not fit).  A.Dt = { D1 [P+1][P+1] row-major, lift1 [2][P+1] } (api.cpp).
 #include <hip/hip_runtime.h>
 
+#include <cxxabi.h>
+#include <dlfcn.h>
+
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.hpp"
 
 namespace sg {
+
+// The host-side handle of a __global__ function carries the kernel's own mangled name: dladdr finds it in the library's
+// dynamic symbol table, __cxa_demangle gives the spelling rocprofv3 prints.
+std::string kernel_name_of(const void* host_fn) {
+  Dl_info info;
+  if (!dladdr(host_fn, &info) || !info.dli_sname) return "(unnamed kernel)";
+  int status = 0;
+  char* d = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &status);
+  std::string out = (status == 0 && d) ? d : info.dli_sname;
+  std::free(d);
+  return out;
+}
+
 
 template <int DIM, int P, int TP = 0>
 struct Geo : ElemDims<DIM, P, TP> {
@@ -398,9 +415,9 @@ static int launch_dp(int kind, const StageArgs& a, hipStream_t s) {
   long nbatch = (nelem + G::EB - 1) / G::EB;
   long grid = nbatch < 256L * 8 ? nbatch : 256L * 8;
   if (kind == 0)
-    hipLaunchKernelGGL((stage_kernel<DIM, P, 0, TP>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    SG_LAUNCH((stage_kernel<DIM, P, 0, TP>), dim3((unsigned)grid), dim3(256), s, a, a);
   else
-    hipLaunchKernelGGL((stage_kernel<DIM, P, 1, TP>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    SG_LAUNCH((stage_kernel<DIM, P, 1, TP>), dim3((unsigned)grid), dim3(256), s, a, a);
   return (int)hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // Launch interface between the C-ABI host code (api.cpp, transfer.cpp, stages.cpp) and the HIP kernels.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "mesh_tables.hpp"
@@ -31,10 +32,7 @@ struct ElemDims {
 constexpr int MK_KSF = 4;     // facet k-steps at degree 4 (15 facet nodes)
 constexpr int MK_KS = 9;      // volume k-steps at degree 4 (35 nodes)
 #ifndef SG_GQ_FROM_DEGREE
-#define SG_GQ_FROM_DEGREE 4   // G stages with the factorised volume term (mfma_stage_GQ) from this degree on, unless SEIGEN_HIP_GQ says otherwise
-#endif
-#ifndef SG_TEAM_DEFAULT
-#define SG_TEAM_DEFAULT 0     // waves per team of the trace-sharing F kernels unless SEIGEN_HIP_TEAM says otherwise
+#define SG_GQ_FROM_DEGREE 4   // G stages with the factorised volume term (mfma_stage_G<.., FACT = 1>) from this degree on, unless SEIGEN_HIP_GQ says otherwise
 #endif
 struct MfmaClassConst {
   int32_t nb_axis[4], nb_dir[4], nb_cls[4];
@@ -42,9 +40,6 @@ struct MfmaClassConst {
   uint32_t nbw[4][MK_KSF];    // [f][ks] byte q: neighbour ELEMENT node matching my facet node 4 ks + q (MeshDev::nb_node)
   uint32_t nfw[4][MK_KSF];    // same, as position in the neighbour's facet list (MeshDev::nb_fnode)
   int32_t nb_face[4];         // neighbour's local facet (MeshDev::nb_face)
-  // team F kernels: (c n) of the NEIGHBOUR across my intra-cube facets 1 and 2 (its table entry, bit for bit), so that
-  // the trace I publish for it, (c n)_j T_ij at my nodes, is exactly what it would compute from my tensor itself
-  double pcn[2][3];
 };
 struct MfmaConst {
   int32_t n[3];
@@ -53,12 +48,6 @@ struct MfmaConst {
   int32_t pad_[2];
   int64_t ncube, ncube_pad;
   uint32_t fw[4][MK_KSF];     // [f][ks] byte q: my element node of facet node 4 ks + q (MeshDev::fnode)
-  // team F kernels: [ks] byte q = row of the wave's trace stash that element node 4 ks + q is published to, for the
-  // intra-cube facets 1 (word [0][ks]) and 2 ([1][ks]): (f - 1) * nf + position in the facet's node list, or the
-  // dummy row 2 * nf for a node that is not on the facet (the stores are unconditional)
-  uint32_t pubw[2][MK_KS];
-  int32_t team_ok;            // facets 1 and 2 are the intra-cube ones for every class (Kuhn split): the team kernels apply
-  int32_t pad2_;
   MfmaClassConst cls[6];
 };
 MfmaConst mfma_const(const MeshDev& md_host);
@@ -118,7 +107,7 @@ struct StageArgs {
   int32_t tensor;          // generic path: quadrilateral cells (ElemDims<2, P, 1>) / hexahedra
   const double* fragV;     // MFMA path: volume operator fragments (mfma_tables.hpp), else null
   const double* fragL;     // MFMA path: facet-lift operator fragments
-  const double* fragQ;     // MFMA path, G stages with the factorised volume term (mfma_stage_GQ): the Q tiles; fragV = the P_r tiles
+  const double* fragQ;     // MFMA path, G stages with the factorised volume term (mfma_stage_G<.., FACT = 1>): the Q tiles; fragV = the P_r tiles
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null
   const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
   const double* sponge_B;      // [slot][nd(a)][nd(b)]
@@ -148,10 +137,9 @@ struct StageArgs {
   // layer together, so the z-neighbour traces and the own rows of the next layer meet in the Infinity Cache.
   int32_t order_chunk;
   int32_t nitems;               // MFMA path: items of this launch (the item list's length, or cell groups x classes)
-  // MFMA path, F stages: waves per team of the trace-sharing kernels (kernels_mfma.hip mfma_stage_FT; 0 = the plain
-  // kernels), and a device word they set when a team barrier gives up (never, unless the kernel is broken)
-  int32_t team;
-  int32_t* err;
+  // Host side only (sg_stage_kernel_name): when set, the launch functions below launch NOTHING and write the name of the
+  // kernel instantiation they would have launched - taken from the same function pointer the launch uses (SG_LAUNCH)
+  std::string* name_out;
   // 2-D tile path, G stages: the sparse nodal source (elastic.py:217-218) added inside the stage kernel instead of
   // by a launch of its own.  src_slot[item] = slot of an item (16 cells of one class) that holds source nodes, or -1;
   // src_idx[slot][node][cell] = row of that node in this step's value table src_vals[row][dim*dim], or -1.
@@ -162,6 +150,21 @@ struct StageArgs {
   SrcStep src_step;          // graph replay: slice and weight from the device-side step counter (ctr != null)
   int32_t src_bump;          // 2-D tile path, first stage of a step (an F stage): bump that counter (one thread)
 };
+
+// Name of a kernel as rocprofv3 prints it ("void sg::mfma_stage_G<double, 4, 0, 1, 1>(sg::StageArgs)"), from the host-side
+// handle of the instantiation (kernels.hip: dladdr + demangling) - the library names its kernels itself, nobody re-derives
+// template arguments from switches.
+std::string kernel_name_of(const void* host_fn);
+#if defined(__HIPCC__)
+// every stage launch goes through here: launch, or (StageArgs::name_out) only name what would be launched
+#define SG_LAUNCH(kernel, grid, block, stream, A, ...)                                           \
+  do {                                                                                           \
+    if ((A).name_out)                                                                            \
+      *(A).name_out = ::sg::kernel_name_of(reinterpret_cast<const void*>(&kernel));              \
+    else                                                                                         \
+      hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                           \
+  } while (0)
+#endif
 
 // kind: 0 = F (velocity RHS), 1 = G (stress RHS)
 int launch_stage(int kind, int dim, int P, const StageArgs& a, void* stream);

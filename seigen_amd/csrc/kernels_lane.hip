@@ -718,9 +718,9 @@ static int launch_hex_p(int kind, const StageArgs& a, long nitems, hipStream_t s
 #define SG_HEX_LAUNCH(K, M)                                                        \
   do {                                                                             \
     if (a.sym)                                                                     \
-      hipLaunchKernelGGL((hex_stage<P, K, M, 1>), grid, block, 0, s, a);           \
+      SG_LAUNCH((hex_stage<P, K, M, 1>), grid, block, s, a, a);           \
     else                                                                           \
-      hipLaunchKernelGGL((hex_stage<P, K, M, 0>), grid, block, 0, s, a);           \
+      SG_LAUNCH((hex_stage<P, K, M, 0>), grid, block, s, a, a);           \
   } while (0)
   if (kind == 0) {
     if (a.mode == 0)
@@ -746,9 +746,9 @@ static int launch_lane_dp(int kind, const StageArgs& a, long nitems, hipStream_t
 #define SG_LANE_LAUNCH(K, M)                                                            \
   do {                                                                                  \
     if (a.sym)                                                                          \
-      hipLaunchKernelGGL((lane_stage<DIM, P, K, M, 1>), grid, block, 0, s, a);          \
+      SG_LAUNCH((lane_stage<DIM, P, K, M, 1>), grid, block, s, a, a);          \
     else                                                                                \
-      hipLaunchKernelGGL((lane_stage<DIM, P, K, M, 0>), grid, block, 0, s, a);          \
+      SG_LAUNCH((lane_stage<DIM, P, K, M, 0>), grid, block, s, a, a);          \
   } while (0)
   if (kind == 0) {
     if (a.mode == 0)

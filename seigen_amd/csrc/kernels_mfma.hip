@@ -74,27 +74,16 @@ struct MG {
   static constexpr int NFRAG_P = 3 * MTT * KR;
 };
 
-// Streaming accesses (SG_STREAM_HINT): old values of the fused combine and all results are touched
-// once per launch; the non-temporal hint keeps them from displacing the cell data that the
-// neighbours' lift phases are about to ask the L2 for: fabric reads -4 % (F) to -23 % (G<4,0>), step
-// time -2 %.  (The same hint on the trace loads themselves changes no traffic and costs time.)
-#if defined(SG_PLAIN_STORES)      // experiment: results through the L2 as ordinary write-back lines, old values still streamed
-#define LD_STREAM(p) __builtin_nontemporal_load(p)
-#define ST_STREAM(p, v) (*(p) = (v))
-#elif !defined(SG_NO_STREAM_HINT)
+// Streaming accesses: old values of the fused combine and all results are touched once per launch; the
+// non-temporal hint keeps them from displacing the cell data that the neighbours' lift phases are about to ask
+// the L2 for: fabric reads -4 % (F) to -23 % (G<4,0>), step time -2 %.  (The same hint on the trace loads
+// themselves changes no traffic and costs time; variants are tools/experiments/kernels_mfma_switches.patch.)
 #define LD_STREAM(p) __builtin_nontemporal_load(p)
 #define ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define LD_STREAM(p) (*(p))
-#define ST_STREAM(p, v) (*(p) = (v))
-#endif
 // A wave raises its issue priority for its MFMA phases (volume, lifts) and drops it for the epilogue,
 // so that the other wave of the SIMD cannot hold up matrix instructions with its loads and stores
 // (+1 % on the step).
-#ifndef SG_PRIO_HI
-#define SG_PRIO_HI 3
-#endif
-#define SG_PRIO(p) do { if (SG_PRIO_HI) __builtin_amdgcn_s_setprio(p); } while (0)
+#define SG_PRIO(p) __builtin_amdgcn_s_setprio(p)
 // Issue priorities per phase, one hex digit each: 0xVLE = volume, lifts, epilogue; per kernel (F / G, plain / fused).
 // The lift phase is the one that waits for memory (neighbour traces) and has little matrix work per load; the volume
 // phase has matrix work in abundance.  With the lifts ABOVE the volume a wave in its lifts gets its few matrix
@@ -102,18 +91,7 @@ struct MG {
 // phase, instead of both waves queueing at equal priority: round 2's 0x330 -> 0x120 is 2-4 % on the step
 // (profiles/r03/priority_sweep.txt: plain stages 1.22-1.28 -> 1.17-1.20 ms; the fused G stage does not care; the
 // fused F stage, bandwidth-bound, wants the opposite order once the neighbours come from the table: 0x320).
-#ifndef SG_PRIO_F0
-#define SG_PRIO_F0 0x120
-#endif
-#ifndef SG_PRIO_F1
-#define SG_PRIO_F1 0x320
-#endif
-#ifndef SG_PRIO_G0
-#define SG_PRIO_G0 0x120
-#endif
-#ifndef SG_PRIO_G1
-#define SG_PRIO_G1 0x120
-#endif
+constexpr int SG_PRIO_F0 = 0x120, SG_PRIO_F1 = 0x320, SG_PRIO_G0 = 0x120, SG_PRIO_G1 = 0x120;
 #define SG_PRIO_VOL ((PRIO3 >> 8) & 3)
 #define SG_PRIO_LIFT ((PRIO3 >> 4) & 3)
 #define SG_PRIO_EPI (PRIO3 & 3)
@@ -233,30 +211,9 @@ struct LaneGeo {
 typedef __attribute__((address_space(4))) const MfmaConst cMfmaConst;
 typedef __attribute__((address_space(4))) const MfmaClassConst cMfmaClassConst;
 
-__device__ __forceinline__ LaneGeo lane_geo(const cMfmaConst& md, const StageArgs& A, long g, int w) {
-  LaneGeo L;
-  L.c = g * 16 + w;
-  L.valid = L.c < md.ncube;
-  // 32-bit arithmetic: a block has far fewer than 2^31 cubes (288 GB hold about 2^24 of them at
-  // degree 1), and the 64-bit divisions this replaces are some hundred instructions each
-  const unsigned cl = L.valid ? (unsigned)L.c : 0u;
-  const unsigned n0 = (unsigned)md.n[0], n1 = (unsigned)md.n[1];
-  const unsigned t = cl / n0, z = t / n1;
-  L.cc[0] = (int)(cl - t * n0);
-  L.cc[1] = (int)(t - z * n1);
-  L.cc[2] = (int)z;
-  bool in = false;
-  for (int bx = 0; bx < A.nbox; ++bx) {
-    bool ib = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) ib = ib && (L.cc[a] >= A.boxes_o[bx][a]) && (L.cc[a] < A.boxes_o[bx][a] + A.boxes_n[bx][a]);
-    in = in || ib;
-  }
-  L.active = L.valid && in;
-  return L;
-}
-
-__device__ __forceinline__ LaneGeo lane_geo(const MeshDev& md, const StageArgs& A, long g, int w) {
+// (MD: the scalar-load copy of the mesh constants, MfmaConst, or the MeshDev copy in LDS)
+template <typename MD>
+__device__ __forceinline__ LaneGeo lane_geo(const MD& md, const StageArgs& A, long g, int w) {
   LaneGeo L;
   L.c = g * 16 + w;
   L.valid = L.c < md.ncube;
@@ -288,9 +245,6 @@ struct NbrRef {
   bool physical;    // domain boundary: no neighbour (p then points at the own cell)
 };
 
-// byte q of a packed node word (MfmaConst): sh = 8 * (lane >> 4)
-__device__ __forceinline__ int word_byte(unsigned w, int sh) { return (int)((w >> sh) & 255u); }
-
 // Whole-block launches test no region boxes: the cube coordinates (two integer divisions per lane) are not needed
 __device__ __forceinline__ LaneGeo lane_geo_all(long ncube, long g, int w) {
   LaneGeo L;
@@ -314,12 +268,6 @@ __device__ __forceinline__ NbrRef<R_> nbr_from_entry(const StageArgs& A, int e, 
   R.cstride = 16;
   R.ghost = e < -1;
   R.physical = e == -1;
-#ifdef SG_EXP_NOTRACE  // timing experiment only (wrong results): every trace read hits the own cell
-  R.p = own_base;
-  R.ghost = false;
-  R.physical = true;
-  return R;
-#endif
   const long slot = e < 0 ? 0 : e;
   const R_* pin = fin + ((slot >> 4) * (long)ND) * NC * 16 + (slot & 15);
   R.p = e < 0 ? own_base : pin;
@@ -340,7 +288,7 @@ struct ItemRange {
 };
 __device__ __forceinline__ ItemRange item_range(long nitems, int wave, int spread, long chunk) {
   ItemRange r;
-  const long wpb = blockDim.x >> 6;   // waves per block (4; 6 in the three-waves-per-SIMD experiment, SG_FW)
+  const long wpb = blockDim.x >> 6;   // waves per block (4)
   r.chunk = 0;
   r.xcd = 0;
   r.nitems = nitems;
@@ -426,9 +374,8 @@ __device__ __forceinline__ void load_tables(R* sAV, R* sAL, MeshDev* sMd, const 
 }
 
 
-// (c n)_j T_ij for one row i of a tensor, in ONE fixed order of operations: the consumer of a facet trace (lifts of
-// mfma_stage_F / mfma_stage_FT) and the neighbour that publishes the same product through LDS (mfma_stage_FT) must
-// agree bit for bit, whichever of the two a launch happens to use for a facet.
+// (c n)_j T_ij for one row i of a tensor, in ONE fixed order of operations (not left to the contraction heuristics: a
+// facet's flux must not depend on which instantiation - whole block, shell, ghost-reading - a launch happens to use).
 template <typename R>
 __device__ __forceinline__ R ndot(R c0, R c1, R c2, R t0, R t1, R t2) {
   R r = c0 * t0;
@@ -444,32 +391,6 @@ __device__ __forceinline__ float ndot<float>(float c0, float c1, float c2, float
   return r;
 }
 
-// Barrier among the TEAM waves of a workgroup that share traces (mfma_stage_FT): an LDS counter every wave bumps once
-// per barrier and then polls.  (gfx950 has one hardware barrier per workgroup and no named barriers; the two teams of
-// a block must stay independent of each other.)  LDS operations of one wave are performed in order, and a poll that
-// sees the bump of a sibling is performed after it, so everything the sibling wrote to LDS before is visible: no
-// vmcnt wait - the global loads in flight across the barrier are the point.  The poll gives up after SG_TEAM_SPIN
-// rounds (some tens of milliseconds) so that a broken launch ends with wrong numbers and an error word, not a hung GPU.
-#ifndef SG_TEAM_SPIN
-#define SG_TEAM_SPIN (1 << 18)
-#endif
-__device__ __forceinline__ bool team_sync(unsigned* ctr, unsigned target, int lane) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  bool ok = true;
-  int spins = 0;
-  for (;;) {
-    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    if ((int)(v - target) >= 0) break;
-    if (++spins > SG_TEAM_SPIN) {
-      ok = false;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  return ok;
-}
 
 // --------------------------------------------------------------------------------------------
 //  G: sh_ij = lam d_ij W_kk + mu (W_ij + W_ji),  W_ik = -Jinv_rk (D_r u_i) + sum_f (c n)_k L_f u^_i
@@ -477,23 +398,25 @@ __device__ __forceinline__ bool team_sync(unsigned* ctr, unsigned target, int la
 //  tile, m = 4*MTF + s for small tile s), so the three D_r u_i of one node meet in the same lane;
 //  only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
 // --------------------------------------------------------------------------------------------
-template <typename R, int P, int MODE, int SYM>
+template <typename R, int P, int MODE, int SYM, int FACT>
 __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
   constexpr int PRIO3 = MODE ? SG_PRIO_G1 : SG_PRIO_G0;
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
-#ifndef SG_PF
-#define SG_PF 4
-#endif
   // B-operand prefetch distance, in k-steps.  A float k-step is 96 matrix cycles per component against 144 in
   // double, so the same latency needs more k-steps in flight (measured: G<float,4,0> 1.10 -> 0.97 ms with 6, 0.94 with 8,
   // which costs the fused kernel more than it gains)
-  constexpr int PF = sizeof(R) == 4 ? 6 : SG_PF;
-  __shared__ R sAV[M::NFRAG_G * 64];
+  constexpr int PF = sizeof(R) == 4 ? 6 : 4;
+  constexpr int QLT = M::QLT, QST = M::QST, KR = M::KR;
+  // operator tiles in LDS: the row tiles of the three D_r (E_r: with the own-trace half of the flux folded in), or
+  // (FACT) those of the P_r in their place (A.fragV) and the Q tiles beside them
+  __shared__ R sAV[(FACT ? M::NFRAG_P : M::NFRAG_G) * 64];
+  __shared__ R sQ[FACT ? M::NFRAG_Q * 64 : 1];
   __shared__ R sAL[M::NFRAG_L * 64];
   __shared__ MeshDev sMd;
-  load_tables<M::NFRAG_G, M::NFRAG_L>(sAV, sAL, &sMd, A);
+  if constexpr (FACT) copy_to_lds<M::NFRAG_Q * 64>(sQ, reinterpret_cast<const R*>(A.fragQ));
+  load_tables<(FACT ? M::NFRAG_P : M::NFRAG_G), M::NFRAG_L>(sAV, sAL, &sMd, A);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -551,12 +474,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
 #pragma unroll
       for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = R(0);
 
-#ifndef SG_GNBUF
-#define SG_GNBUF 2
-#endif
-    constexpr int NB = SG_GNBUF;   // trace buffers: facet f in nx[f % NB], the next NB - 1 facets on their way
-    R nx[NB][KSF][3];
-    auto request = [&](int f, R (&dst)[KSF][3]) {
+    constexpr int NB = 2;   // trace buffers: facet f in nx[f % NB], the next NB - 1 facets on their way
+    constexpr int NBO = FACT ? NB : 1;
+    R nx[NB][KSF][3], nxo[NBO][KSF][3];   // nxo (FACT): the own traces of the same facet nodes
+    auto request = [&](int f, R (&dst)[KSF][3], R (&dso)[KSF][3]) {
       const NbrRef<R> NR = nbr_from_entry<ND, NF, 3>(A, nbe[f], 2 * sMd.nb_axis[k][f] + (sMd.nb_dir[k][f] > 0 ? 1 : 0), own);
 #pragma unroll
       for (int ks = 0; ks < KSF; ++ks) {
@@ -564,16 +485,80 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
         const int on = sMd.fnode[f][bb];
         const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) dst[ks][i] = NR.p[(nn * 3 + i) * NR.cstride];
+        for (int i = 0; i < 3; ++i) {
+          dst[ks][i] = NR.p[(nn * 3 + i) * NR.cstride];
+          // FACT: u^ = 1/2 (own + neighbour) (own + own on a boundary facet), the 1/2 being part of the lift tiles.
+          // Two loads per value: the own rows were read a phase ago and come out of the L2.
+          if constexpr (FACT) dso[ks][i] = own[(on * 3 + i) * 16];
+        }
       }
     };
     SG_PRIO(SG_PRIO_VOL);
     STAMP(st1);
-    // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead.
-    //      One pass over the k-steps per reference direction r with all row tiles of D_r live:
-    //      one load of a B row feeds 3*MTT MFMAs, and the cell data are read three times (twice
-    //      through L1/L2); 3*MTF accumulator tiles + 3*NSM values are live next to Sd/So.
-    {
+    // W_ik += Jm[r][k] (D_r u_i) for the row tiles of one reference direction.  On the Kuhn classes J^-1 has five
+    // non-zeros out of nine: the zero columns are skipped with a scalar branch (the class is uniform over the wave)
+    auto fold_dir = [&](int r, const d4 (&acc)[M::MTFA][3], const R (&accs)[M::NSMA][3]) {
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const R c = Jm[r][kk];
+        if (uniform_nonzero(c)) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int t = 0; t < MTF; ++t)
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                if (4 * t + reg >= S4) continue;  // padded rows of the last float tile
+                if (i == kk)
+                  Sd[i][4 * t + reg] += c * acc[t][i][reg];
+                else
+                  So[i + kk - 1][4 * t + reg] += c * acc[t][i][reg];
+              }
+#pragma unroll
+            for (int t = 0; t < NSM; ++t) {
+              if (i == kk)
+                Sd[i][4 * MTF + t] += c * accs[t][i];
+              else
+                So[i + kk - 1][4 * MTF + t] += c * accs[t][i];
+            }
+          }
+        }
+      }
+      // pin the folds here: LLVM otherwise sinks these FMA chains down to the epilogue (their
+      // only use), which keeps every accumulator tile live and spills
+#pragma unroll
+      for (int m = 0; m < S4; ++m)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+    };
+    // one k-step of a direction's row tiles: acc += tile(r, t, ks) x b
+    auto tiles_step = [&](int nks, int r, int ks, const R (&b)[3], d4 (&acc)[M::MTFA][3], R (&accs)[M::NSMA][3]) {
+#pragma unroll
+      for (int t = 0; t < MTT; ++t) {
+        const R a = sAV[((r * MTT + t) * nks + ks) * 64 + lo];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (t < MTF)
+            acc[t < MTF ? t : 0][i] = MFMA64(a, b[i], acc[t < MTF ? t : 0][i]);
+          else
+            accs[t < MTF ? 0 : t - MTF][i] = MFMA4(a, b[i], accs[t < MTF ? 0 : t - MTF][i]);
+        }
+      }
+    };
+    auto clear_acc = [&](d4 (&acc)[M::MTFA][3], R (&accs)[M::NSMA][3]) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int t = 0; t < MTF; ++t) acc[t][i] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NSM; ++t) accs[t][i] = R(0);
+      }
+    };
+    if constexpr (!FACT) {
+      // ---- volume: B = the cells' own nodal values, straight from memory, PF k-steps ahead.
+      //      One pass over the k-steps per reference direction r with all row tiles of D_r live:
+      //      one load of a B row feeds 3*MTT MFMAs, and the cell data are read three times (twice
+      //      through L1/L2); 3*MTF accumulator tiles + 3*NSM values are live next to Sd/So.
       constexpr int NS = 3 * KS;
       R bq[PF][3];
 #pragma unroll
@@ -584,13 +569,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
       for (int r = 0; r < 3; ++r) {
         d4 acc[M::MTFA][3];
         R accs[M::NSMA][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-          for (int t = 0; t < MTF; ++t) acc[t][i] = d4{0, 0, 0, 0};
-#pragma unroll
-          for (int t = 0; t < NSM; ++t) accs[t][i] = R(0);
-        }
+        clear_acc(acc, accs);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int s = r * KS + ks;
@@ -601,361 +580,18 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
 #pragma unroll
             for (int i = 0; i < 3; ++i) bq[s % PF][i] = brow((s + PF) % KS)[i * 16];
           }
-#pragma unroll
-          for (int t = 0; t < MTT; ++t) {
-            const R a = sAV[((r * MTT + t) * KS + ks) * 64 + lo];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              if (t < MTF)
-                acc[t < MTF ? t : 0][i] = MFMA64(a, b[i], acc[t < MTF ? t : 0][i]);
-              else
-                accs[t < MTF ? 0 : t - MTF][i] = MFMA4(a, b[i], accs[t < MTF ? 0 : t - MTF][i]);
-            }
-          }
+          tiles_step(KS, r, ks, b, acc, accs);
         }
-        // W_ik += Jm[r][k] (D_r u_i).  On the Kuhn classes J^-1 has five non-zeros out of nine: the
-        // zero columns are skipped with a scalar branch (the class is uniform over the wave)
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          const R c = Jm[r][kk];
-          if (uniform_nonzero(c)) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-              for (int t = 0; t < MTF; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                  if (4 * t + reg >= S4) continue;  // padded rows of the last float tile
-                  if (i == kk)
-                    Sd[i][4 * t + reg] += c * acc[t][i][reg];
-                  else
-                    So[i + kk - 1][4 * t + reg] += c * acc[t][i][reg];
-                }
-#pragma unroll
-              for (int t = 0; t < NSM; ++t) {
-                if (i == kk)
-                  Sd[i][4 * MTF + t] += c * accs[t][i];
-                else
-                  So[i + kk - 1][4 * MTF + t] += c * accs[t][i];
-              }
-            }
-          }
-        }
-        // pin the folds here: LLVM otherwise sinks these FMA chains down to the epilogue (their
-        // only use), which keeps every accumulator tile live and spills
-#pragma unroll
-        for (int m = 0; m < S4; ++m)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+        fold_dir(r, acc, accs);
       }
-    }
-
-    STAMP(st2);
-    // ---- facet lifts.  u^ = avg(u) on interior facets, own trace on the boundary
-    //      (elastic.py:213-216).  The own half of avg(u) is part of the volume tiles (E_r,
-    //      mfma_tables.cpp), so the lift carries 1/2 u- on interior facets and the missing
-    //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
-    //      (a boundary lane's neighbour pointer is its own cell); the 1/2 is in the lift tiles.
-    //      Register budget: the facet's KSF*3 B values stay resident while the row tiles are
-    //      accumulated one at a time (3 accumulators instead of 3*MTT); the next facet's values are
-    //      requested before the last tile pass.  Row tile t covers the row-quads m = 4t .. 4t+3
-    //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
-    {
-#pragma unroll
-      for (int f0 = 0; f0 < NB - 1; ++f0) request(f0, nx[f0]);
-      SG_PRIO(SG_PRIO_LIFT);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        R(&flf)[KSF][3] = nx[f % NB];
-#pragma unroll
-        for (int t = 0; t < MTT; ++t) {
-          // next facet's traces: asked for a whole facet ahead
-          if (t == 0 && f + NB - 1 < 4) request(f + NB - 1, nx[(f + NB - 1) % NB]);
-          // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
-          auto fold = [&](int m0, int nm, const R (&v)[3][4]) {
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-              const R c = cnf[f][kk];
-              if (uniform_nonzero(c)) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                  for (int j = 0; j < 4; ++j)
-                    if (j < nm && m0 + j < S4) {
-                      if (i == kk)
-                        Sd[i][m0 + j] += c * v[i][j];
-                      else
-                        So[i + kk - 1][m0 + j] += c * v[i][j];
-                    }
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nm && m0 + j < S4) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m0 + j]), "+v"(So[i][m0 + j]));
-              }
-          };
-          if (t < MTF) {
-            d4 tmp[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) tmp[i] = d4{0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KSF; ++ks) {
-              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) tmp[i] = MFMA64(a, flf[ks][i], tmp[i]);
-            }
-            {
-              R v[3][4];
-#pragma unroll
-              for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) v[i][reg] = tmp[i][reg];
-              fold(4 * t, 4, v);
-            }
-          } else {
-            R tmp[3] = {R(0), R(0), R(0)};
-#pragma unroll
-            for (int ks = 0; ks < KSF; ++ks) {
-              const R a = sAL[((f * MTT + t) * KSF + ks) * 64 + lo];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) tmp[i] = MFMA4(a, flf[ks][i], tmp[i]);
-            }
-            {
-              const R v[3][4] = {{tmp[0], 0, 0, 0}, {tmp[1], 0, 0, 0}, {tmp[2], 0, 0, 0}};
-              fold(4 * MTF + (t - MTF), 1, v);
-            }
-          }
-        }
-      }
-    }
-
-    SG_PRIO(SG_PRIO_EPI);
-    STAMP(st3);
-    // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
-    //      vmcnt counts loads and stores together and the two kinds complete out of order with
-    //      each other, so any wait for a load (or a scratch reload) with stores in flight becomes a
-    //      wait for every store's acknowledgement.  Hence: finish ALL loads first, building the
-    //      results in place in Sd/So, and issue the item's stores back to back at the very end.
-    {
-      const long e = (L.valid ? L.c : 0) * 6 + k;
-      const R lam = (R)(A.per_cell ? A.lam[e] : A.lam0);
-      const R mu = (R)(A.per_cell ? A.mu[e] : A.mu0);
-      const long obase = ((g * 6 + k) * (long)ND) * 9 * 16 + w;
-      // row-quad m of this lane = node 4 m + q: per-item base + compile-time offsets (see brow)
-      int qo9 = q * 9 * 16;
-      asm volatile("" : "+v"(qo9));
-      const long ob_q = obase + qo9;
-      const long ob_l = (4 * (S4 - 1) + q < ND) ? ob_q + (long)(S4 - 1) * 4 * 9 * 16 : obase;
-      auto orow = [&](int m) { return (m == S4 - 1) ? ob_l : ob_q + (long)m * 4 * 9 * 16; };
-      if constexpr (SYM || MODE == 0) {
-        constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-#ifndef SG_PDE
-#define SG_PDE 4
-#endif
-        constexpr int PDE = SG_PDE;      // row-quads of old values in flight (MODE 1)
-        R po[PDE][6], pa[PDE][6];
-        auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
-        auto fetch_old = [&](int m) {
-          const long o1 = orow(m);
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            po[m % PDE][c] = LD_STREAM(&out[o1 + line(c) * 16]);
-            pa[m % PDE][c] = LD_STREAM(&aux[o1 + line(c) * 16]);
-          }
-        };
-        if (MODE == 1) {
-#pragma unroll
-          for (int m = 0; m < PDE && m < S4; ++m) fetch_old(m);
-        }
-#pragma unroll
-        for (int m = 0; m < S4; ++m) {
-          const R tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            Sd[i][m] = R(2) * mu * Sd[i][m] + tr;
-            So[i][m] = mu * So[i][m];
-          }
-          if (MODE == 1) {
-            // line order of the six slots: Sd0 So0 So1 Sd1 So2 Sd2
-            Sd[0][m] = c_self * po[m % PDE][0] + c_aux * pa[m % PDE][0] + c_new * Sd[0][m];
-            So[0][m] = c_self * po[m % PDE][1] + c_aux * pa[m % PDE][1] + c_new * So[0][m];
-            So[1][m] = c_self * po[m % PDE][2] + c_aux * pa[m % PDE][2] + c_new * So[1][m];
-            Sd[1][m] = c_self * po[m % PDE][3] + c_aux * pa[m % PDE][3] + c_new * Sd[1][m];
-            So[2][m] = c_self * po[m % PDE][4] + c_aux * pa[m % PDE][4] + c_new * So[2][m];
-            Sd[2][m] = c_self * po[m % PDE][5] + c_aux * pa[m % PDE][5] + c_new * Sd[2][m];
-            if (m + PDE < S4) fetch_old(m + PDE);
-          }
-#pragma unroll
-          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
-        }
-#pragma unroll
-        for (int m = 0; m < S4; ++m) {
-          const int a = 4 * m + q;
-          const long o = orow(m);
-          if (L.active && a < ND) {
-            ST_STREAM(&out[o + 0 * 16], Sd[0][m]);
-            ST_STREAM(&out[o + 1 * 16], So[0][m]);
-            ST_STREAM(&out[o + 2 * 16], So[1][m]);
-            ST_STREAM(&out[o + 4 * 16], Sd[1][m]);
-            ST_STREAM(&out[o + 5 * 16], So[2][m]);
-            ST_STREAM(&out[o + 8 * 16], Sd[2][m]);
-            if (!SYM) {
-              ST_STREAM(&out[o + 3 * 16], So[0][m]);
-              ST_STREAM(&out[o + 6 * 16], So[1][m]);
-              ST_STREAM(&out[o + 7 * 16], So[2][m]);
-            }
-          }
-        }
-        (void)NL;
-      } else {
-        // full-tensor in-place combine (asymmetric user data, rare): nine results per node
-#pragma unroll
-        for (int m = 0; m < S4; ++m) {
-          const int a = 4 * m + q;
-          const long o = orow(m);
-          const R tr = lam * (Sd[0][m] + Sd[1][m] + Sd[2][m]);
-          R s[9];
-          s[0] = R(2) * mu * Sd[0][m] + tr;
-          s[4] = R(2) * mu * Sd[1][m] + tr;
-          s[8] = R(2) * mu * Sd[2][m] + tr;
-          s[1] = s[3] = mu * So[0][m];
-          s[2] = s[6] = mu * So[1][m];
-          s[5] = s[7] = mu * So[2][m];
-#pragma unroll
-          for (int ij = 0; ij < 9; ++ij) s[ij] = c_self * out[o + ij * 16] + c_aux * aux[o + ij * 16] + c_new * s[ij];
-          if (L.active && a < ND) {
-#pragma unroll
-            for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
-          }
-        }
-      }
-    }
-    STAMP(st4);
-    STAMP_ACC;
-  }
-  STAMP_FLUSH;
-}
-
-// --------------------------------------------------------------------------------------------
-//  G with the volume term FACTORISED (double, degrees 3 and 4; mfma_tables.hpp): the three D_r of a degree-p element
-//  differentiate, so they have rank dim P_{p-1} and share their row space: D_r = P_r Q.  y_i = Q u_i once, then
-//  z_ri = P_r y_i - 8640 matrix cycles per 16 cells at degree 4 instead of 11664, and ONE pass over the own rows
-//  instead of three.  The price: the own-trace half of the central flux cannot stay folded into the volume tiles
-//  (E_r has full rank), so the lifts take 1/2 (own + neighbour) again and load the own traces as well.
-//  Everything else - folds, epilogue, regions, ghosts - is mfma_stage_G.
-// --------------------------------------------------------------------------------------------
-template <typename R, int P, int MODE, int SYM>
-__global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_GQ(StageArgs A) {
-  using M = MG<P, R>;
-  typedef typename RT<R>::v4 d4;
-  constexpr int PRIO3 = MODE ? SG_PRIO_G1 : SG_PRIO_G0;
-  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
-#ifndef SG_PF
-#define SG_PF 4
-#endif
-  // B-operand prefetch distance, in k-steps.  A float k-step is 96 matrix cycles per component against 144 in
-  // double, so the same latency needs more k-steps in flight (measured: G<float,4,0> 1.10 -> 0.97 ms with 6, 0.94 with 8,
-  // which costs the fused kernel more than it gains)
-  constexpr int PF = sizeof(R) == 4 ? 6 : SG_PF;
-  constexpr int RK = M::RK, QLT = M::QLT, QST = M::QST, KR = M::KR;
-  __shared__ R sQ[M::NFRAG_Q * 64];
-  __shared__ R sP[M::NFRAG_P * 64];
-  __shared__ R sAL[M::NFRAG_L * 64];
-  __shared__ MeshDev sMd;
-  copy_to_lds<M::NFRAG_Q * 64>(sQ, reinterpret_cast<const R*>(A.fragQ));
-  load_tables<M::NFRAG_P, M::NFRAG_L>(sP, sAL, &sMd, A);   // A.fragV holds the P_r tiles for this kernel
-  (void)RK;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, w = lane & 15;
-  // uniform reads of class constants: constant address space => s_load (scalar cache)
-  typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
-  const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
-  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
-  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
-  R* __restrict__ out = reinterpret_cast<R*>(A.out);
-  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
-  const long ngroups = sMd.ncube_pad >> 4;
-  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
-
-  STAMP_DECL;
-  for (long it = ir.lo; it < ir.hi; it += ir.step) {
-    STAMP(st0);
-    const long iti = item_of(ir, it);
-    if (iti < 0) continue;
-    const long item = A.item_list ? (long)A.item_list[iti] : iti;
-    const long g = item / 6;
-    const int k = (int)(item - g * 6);
-    const LaneGeo L = A.all_active ? lane_geo_all(sMd.ncube, g, w) : lane_geo(sMd, A, g, w);
-    const nbr4 nbe = load_nbr4(A, item, w);
-    if (!__any(L.active)) continue;
-    const R* own = in + ((g * 6 + k) * (long)ND) * 3 * 16 + w;
-    // B row of this lane at k-step ks = node 4 ks + q: one pointer per item plus compile-time
-    // offsets (a table of per-k-step offsets is item-invariant, gets hoisted out of the item loop
-    // as 64-bit values and spilled; every reload then waits for ALL loads in flight).  Only the last
-    // k-step can run past ND; those rows meet all-zero operator columns, so any finite value will
-    // do there: clamp instead of branching.
-    int qo = q * 3 * 16;
-    asm volatile("" : "+v"(qo));
-    const R* ownq = own + qo;
-    const R* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 3 * 16 : own;
-    auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 3 * 16; };
-    // operator tiles are item-invariant: an opaque lane offset keeps the compiler from hoisting
-    // all of them into registers (and, unlike a laundered pointer, keeps the reads ds_read_b64)
-    int lo = lane;
-    asm volatile("" : "+v"(lo));
-
-    R Jm[3][3], cnf[4][3];  // class constants (wave-uniform)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Jm[r][j] = (R)(-md->Jinv[k][r][j]);
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) cnf[f][j] = (R)md->cn[k][f][j];
-
-    R Sd[3][S4], So[3][S4];  // W_ii and W_ij + W_ji for (0,1), (0,2), (1,2)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int m = 0; m < S4; ++m) Sd[i][m] = So[i][m] = R(0);
-
-#ifndef SG_GNBUF
-#define SG_GNBUF 2
-#endif
-    constexpr int NB = SG_GNBUF;   // trace buffers: facet f in nx[f % NB], the next NB - 1 facets on their way
-    R nx[NB][KSF][3], nxo[NB][KSF][3];
-    auto request = [&](int f, R (&dst)[KSF][3], R (&dso)[KSF][3]) {
-      const NbrRef<R> NR = nbr_from_entry<ND, NF, 3>(A, nbe[f], 2 * sMd.nb_axis[k][f] + (sMd.nb_dir[k][f] > 0 ? 1 : 0), own);
-#pragma unroll
-      for (int ks = 0; ks < KSF; ++ks) {
-        const int bb = (4 * ks + q < NF) ? 4 * ks + q : 0;  // padded rows meet zero lift columns
-        const int on = sMd.fnode[f][bb];
-        const int nn = NR.ghost ? sMd.nb_fnode[k][f][bb] : (NR.physical ? on : sMd.nb_node[k][f][bb]);
-        // u^ = 1/2 (own + neighbour) (own + own on a boundary facet); the 1/2 is in the lift tiles.  Two loads
-        // per value: the own rows were read a phase ago and come out of the L2.
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          dst[ks][i] = NR.p[(nn * 3 + i) * NR.cstride];
-#ifdef SG_EXP_NOOWN   // timing experiment only (wrong results): what the lifts cost without the own-trace loads
-          dso[ks][i] = R(0);
-#else
-          dso[ks][i] = own[(on * 3 + i) * 16];
-#endif
-        }
-      }
-    };
-    SG_PRIO(SG_PRIO_VOL);
-    STAMP(st1);
-    // ---- volume, factorised: y_i = Q u_i (one pass over the own rows, PF k-steps ahead), then per reference
-    //      direction z = P_r y_i with the results of the first product as B operands of the second as they are
-    //      (accumulator register `reg` of a large tile = k-step `reg`; a small tile's value = its k-step), folded
-    //      into W with J^-1 as in mfma_stage_G.
-    {
+    } else {
+      // ---- volume, FACTORISED (double, degrees 3 and 4; mfma_tables.hpp): the three D_r of a degree-p element
+      //      differentiate, so they have rank dim P_{p-1} and share their row space: D_r = P_r Q.  y_i = Q u_i once
+      //      (one pass over the own rows, PF k-steps ahead), then per reference direction z = P_r y_i with the results
+      //      of the first product as B operands of the second as they are (accumulator register `reg` of a large tile
+      //      = k-step `reg`; a small tile's value = its k-step): 8640 matrix cycles per 16 cells at degree 4 instead
+      //      of 11664.  The price: the own-trace half of the central flux cannot stay folded into rank-deficient
+      //      tiles, so the lifts take 1/2 (own + neighbour) and load the own traces as well (request).
       d4 yl[QLT > 0 ? QLT : 1][3];
       R ys[QST > 0 ? QST : 1][3];
 #pragma unroll
@@ -995,88 +631,46 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_GQ(S
       for (int r = 0; r < 3; ++r) {
         d4 acc[M::MTFA][3];
         R accs[M::NSMA][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-          for (int t = 0; t < MTF; ++t) acc[t][i] = d4{0, 0, 0, 0};
-#pragma unroll
-          for (int t = 0; t < NSM; ++t) accs[t][i] = R(0);
-        }
+        clear_acc(acc, accs);
 #pragma unroll
         for (int ks = 0; ks < KR; ++ks) {
           R b[3];
 #pragma unroll
           for (int i = 0; i < 3; ++i) b[i] = (ks < 4 * QLT) ? yl[(ks / 4) < QLT ? ks / 4 : 0][i][ks % 4] : ys[(ks - 4 * QLT) >= 0 && (ks - 4 * QLT) < QST ? ks - 4 * QLT : 0][i];
-#pragma unroll
-          for (int t = 0; t < MTT; ++t) {
-            const R a = sP[((r * MTT + t) * KR + ks) * 64 + lo];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              if (t < MTF)
-                acc[t < MTF ? t : 0][i] = MFMA64(a, b[i], acc[t < MTF ? t : 0][i]);
-              else
-                accs[t < MTF ? 0 : t - MTF][i] = MFMA4(a, b[i], accs[t < MTF ? 0 : t - MTF][i]);
-            }
-          }
+          tiles_step(KR, r, ks, b, acc, accs);
         }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          const R c = Jm[r][kk];
-          if (uniform_nonzero(c)) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-              for (int t = 0; t < MTF; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                  if (4 * t + reg >= S4) continue;
-                  if (i == kk)
-                    Sd[i][4 * t + reg] += c * acc[t][i][reg];
-                  else
-                    So[i + kk - 1][4 * t + reg] += c * acc[t][i][reg];
-                }
-#pragma unroll
-              for (int t = 0; t < NSM; ++t) {
-                if (i == kk)
-                  Sd[i][4 * MTF + t] += c * accs[t][i];
-                else
-                  So[i + kk - 1][4 * MTF + t] += c * accs[t][i];
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int m = 0; m < S4; ++m)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Sd[i][m]), "+v"(So[i][m]));
+        fold_dir(r, acc, accs);
       }
     }
 
     STAMP(st2);
     // ---- facet lifts.  u^ = avg(u) on interior facets, own trace on the boundary
-    //      (elastic.py:213-216).  The own half of avg(u) is part of the volume tiles (E_r,
+    //      (elastic.py:213-216).  Plain tiles: the own half of avg(u) is part of the volume tiles (E_r,
     //      mfma_tables.cpp), so the lift carries 1/2 u- on interior facets and the missing
     //      1/2 u+ on boundary facets: in both cases half of whatever np[f] points at
     //      (a boundary lane's neighbour pointer is its own cell); the 1/2 is in the lift tiles.
+    //      FACT: 1/2 (own + that).
     //      Register budget: the facet's KSF*3 B values stay resident while the row tiles are
     //      accumulated one at a time (3 accumulators instead of 3*MTT); the next facet's values are
     //      requested before the last tile pass.  Row tile t covers the row-quads m = 4t .. 4t+3
     //      (large) or the single row-quad m = 4*MTF + (t - MTF) (small).
     {
 #pragma unroll
-      for (int f0 = 0; f0 < NB - 1; ++f0) request(f0, nx[f0], nxo[f0]);
+      for (int f0 = 0; f0 < NB - 1; ++f0) request(f0, nx[f0], nxo[f0 % NBO]);
       SG_PRIO(SG_PRIO_LIFT);
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        R flf[KSF][3];
+        R(&flf)[KSF][3] = nx[f % NB];
+        if constexpr (FACT) {
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks)
+          for (int ks = 0; ks < KSF; ++ks)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) flf[ks][i] = nx[f % NB][ks][i] + nxo[f % NB][ks][i];
+            for (int i = 0; i < 3; ++i) flf[ks][i] += nxo[f % NBO][ks][i];
+        }
 #pragma unroll
         for (int t = 0; t < MTT; ++t) {
           // next facet's traces: asked for a whole facet ahead
-          if (t == 0 && f + NB - 1 < 4) request(f + NB - 1, nx[(f + NB - 1) % NB], nxo[(f + NB - 1) % NB]);
+          if (t == 0 && f + NB - 1 < 4) request(f + NB - 1, nx[(f + NB - 1) % NB], nxo[(f + NB - 1) % NBO]);
           // W_ik += (c n)_f,k (L_f u^_i): half of the normal components of a Kuhn class are zero
           auto fold = [&](int m0, int nm, const R (&v)[3][4]) {
 #pragma unroll
@@ -1157,10 +751,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_GQ(S
       auto orow = [&](int m) { return (m == S4 - 1) ? ob_l : ob_q + (long)m * 4 * 9 * 16; };
       if constexpr (SYM || MODE == 0) {
         constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-#ifndef SG_PDE
-#define SG_PDE 4
-#endif
-        constexpr int PDE = SG_PDE;      // row-quads of old values in flight (MODE 1)
+        constexpr int PDE = 4;           // row-quads of old values in flight (MODE 1)
         R po[PDE][6], pa[PDE][6];
         auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
         auto fetch_old = [&](int m) {
@@ -1324,23 +915,22 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     // memory latency at the end of the item (the epilogue of F<4,1> took 10 k of an item's 67 k cycles against 2.8 k in
     // F<4,0>).  Rounding: the sum is formed at the scale of u / c_new, i.e. with the absolute error the final u carries
     // anyway.  c_new = 0 (dt = 0) keeps the late form.
-#ifndef SG_F1_EARLY
-#define SG_F1_EARLY 1
-#endif
     // (double only: in float u / c_new could leave the exponent range for small dt)
-    const bool early = MODE == 1 && SG_F1_EARLY && sizeof(R) == 8 && uniform_nonzero(c_new);
+    const bool early = MODE == 1 && sizeof(R) == 8 && uniform_nonzero(c_new);
     R cs = c_self, ca = c_aux, cn = c_new;
     if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
       cs = (R)A.rho2[2 * e];
       ca *= (R)A.rho2[2 * e + 1];
       cn *= (R)A.rho2[2 * e + 1];
     }
-    if (early) {
-      R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
+    // old values of the in-place combine: every one of the item requested before the first is used
+    R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
+    auto fetch_old = [&]() {
 #pragma unroll
       for (int t = 0; t < MTF; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+          // the last float tile is zero-padded: its rows beyond ND read a valid address and are not stored
           const bool row_ok = RT<R>::SMALL || (16 * t + 4 * reg + q < ND);
           const long o = row_ok ? ub_q + (long)(16 * t + 4 * reg) * 3 * 16 : ubase;
 #pragma unroll
@@ -1359,6 +949,9 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
           pas[t][i] = LD_STREAM(&aux[o + i * 16]);
         }
       }
+    };
+    if (early) {
+      fetch_old();
       const R icn = R(1) / cn;
 #pragma unroll
       for (int t = 0; t < MTF; ++t)
@@ -1382,19 +975,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 
     SG_PRIO(SG_PRIO_VOL);
     STAMP(st1);
-    // Phase order by class parity (-DSG_PHASE_PARITY): the six Kuhn classes of a cube form a ring of intra-cube face
-    // neighbours 0-1-4-5-3-2-0, i.e. two sets {0, 3, 4} and {1, 2, 5} whose intra-cube neighbours all lie in the
-    // other set (cross-cube neighbours lie in the same one).  One set runs volume -> lifts, the other lifts -> volume:
-    // a wave then asks for its intra-cube neighbours' traces (half of all trace reads) while the waves that own those
-    // cells stream the same lines as their B rows, instead of half an item (~12 us, more than the 4 MiB L2 holds)
-    // later.  Same sums in a different order for the second set.
     auto do_volume = [&]() {
       // ---- volume: K runs over (r, node); B = T~_ir = Jinv_rj T_ij formed in registers
       {
-#ifndef SG_PFV
-#define SG_PFV 1
-#endif
-        constexpr int PFV = sizeof(R) == 4 ? 2 : SG_PFV;  // k-steps of own tensors in flight ahead of the MFMAs
+        constexpr int PFV = sizeof(R) == 4 ? 2 : 1;  // k-steps of own tensors in flight ahead of the MFMAs
         R Tq[PFV][9];
 #pragma unroll
         for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
@@ -1433,10 +1017,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       //      carries +1/2 (c n).T- on interior facets and -1/2 (c n).T+ on boundary facets (which
       //      cancels the folded half): wf * (c n).T of whatever np[f] points at, the 1/2 being part
       //      of the lift tiles.
-#ifndef SG_PFLF
-#define SG_PFLF 2
-#endif
-      constexpr int PFL = sizeof(R) == 4 ? 3 : SG_PFLF;  // facet k-steps of neighbour traces in flight
+      constexpr int PFL = sizeof(R) == 4 ? 3 : 2;  // facet k-steps of neighbour traces in flight
       const R* np[4];
       R wf[4];
       int noff[4][KSF];
@@ -1492,22 +1073,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       }
 
     };
-#ifdef SG_PHASE_PARITY
-    if (__builtin_amdgcn_readfirstlane((k == 0 || k == 3 || k == 4) ? 1 : 0)) {
-      do_volume();
-      STAMP(st2);
-      do_lifts();
-    } else {
-      do_lifts();
-      STAMP(st2);
-      do_volume();
-    }
-#else
     do_volume();
     STAMP(st2);
     SG_PRIO(SG_PRIO_LIFT);
     do_lifts();
-#endif
 
     SG_PRIO(SG_PRIO_EPI);
     STAMP(st3);
@@ -1564,32 +1133,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #pragma unroll
         for (int i = 0; i < 3; ++i) accs[i][t] = cn * accs[i][t];
     } else if (MODE == 1) {
-      // every old value of the item is requested before the first one is used: one memory latency
-      // per item instead of one per row tile (the lifts' registers are free by now)
-      R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
-#pragma unroll
-      for (int t = 0; t < MTF; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          // the last float tile is zero-padded: its rows beyond ND read a valid address and are not stored
-          const bool row_ok = RT<R>::SMALL || (16 * t + 4 * reg + q < ND);
-          const long o = row_ok ? ub_q + (long)(16 * t + 4 * reg) * 3 * 16 : ubase;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
-            pa[t][reg][i] = LD_STREAM(&aux[o + i * 16]);
-          }
-        }
-#pragma unroll
-      for (int t = 0; t < NSM; ++t) {
-        const int a = 16 * MTF + 4 * t + q;
-        const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          pos[t][i] = LD_STREAM(&out[o + i * 16]);
-          pas[t][i] = LD_STREAM(&aux[o + i * 16]);
-        }
-      }
+      // one memory latency per item instead of one per row tile (the lifts' registers are free by now)
+      fetch_old();
 #pragma unroll
       for (int t = 0; t < MTF; ++t)
 #pragma unroll
@@ -1635,404 +1180,6 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
   STAMP_FLUSH;
 }
 
-
-// --------------------------------------------------------------------------------------------
-//  F with traces shared through LDS ("team" kernel; double, degrees 3 and 4).
-//
-//  The plain F kernel above reads every facet value once as own data and about 1.7 times as somebody's neighbour
-//  trace, and most of those trace reads miss the L2 (profiles/r03: F<4,0> moves 6.8 GB over the fabric for 4.0 GB of
-//  own data).  Half of a cell's facets - 1 and 2, opposite the vertices 1 and 2 of the Kuhn tetrahedron - lie INSIDE
-//  its cube: the neighbour is another class of the same cube, i.e. the same lane of another item of the same cell
-//  group, and the items of a group are consecutive.  So the TEAM waves of a team (blocks are eight waves = 8 / TEAM
-//  teams) take TEAM consecutive items in lock-step, and every wave
-//    * in its volume phase, while the own tensors pass through its registers anyway, PUBLISHES for its two intra-cube
-//      facets what the neighbour needs from it - (c n)_j T_ij with the NEIGHBOUR's scaled normal, three values per
-//      facet node instead of six or nine - into its stash in LDS (31 rows of 3 x 16 values: 15 per facet + one dummy
-//      row that takes the stores of the nodes on neither facet, so that the stores need no branch);
-//    * after the team's barrier looks for the items of its two intra-cube neighbours among its team mates and, where
-//      it finds one, lifts that facet from the mate's stash (12 ds_read_b64) instead of 24-36 global loads; the
-//      fall-back (the neighbour's item belongs to another team or round: with TEAM = 4 a third of the intra-cube
-//      facets, with 8 a sixth) is the global path, which gives the same bits (ndot).
-//  The two facets on cube faces keep the global path; their first loads are in flight across the barrier.
-//  LDS: 66 KB of operator tiles (once per CU instead of twice) + 8 x 11.6 KB of stashes = 158 KB, one block per CU.
-// --------------------------------------------------------------------------------------------
-template <typename R, int P, int MODE, int SYM, int GHOST, int TEAM>
-__global__ __launch_bounds__(512, 1) void mfma_stage_FT(StageArgs A) {
-  using M = MG<P, R>;
-  typedef typename RT<R>::v4 d4;
-  constexpr int PRIO3 = MODE ? SG_PRIO_F1 : SG_PRIO_F0;
-  constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
-  constexpr int NW = 8;                           // waves per block
-  constexpr int STASH = (2 * NF + 1) * 3 * 16;    // values per wave
-  static_assert(NW % TEAM == 0 && KS <= MK_KS && KSF <= MK_KSF, "team kernel shape");
-  __shared__ R sAV[M::NFRAG_F * 64];
-  __shared__ R sAL[M::NFRAG_L * 64];
-  __shared__ R sTr[NW * STASH];
-  __shared__ int sItem[NW];
-  __shared__ unsigned sCtr[NW / TEAM];
-  if (threadIdx.x < NW) sItem[threadIdx.x] = -1;
-  if (threadIdx.x < NW / TEAM) sCtr[threadIdx.x] = 0u;
-  load_tables<M::NFRAG_F, M::NFRAG_L, R, 512>(sAV, sAL, A);
-  const cMfmaConst& mk = *(const cMfmaConst*)(unsigned long long)A.mk;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int team0 = wave & ~(TEAM - 1);
-  const int q = lane >> 4, w = lane & 15;
-  typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
-  const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
-  const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
-  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
-  R* __restrict__ out = reinterpret_cast<R*>(A.out);
-  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
-  const long ngroups = mk.ncube_pad >> 4;
-  const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
-  // every wave of a team makes the same number of rounds (a wave without an item still meets the barriers)
-  const long lo_team = ir.lo - (wave - team0);
-  const long nrounds = ir.hi > lo_team ? (ir.hi - lo_team + ir.step - 1) / ir.step : 0;
-  unsigned* const ctr = &sCtr[wave / TEAM];
-  unsigned epoch = 0;
-  bool sync_ok = true;
-  R* const mytr = sTr + wave * STASH;
-
-  STAMP_DECL;
-  for (long rnd = 0; rnd < nrounds; ++rnd) {
-    STAMP(st0);
-    const long it = ir.lo + rnd * ir.step;
-    long item = -1;
-    if (it < ir.hi) {
-      const long iti = item_of(ir, it);
-      if (iti >= 0) item = A.item_list ? (long)A.item_list[iti] : iti;
-    }
-    const long itemc = item < 0 ? 0 : item;
-    const long g = itemc / 6;
-    const int k = (int)(itemc - g * 6);
-    const LaneGeo L = A.all_active ? lane_geo_all(mk.ncube, g, w) : lane_geo(mk, A, g, w);
-    const bool work = __builtin_amdgcn_readfirstlane((item >= 0 && __any(L.active)) ? 1 : 0) != 0;
-    const cMfmaClassConst& kc = mk.cls[k];
-    // opaque per item: the stash rows of the publication (mk.pubw) are item-invariant, and LLVM would compute all 18
-    // of them once, outside the item loop, and keep them in (spilled) registers
-    int qsh = q * 8;
-    asm volatile("" : "+v"(qsh));
-    const nbr4 nbe = load_nbr4(A, itemc, w);
-    const R* own = in + ((g * 6 + k) * (long)ND) * 9 * 16 + w;
-    int qo = q * 9 * 16;  // B rows: see mfma_stage_G
-    asm volatile("" : "+v"(qo));
-    const R* ownq = own + qo;
-    const R* ownl = (4 * (KS - 1) + q < ND) ? ownq + (KS - 1) * 4 * 9 * 16 : own;
-    auto brow = [&](int ks) { return (ks == KS - 1) ? ownl : ownq + ks * 4 * 9 * 16; };
-    int lo = lane;
-    asm volatile("" : "+v"(lo));
-
-    // my team mates have read what they wanted from my stash of the previous round
-    epoch += TEAM;
-    sync_ok = team_sync(ctr, epoch, lane) && sync_ok;
-    if (lane == 0) sItem[wave] = work ? (int)item : -1;
-
-    R Jm[3][3];
-    d4 acc[3][M::MTFA];
-    R accs[3][M::NSMA];
-    // The facets that come from memory - 0 and 3 (cube faces), and an intra-cube facet whose neighbour no team mate
-    // holds - are worked off as ONE stream of facets with the facet number a wave-uniform run-time value: one copy of
-    // the code, and the fall-back does by construction the arithmetic of the normal case.
-    constexpr int PFL = (KSF % SG_PFLF == 0) ? SG_PFLF : KSF;   // k-steps of traces in flight; divides KSF (register rotation)
-    struct FSet {       // where a facet's traces are found
-      const R* p;
-      int off[KSF];
-      R wf, cn[3];
-      bool gh;
-      int fax;
-    };
-    auto facet_setup = [&](int f) {
-      FSet S;
-      const int e = f == 0 ? nbe[0] : (f == 1 ? nbe[1] : (f == 2 ? nbe[2] : nbe[3]));
-      const int axis = kc.nb_axis[f];
-      const NbrRef<R> NR = nbr_from_entry<ND, NF, 9>(A, e, 2 * axis + (kc.nb_dir[f] > 0 ? 1 : 0), own);
-      S.p = NR.p;
-      S.gh = GHOST && NR.ghost;
-      S.fax = GHOST ? axis : 0;
-      S.wf = NR.physical ? R(-1) : R(1);
-#pragma unroll
-      for (int ks = 0; ks < KSF; ++ks) {
-        const int on = word_byte(mk.fw[f][ks], qsh);
-        const int nn = NR.ghost ? word_byte(kc.nfw[f][ks], qsh) : (NR.physical ? on : word_byte(kc.nbw[f][ks], qsh));
-        S.off[ks] = NR.ghost ? nn * 3 : nn * 9 * NR.cstride;
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) S.cn[j] = (R)md->cn[k][f][j];
-      return S;
-    };
-    R nq[PFL][9];
-    FSet cur;
-    if (work) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Jm[r][j] = (R)md->Jinv[k][r][j];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int t = 0; t < MTF; ++t) acc[i][t] = d4{0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < NSM; ++t) accs[i][t] = R(0);
-      }
-      SG_PRIO(SG_PRIO_VOL);
-      STAMP(st1);
-      // ---- volume (as in mfma_stage_F) + publication of the two intra-cube traces
-      {
-        R pcn[2][3];
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) pcn[fi][j] = (R)kc.pcn[fi][j];
-        constexpr int PFV = SG_PFV;
-        R Tq[PFV][9];
-#pragma unroll
-        for (int s0 = 0; s0 < PFV && s0 < KS; ++s0) load_tensor<SYM>(brow(s0), 16, Tq[s0]);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          R T[9];
-#pragma unroll
-          for (int c = 0; c < 9; ++c) T[c] = Tq[ks % PFV][c];
-          if (ks + PFV < KS) {
-            load_tensor<SYM>(brow(ks + PFV), 16, Tq[ks % PFV]);
-          }
-#pragma unroll
-          for (int fi = 0; fi < 2; ++fi) {
-            const int row = word_byte(mk.pubw[fi][ks], qsh);
-            R* dst = mytr + row * 48 + w;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              dst[i * 16] = ndot<R>(pcn[fi][0], pcn[fi][1], pcn[fi][2], T[i * 3 + 0], T[i * 3 + 1], T[i * 3 + 2]);
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            R Tt[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) Tt[i] = Jm[r][0] * T[i * 3 + 0] + Jm[r][1] * T[i * 3 + 1] + Jm[r][2] * T[i * 3 + 2];
-#pragma unroll
-            for (int t = 0; t < MTT; ++t) {
-              const R a = sAV[(t * 3 * KS + KS * r + ks) * 64 + lo];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) {
-                if (t < MTF)
-                  acc[i][t < MTF ? t : 0] = MFMA64(a, Tt[i], acc[i][t < MTF ? t : 0]);
-                else
-                  accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, Tt[i], accs[i][t < MTF ? 0 : t - MTF]);
-              }
-            }
-          }
-        }
-      }
-      STAMP(st2);
-      SG_PRIO(SG_PRIO_LIFT);
-      // ---- the first loads of the facet stream (facet 0): in flight across the barrier and the stash facets
-      cur = facet_setup(0);
-#pragma unroll
-      for (int s = 0; s < PFL; ++s) load_trace<SYM, GHOST>(cur.p + cur.off[s], cur.gh, cur.fax, nq[s]);
-    }
-
-    // every mate has published this round's traces
-    STAMP(sta);
-    epoch += TEAM;
-    sync_ok = team_sync(ctr, epoch, lane) && sync_ok;
-    STAMP(stb);
-    if (!work) continue;
-
-    // one k-step of one facet's lifts from the three values per facet node in fl; lof = lane + the facet's tiles
-    auto lift_step = [&](int lof, int ks, const R (&fl)[3]) {
-#pragma unroll
-      for (int t = 0; t < MTT; ++t) {
-        const R a = sAL[(t * KSF + ks) * 64 + lof];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          if (t < MTF)
-            acc[i][t < MTF ? t : 0] = MFMA64(a, fl[i], acc[i][t < MTF ? t : 0]);
-          else
-            accs[i][t < MTF ? 0 : t - MTF] = MFMA4(a, fl[i], accs[i][t < MTF ? 0 : t - MTF]);
-        }
-      }
-    };
-    // ---- the lifts, always in the facet order 0, 3, 1, 2 (the sums must not depend on where a trace came from: a
-    //      multi-block run is bitwise the single-block run).  Facets 0 and 3 lie on cube faces: traces from memory.
-    //      Facets 1 and 2 lie inside the cube: from a team mate's stash where one holds the neighbour's item, else
-    //      from memory like the others.  The facets from memory form one stream - PFL k-steps of traces in flight,
-    //      the next such facet's set-up made a facet ahead, its first loads issued during the last k-steps of this one.
-    int sl[2];
-    unsigned mcode = 0u | (3u << 2);   // the facets that come from memory, in order, two bits each
-    int nmem = 2;
-    {
-      int mates[TEAM];
-#pragma unroll
-      for (int j = 0; j < TEAM; ++j) mates[j] = sItem[team0 + j];
-#pragma unroll
-      for (int fi = 0; fi < 2; ++fi) {
-        const int want = (int)(g * 6) + kc.nb_cls[1 + fi];
-        int s1 = -1;
-#pragma unroll
-        for (int j = 0; j < TEAM; ++j) s1 = (mates[j] == want) ? team0 + j : s1;
-        sl[fi] = __builtin_amdgcn_readfirstlane(s1);
-        if (sl[fi] < 0) {
-          mcode |= (unsigned)(1 + fi) << (2 * nmem);
-          nmem += 1;
-        }
-      }
-    }
-    int jm = 0;
-    for (int j = 0; j < 4; ++j) {
-      const int f = (int)((0x9Cu >> (2 * j)) & 3u);   // 0, 3, 1, 2
-      const int lof = lo + f * (MTT * KSF * 64);
-      const int slj = j < 2 ? -1 : (j == 2 ? sl[0] : sl[1]);
-      if (slj >= 0) {
-        const R* tb = sTr + slj * STASH + (kc.nb_face[f] - 1) * (NF * 48) + w;
-        R fl[KSF][3];
-#pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          const int pos = word_byte(kc.nfw[f][ks], qsh);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) fl[ks][i] = tb[pos * 48 + i * 16];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) lift_step(lof, ks, fl[ks]);
-      } else {
-        const bool more = jm + 1 < nmem;
-        FSet nxt = cur;
-        if (more) nxt = facet_setup((int)((mcode >> (2 * jm + 2)) & 3u));
-#pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) {
-          R fl[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            fl[i] = cur.wf * ndot<R>(cur.cn[0], cur.cn[1], cur.cn[2], nq[ks % PFL][i * 3 + 0], nq[ks % PFL][i * 3 + 1],
-                                     nq[ks % PFL][i * 3 + 2]);
-          if (ks + PFL < KSF) {
-            load_trace<SYM, GHOST>(cur.p + cur.off[ks + PFL], cur.gh, cur.fax, nq[ks % PFL]);
-          } else if (more) {
-            load_trace<SYM, GHOST>(nxt.p + nxt.off[ks + PFL - KSF], nxt.gh, nxt.fax, nq[ks % PFL]);
-          }
-          lift_step(lof, ks, fl);
-        }
-        cur = nxt;
-        jm += 1;
-      }
-    }
-
-    SG_PRIO(SG_PRIO_EPI);
-    STAMP(st3);
-    // ---- sponge and epilogue: as in mfma_stage_F
-    const long e = (L.valid ? L.c : 0) * 6 + k;
-    const long ubase = ((g * 6 + k) * (long)ND) * 3 * 16 + w;
-    int qo3 = q * 3 * 16;
-    asm volatile("" : "+v"(qo3));
-    const long ub_q = ubase + qo3;
-    if (A.sponge_slot != nullptr) {
-      const int slot = L.active ? A.sponge_slot[e] : -1;
-      if (__any(slot >= 0)) {
-        if (slot >= 0) {
-          auto damp = [&](int a, R& r0, R& r1, R& r2) {
-            if (a < ND) {
-              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;
-              const R* ua = reinterpret_cast<const R*>(A.uabs);
-              R s0 = 0, s1 = 0, s2 = 0;
-              for (int b = 0; b < ND; ++b) {
-                const R bb = (R)B[b];
-                s0 += bb * ua[ubase + (b * 3 + 0) * 16];
-                s1 += bb * ua[ubase + (b * 3 + 1) * 16];
-                s2 += bb * ua[ubase + (b * 3 + 2) * 16];
-              }
-              r0 -= s0;
-              r1 -= s1;
-              r2 -= s2;
-            }
-          };
-#pragma unroll
-          for (int t = 0; t < MTF; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              R r0 = acc[0][t][reg], r1 = acc[1][t][reg], r2 = acc[2][t][reg];
-              damp(16 * t + 4 * reg + q, r0, r1, r2);
-              acc[0][t][reg] = r0;
-              acc[1][t][reg] = r1;
-              acc[2][t][reg] = r2;
-            }
-#pragma unroll
-          for (int t = 0; t < NSM; ++t) damp(16 * MTF + 4 * t + q, accs[0][t], accs[1][t], accs[2][t]);
-        }
-      }
-    }
-    if (MODE == 1) {
-      R cs = c_self, ca = c_aux, cn = c_new;
-      if (A.rho2 != nullptr) {
-        cs = (R)A.rho2[2 * e];
-        ca *= (R)A.rho2[2 * e + 1];
-        cn *= (R)A.rho2[2 * e + 1];
-      }
-      R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
-#pragma unroll
-      for (int t = 0; t < MTF; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
-            pa[t][reg][i] = LD_STREAM(&aux[o + i * 16]);
-          }
-        }
-#pragma unroll
-      for (int t = 0; t < NSM; ++t) {
-        const int a = 16 * MTF + 4 * t + q;
-        const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          pos[t][i] = LD_STREAM(&out[o + i * 16]);
-          pas[t][i] = LD_STREAM(&aux[o + i * 16]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < MTF; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            R v = cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg];
-            asm volatile("" : "+v"(v));
-            acc[i][t][reg] = v;
-          }
-#pragma unroll
-      for (int t = 0; t < NSM; ++t)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          accs[i][t] = cs * pos[t][i] + ca * pas[t][i] + cn * accs[i][t];
-          asm volatile("" : "+v"(accs[i][t]));
-        }
-    }
-    if (L.active) {
-#pragma unroll
-      for (int t = 0; t < MTF; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const long o = ub_q + (long)(16 * t + 4 * reg) * 3 * 16;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], acc[i][t][reg]);
-        }
-#pragma unroll
-      for (int t = 0; t < NSM; ++t) {
-        const int a = 16 * MTF + 4 * t + q;
-        if (a < ND) {
-          const long o = ub_q + (long)(16 * MTF + 4 * t) * 3 * 16;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) ST_STREAM(&out[o + i * 16], accs[i][t]);
-        }
-      }
-    }
-    STAMP(st4);
-    STAMP_ACC;
-  }
-  if (!sync_ok && A.err != nullptr && lane == 0) atomicOr(A.err, 1);
-  STAMP_FLUSH;
-}
-
 template <typename R, int P, int SYM>
 static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
   // persistent grid, at most 2 blocks per CU; a multiple of 8 (one item range per XCD label)
@@ -2048,57 +1195,31 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
     // blocks without neighbour blocks never meet a packed remote trace: GHOST = 0 instantiation
     bool ghosts = false;
     for (int sd = 0; sd < 6; ++sd) ghosts = ghosts || (a.ghost[sd] != nullptr);
-    if constexpr (sizeof(R) == 8 && P >= 3) {
-      if (a.team == 4 || a.team == 8) {
-        // blocks of eight waves, one per CU: half as many blocks for the same number of wave slots
-        unsigned nb2 = (unsigned)(a.grid_blocks > 0 ? a.grid_blocks : 512) / 2u;
-        if (a.nitems > 0 && !a.spread) {
-          const unsigned need = (((unsigned)a.nitems + 7u) / 8u + 7u) / 8u * 8u;
-          nb2 = need < nb2 ? need : nb2;
-        }
-        nb2 = nb2 < 8u ? 8u : nb2 / 8u * 8u;
-        const dim3 g2(nb2), b2(512);
-#define SG_LAUNCH_FT(MODE_, GH_)                                                            \
-  do {                                                                                      \
-    if (a.team == 4)                                                                        \
-      hipLaunchKernelGGL((mfma_stage_FT<R, P, MODE_, SYM, GH_, 4>), g2, b2, 0, s, a);       \
-    else                                                                                    \
-      hipLaunchKernelGGL((mfma_stage_FT<R, P, MODE_, SYM, GH_, 8>), g2, b2, 0, s, a);       \
-  } while (0)
-        if (a.mode == 0) {
-          if (ghosts) SG_LAUNCH_FT(0, 1); else SG_LAUNCH_FT(0, 0);
-        } else {
-          if (ghosts) SG_LAUNCH_FT(1, 1); else SG_LAUNCH_FT(1, 0);
-        }
-#undef SG_LAUNCH_FT
-        return (int)hipGetLastError();
-      }
-    }
     if (a.mode == 0) {
       if (ghosts)
-        hipLaunchKernelGGL((mfma_stage_F<R, P, 0, SYM, 1>), grid, block, 0, s, a);
+        SG_LAUNCH((mfma_stage_F<R, P, 0, SYM, 1>), grid, block, s, a, a);
       else
-        hipLaunchKernelGGL((mfma_stage_F<R, P, 0, SYM, 0>), grid, block, 0, s, a);
+        SG_LAUNCH((mfma_stage_F<R, P, 0, SYM, 0>), grid, block, s, a, a);
     } else {
       if (ghosts)
-        hipLaunchKernelGGL((mfma_stage_F<R, P, 1, SYM, 1>), grid, block, 0, s, a);
+        SG_LAUNCH((mfma_stage_F<R, P, 1, SYM, 1>), grid, block, s, a, a);
       else
-        hipLaunchKernelGGL((mfma_stage_F<R, P, 1, SYM, 0>), grid, block, 0, s, a);
+        SG_LAUNCH((mfma_stage_F<R, P, 1, SYM, 0>), grid, block, s, a, a);
     }
   } else {
     if constexpr (sizeof(R) == 8 && P >= 3) {
       if (a.fragQ != nullptr) {      // factorised volume term (StageArgs::fragQ; a.fragV then holds the P_r tiles)
         if (a.mode == 0)
-          hipLaunchKernelGGL((mfma_stage_GQ<R, P, 0, SYM>), grid, block, 0, s, a);
+          SG_LAUNCH((mfma_stage_G<R, P, 0, SYM, 1>), grid, block, s, a, a);
         else
-          hipLaunchKernelGGL((mfma_stage_GQ<R, P, 1, SYM>), grid, block, 0, s, a);
+          SG_LAUNCH((mfma_stage_G<R, P, 1, SYM, 1>), grid, block, s, a, a);
         return (int)hipGetLastError();
       }
     }
     if (a.mode == 0)
-      hipLaunchKernelGGL((mfma_stage_G<R, P, 0, SYM>), grid, block, 0, s, a);
+      SG_LAUNCH((mfma_stage_G<R, P, 0, SYM, 0>), grid, block, s, a, a);
     else
-      hipLaunchKernelGGL((mfma_stage_G<R, P, 1, SYM>), grid, block, 0, s, a);
+      SG_LAUNCH((mfma_stage_G<R, P, 1, SYM, 0>), grid, block, s, a, a);
   }
   return (int)hipGetLastError();
 }

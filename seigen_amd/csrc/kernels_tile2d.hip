@@ -551,14 +551,14 @@ static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems
   const dim3 grid((unsigned)blocks), block(256);
   if (kind == 0) {
     if (a.mode == 0)
-      hipLaunchKernelGGL((tile2d_stage<P, 0, 0, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
+      SG_LAUNCH((tile2d_stage<P, 0, 0, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
     else
-      hipLaunchKernelGGL((tile2d_stage<P, 0, 1, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
+      SG_LAUNCH((tile2d_stage<P, 0, 1, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
   } else {
     if (a.mode == 0)
-      hipLaunchKernelGGL((tile2d_stage<P, 1, 0, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
+      SG_LAUNCH((tile2d_stage<P, 1, 0, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
     else
-      hipLaunchKernelGGL((tile2d_stage<P, 1, 1, SYM, GHOST, TP, R>), grid, block, 0, s, a, c);
+      SG_LAUNCH((tile2d_stage<P, 1, 1, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
   }
   return (int)hipGetLastError();
 }

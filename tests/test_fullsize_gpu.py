@@ -152,35 +152,22 @@ def test_full_size_2d_workloads_tile_vs_generic(gpu, monkeypatch, config):
     (tests/explosive_source/explosive_source_lf4.py:17-45); Marmousi 383 x 121, P3, per-cell lambda / mu and a Ricker
     source - 20 LF4 steps on the production path (2-D MFMA tile kernels) against the independently written generic
     kernel family (itself checked against the oracle at small sizes): every field, everywhere, to 1e-10."""
-    import importlib.util
-    import os
     from seigen_amd import _lib
     import seigen_amd.elastic
     import seigen_amd.harness.explosive_source as hx
+    from seigen_amd.harness import baseline_configs as bc     # the set-ups bench.py's "configs" object measures
     monkeypatch.setattr(seigen_amd.elastic, "log", lambda s: None)
     monkeypatch.setattr(hx, "log", lambda s: None)
-    spec = importlib.util.spec_from_file_location(
-        "bench_configs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_configs.py"))
-    bc = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bc)
     steps, out = 20, {}
-
-    def capture(elastic, nsteps, warmup):                   # the workload builders of tools/bench_configs.py hand over here
-        elastic.setup()
-        blk = elastic.block
-        times = [elastic.dt * (k + 1) for k in range(nsteps)]
-        nodes, values, static = elastic._source_table(times)
-        assert len(nodes) > 0
-        blk.set_source(nodes, values, static=static)
-        blk.step(nsteps)
-        res = tuple(blk.get_field(f) for f in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH))
-        blk.close()
-        return dict(value=0.0, res=res)
-
-    monkeypatch.setattr(bc, "timed", capture)
     for path in ("generic", "tile"):
         monkeypatch.setenv("SEIGEN_HIP_PATH", path)
-        out[path] = (bc.config2 if config == "c2" else bc.config5)(steps, 0)["res"]
+        elastic, _ = (bc.config2 if config == "c2" else bc.config5)(steps)
+        nodes, _, _ = elastic._source_table([elastic.dt * (k + 1) for k in range(steps)])
+        assert len(nodes) > 0
+        blk = elastic.block
+        blk.step(steps)
+        out[path] = tuple(blk.get_field(f) for f in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH))
+        blk.close()
     assert np.isfinite(out["generic"][1]).all() and np.abs(out["generic"][1]).max() > 0
     for a, b in zip(out["tile"], out["generic"]):
         scale = max(np.abs(b).max(), 1e-300)

@@ -1,4 +1,4 @@
-"""The G stage kernels with the FACTORISED volume term (kernels_mfma.hip mfma_stage_GQ, SEIGEN_HIP_GQ=1; double, 3-D,
+"""The G stage kernels with the FACTORISED volume term (kernels_mfma.hip mfma_stage_G<.., FACT = 1>, SEIGEN_HIP_GQ=1; double, 3-D,
 degrees 3 and 4).  The three derivative operators D_r behind `g` (seigen/elastic.py:211-219) have rank dim P_{p-1} and
 share their row space, D_r = P_r Q: y = Q u once, then P_r y per direction - 26 % fewer matrix cycles in the volume
 phase; the own-trace half of the central flux goes back to the lifts.  The default at degree 4 (profiles/r04/
@@ -82,3 +82,35 @@ def test_gq_multiblock_bitwise(gpu, monkeypatch, degree, n, grid):
     monkeypatch.setenv("SEIGEN_HIP_GQ", "1")
     for pipelined in (True, False):
         _multiblock_case(3, degree, n, grid, pipelined, extras=True)
+
+
+@pytest.mark.parametrize("gq,fact", [("1", 1), ("0", 0)])
+def test_library_names_the_kernels_it_runs(gpu, monkeypatch, gq, fact):
+    """sg_stage_kernel_name: the stage's own dispatch code reports the instantiation it launches (what rocprofv3 prints),
+    so bench.py and the profiles never re-derive template arguments from environment switches."""
+    monkeypatch.setenv("SEIGEN_HIP_GQ", gq)
+    blk = make_block(4, (16, 2, 2), (1.0, 1.0, 1.0))
+    blk.set_params(1.0, 0.01, 0.5, 0.25)
+    names = [blk.stage_kernel_name(st) for st in range(6)]
+    assert names[0] == names[4] == "sg::mfma_stage_F<double, 4, 0, 1, 0>"
+    assert names[2] == "sg::mfma_stage_F<double, 4, 1, 1, 0>"
+    assert names[1] == names[3] == "sg::mfma_stage_G<double, 4, 0, 1, %d>" % fact
+    assert names[5] == "sg::mfma_stage_G<double, 4, 1, 1, %d>" % fact
+    full = blk.stage_kernel_name(1, short=False)
+    assert full.startswith("void sg::mfma_stage_G<") and full.endswith("(sg::StageArgs)")
+    c0 = blk.counters()
+    assert c0["launches"] == [0] * 6          # naming launches nothing
+    blk.close()
+
+
+def test_kernel_names_other_families(gpu):
+    from seigen_amd.backend import HipBlock
+    blk = HipBlock(2, 2, (32, 32, 1), [0.1, 0.1, 1.0], [0.0] * 3, "left")
+    blk.set_params(1.0, 0.01, 0.5, 0.25)
+    assert blk.stage_kernel_name(0).startswith("sg::tile2d_stage<2, 0, 0,")
+    assert blk.stage_kernel_name(5).startswith("sg::tile2d_stage<2, 1, 1,")
+    blk.close()
+    blk = HipBlock(3, 3, (4, 4, 4), [0.25] * 3, [0.0] * 3, "quadrilateral")
+    blk.set_params(1.0, 0.01, 0.5, 0.25)
+    assert "stage_kernel<3, 3" in blk.stage_kernel_name(0) or "hex" in blk.stage_kernel_name(0)
+    blk.close()
