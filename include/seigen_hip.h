@@ -253,6 +253,20 @@ typedef struct sg_comm_stats {
 } sg_comm_stats_t;
 int sg_comm_get_unique_id(void* id, size_t nbytes);
 int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nranks, const int32_t* peers);
+/* RCCL is bound at run time, on first use: the copy already in the process (torch brings its own) or the system's
+ * librccl.so; SG_ERR_STATE where there is none (single blocks and the device-free entry points do not need it).
+ * sg_comm_version: its version as RCCL encodes it (e.g. 22606). */
+int sg_comm_version(int* version);
+/* Everything sg_comm_init can refuse WITHOUT another rank (RCCL present, rank / nranks, peers[] against
+ * sg_config::nbr_mask; two sides may share a peer only as the two ends of one axis).  Hosts call it on every rank and
+ * agree on the result BEFORE the collective sg_comm_init: a rank that failed alone would leave the others waiting. */
+int sg_comm_check(sg_handle* h, int rank, int nranks, const int32_t* peers);
+/* Collective self-test of the exchange, after sg_comm_init: every rank sends a pattern naming (rank, side, position)
+ * from each send buffer and counts the values that did not arrive from the FACING side of the right neighbour
+ * (0 = every side receives its neighbour's trace; the role of a halo-exchange consistency check before a run).
+ * Receives are posted in the order of the facing sides, so two faces between the same pair of ranks - a block that is
+ * its own neighbour across an axis - are paired correctly, not mirrored. */
+int sg_comm_selftest(sg_handle* h, int64_t* mismatches);
 int sg_comm_finalize(sg_handle* h);
 int sg_comm_get_stats(sg_handle* h, sg_comm_stats_t* out, int reset);
 /* one exchange of `field`'s traces on its own (tests), and the device addresses of a side's buffers */

@@ -86,7 +86,8 @@ class SoExtra(C.Structure):
 
 class CPort(object):
     def __init__(self, mesh, P):
-        self.lib = C.CDLL(build())
+        # SEIGEN_ORACLE_LIB: another build of the same source (the sanitizer build of oracle/c/Makefile `asan`)
+        self.lib = C.CDLL(os.environ.get("SEIGEN_ORACLE_LIB") or build())
         self.lib.so_max_threads.restype = C.c_int
         self.mesh, self.P = mesh, P
         d = self.dim = mesh.dim

@@ -74,6 +74,9 @@ SYMBOLS = {
     "sg_halo_attach": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sg_comm_get_unique_id": (C.c_int, [_P, C.c_size_t]),
     "sg_comm_init": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "sg_comm_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "sg_comm_check": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "sg_comm_selftest": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sg_comm_finalize": (C.c_int, [_P]),
     "sg_comm_get_stats": (C.c_int, [_P, C.POINTER(SgCommStats), C.c_int]),
     "sg_comm_exchange": (C.c_int, [_P, C.c_int]),

@@ -247,9 +247,22 @@ class HipBlock(object):
     # ---- native exchange over RCCL (csrc/comm.cpp): step() then runs the whole pipelined schedule in the library
     def comm_init(self, unique_id, rank, nranks, peers):
         """peers: rank of the face neighbour per block side (2 * axis + hi), -1 / None where there is none."""
-        arr = (C.c_int32 * 6)(*[(-1 if (i >= len(peers) or peers[i] is None) else int(peers[i])) for i in range(6)])
         buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
-        _lib.check(self.lib.sg_comm_init(self.h, buf, _lib.COMM_ID_BYTES, int(rank), int(nranks), arr), self.h)
+        _lib.check(self.lib.sg_comm_init(self.h, buf, _lib.COMM_ID_BYTES, int(rank), int(nranks), self._peer_array(peers)), self.h)
+
+    def _peer_array(self, peers):
+        return (C.c_int32 * 6)(*[(-1 if (i >= len(peers) or peers[i] is None) else int(peers[i])) for i in range(6)])
+
+    def comm_check(self, rank, nranks, peers):
+        """what sg_comm_init would refuse without talking to another rank (raises); call on every rank and agree on the
+        outcome before the collective comm_init"""
+        _lib.check(self.lib.sg_comm_check(self.h, int(rank), int(nranks), self._peer_array(peers)), self.h)
+
+    def comm_selftest(self):
+        """collective: pattern exchange; number of values that did not arrive from the facing side of the right neighbour"""
+        bad = C.c_int64()
+        _lib.check(self.lib.sg_comm_selftest(self.h, C.byref(bad)), self.h)
+        return int(bad.value)
 
     def comm_finalize(self):
         _lib.check(self.lib.sg_comm_finalize(self.h), self.h)

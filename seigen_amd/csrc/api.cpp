@@ -3,57 +3,6 @@
 // the fused six-launch LF4 step (seigen/elastic.py:283-313) and halo packs: stages.cpp.
 #include "handle.hpp"
 
-std::string g_create_err;
-
-// Which kernel family runs a block (and with it the layout's group width gw: 16 cubes per 128-byte line for the
-// MFMA and tile kernels, 64 for the lane kernels, 1 = host layout for the generic kernel).
-KernelPath choose_kernel_path(const sg_config& cfg) {
-  KernelPath kp;
-  if (cfg.diagonal == SG_DIAGONAL_QUAD) {
-    // quadrilateral cells: the MFMA tile kernels (DQ_4: two 16-row tiles), or on request the table-driven generic
-    // kernels (host layout); same size threshold and SEIGEN_HIP_PATH overrides as for triangles
-    const char* pe = std::getenv("SEIGEN_HIP_PATH");
-    const bool fg = pe && std::strcmp(pe, "generic") == 0, ft = pe && std::strcmp(pe, "tile") == 0;
-    kp.tile = cfg.dim == 2 && tile2d_supported_quad(cfg.degree) && !fg &&
-              (ft || (int64_t)cfg.n[0] * cfg.n[1] >= SG_TILE2D_MIN_CELLS / 2);
-    // hexahedra (DQ_1, DQ_2): the sum-factorised lane-per-cell kernels (kernels_lane.hip hex_stage) from
-    // SG_HEX_LANE_MIN_CELLS(degree) cubes up (below that the thread-per-node generic kernel has more parallelism);
-    // SEIGEN_HIP_PATH=lane / generic forces one or the other
-    const bool fl = pe && std::strcmp(pe, "lane") == 0;
-    kp.lane = cfg.dim == 3 && lane_supported_hex(cfg.dim, cfg.degree) && !fg &&
-              (fl || (int64_t)cfg.n[0] * cfg.n[1] * cfg.n[2] >= SG_HEX_LANE_MIN_CELLS(cfg.degree));
-    kp.gw = kp.tile ? 16 : (kp.lane ? 64 : 1);
-    return kp;
-  }
-  const int ncls = cfg.dim == 1 ? 1 : (cfg.dim == 2 ? 2 : 6);
-  // kernel path: MFMA kernels (interleaved layout) where they exist, unless SEIGEN_HIP_PATH=generic
-  const char* path_env = std::getenv("SEIGEN_HIP_PATH");
-  const bool force_generic = path_env && std::strcmp(path_env, "generic") == 0;
-  // 3-D: the MFMA kernels at every degree (degrees 1 and 2 use 4x4x4 tiles only); measured with
-  // tools/path_sweep.py they beat the lane and generic kernels everywhere except degree 1 on blocks
-  // under 65536 cells (SEIGEN_HIP_PATH=mfma forces them)
-  const bool force_mfma = path_env && std::strcmp(path_env, "mfma") == 0;
-  const int64_t ncube_all = (int64_t)cfg.n[0] * (cfg.dim > 1 ? cfg.n[1] : 1) * (cfg.dim > 2 ? cfg.n[2] : 1);
-  const int64_t ncells_all = ncube_all * ncls;
-  kp.mfma = mfma_supported(cfg.dim, cfg.degree) && !force_generic &&
-            !(path_env && std::strcmp(path_env, "lane") == 0) &&
-            (cfg.degree >= 2 || ncells_all >= 65536 || force_mfma);
-  // lane-per-cell kernels need enough 64-cell groups to fill the chip; below that the
-  // thread-per-node generic kernel has more parallelism (SEIGEN_HIP_PATH=lane forces them)
-  const bool force_lane = path_env && std::strcmp(path_env, "lane") == 0;
-  kp.lane = !kp.mfma && lane_supported(cfg.dim, cfg.degree) && !force_generic &&
-            (force_lane || ncells_all >= (cfg.degree == 1 ? 196608 : 120000));  // crossovers measured
-                                                                 // (tools/path_sweep.py, profiles/r02/small_2d_configs_negative_results.txt)
-  // 2-D: the MFMA tile kernels (16 cells per wave, operators in registers) from SG_TILE2D_MIN_CELLS cells up
-  // (measured crossover against the generic kernel, tools/path_sweep.py); SEIGEN_HIP_PATH=tile forces them
-  const bool force_tile = path_env && std::strcmp(path_env, "tile") == 0;
-  kp.tile = tile2d_supported(cfg.dim, cfg.degree) && !force_generic && !force_lane &&
-            (force_tile || ncells_all >= SG_TILE2D_MIN_CELLS);
-  if (kp.tile) kp.lane = false;
-  kp.gw = (kp.mfma || kp.tile) ? 16 : (kp.lane ? 64 : 1);
-  return kp;
-}
-
 extern "C" {
 
 const char* sg_last_error(const sg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -460,67 +409,6 @@ int sg_sync(sg_handle* h) {
   return SG_OK;
 }
 
-// Node coordinates of a block: the affine image of the reference lattice under every cell's vertex map (one
-// arithmetic, shared by sg_block_node_coords and the source box test of sg_set_source_box_ricker).
-struct NodeGeom {
-  int d = 0, degree = 0, nq = 0, ncls = 0;
-  std::vector<int> lat;
-  int off[MAX_CLS][4][3];
-  const sg_config* cfg = nullptr;
-  bool init(const sg_config* c, int deg) {
-    cfg = c;
-    d = c->dim;
-    degree = deg;
-    const bool quad = c->diagonal == SG_DIAGONAL_QUAD;
-    if (quad && d != 2 && d != 3) return false;
-    const int kind = quad ? KIND_TENSOR : KIND_SIMPLEX;
-    lattice_points(d, degree, lat, kind);
-    nq = num_nodes(d, degree, kind);
-    if (quad) {   // vertex 0 the low corner, vertex 1 / 2 / 3 one cell along x / y / z: the affine map of the unit square / cube
-      std::memset(off, 0, sizeof(off));
-      ncls = 1;
-      for (int m = 0; m < d; ++m) off[0][m + 1][m] = 1;
-    } else {
-      class_vertices(d, c->diagonal, ncls, off);
-    }
-    return true;
-  }
-  // coordinates of node a of the cell of class k in cube c
-  void node(const int c[3], int k, int a, double x[3]) const {
-    double X[4][3];
-    for (int v = 0; v <= d; ++v)
-      for (int i = 0; i < d; ++i) X[v][i] = cfg->origin[i] + (double)(cfg->cube0[i] + c[i] + off[k][v][i]) * cfg->h[i];
-    for (int i = 0; i < d; ++i) {
-      double xv = X[0][i];
-      for (int m = 0; m < d; ++m) xv += (X[m + 1][i] - X[0][i]) * ((double)lat[a * d + m] / (double)degree);
-      x[i] = xv;
-    }
-  }
-};
-
-int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t nbytes) {
-  if (!cfg || !out || degree < 1 || degree > 8 || cfg->dim < 1 || cfg->dim > 3) return SG_ERR_ARG;
-  NodeGeom G;
-  if (!G.init(cfg, degree)) return SG_ERR_ARG;
-  const int d = G.d;
-  int n[3] = {1, 1, 1};
-  for (int a = 0; a < d; ++a) n[a] = cfg->n[a];
-  if (nbytes != (size_t)n[0] * n[1] * n[2] * G.ncls * G.nq * d * sizeof(double)) return SG_ERR_ARG;
-  size_t o = 0;
-  for (int ck = 0; ck < n[2]; ++ck)
-    for (int cj = 0; cj < n[1]; ++cj)
-      for (int ci = 0; ci < n[0]; ++ci) {
-        const int c[3] = {ci, cj, ck};
-        for (int k = 0; k < G.ncls; ++k)
-          for (int a = 0; a < G.nq; ++a) {
-            double x[3];
-            G.node(c, k, a, x);
-            for (int i = 0; i < d; ++i) out[o++] = x[i];
-          }
-      }
-  return SG_OK;
-}
-
 int sg_node_coords(const sg_handle* h, int degree, double* out, size_t nbytes) {
   if (!h) return SG_ERR_ARG;
   return sg_block_node_coords(&h->cfg, degree, out, nbytes);
@@ -857,80 +745,6 @@ int sg_leave_sym(sg_handle* h) {
 int sg_halo_attach(sg_handle* h, int field, int side, const void* dev_in) {
   if (!h || field < 0 || field > 3 || side < 0 || side >= 2 * h->cfg.dim) return SG_ERR_ARG;
   h->ghost[field][side] = (const double*)dev_in;
-  return SG_OK;
-}
-
-int64_t sg_reference_operator(int dim, int degree, int which, int q, double* out, size_t nbytes) {
-  return sg_reference_operator_cell(0, dim, degree, which, q, out, nbytes);
-}
-
-int64_t sg_reference_operator_cell(int cell_type, int dim, int degree, int which, int q, double* out, size_t nbytes) {
-  std::vector<double> v;
-  if (cell_type != KIND_SIMPLEX && cell_type != KIND_TENSOR) return SG_ERR_ARG;
-  try {
-    if (which == 3) {
-      if (q < 1 || q > 6 || dim < 1 || dim > 3 || degree < 1 || degree > 4) return SG_ERR_ARG;
-      v = sponge_tensor(dim, degree, q, cell_type);
-    } else {
-      RefElem re = make_refelem(dim, degree, cell_type);
-      if (which == 0) v = re.D;
-      else if (which == 1) v = re.L;
-      else if (which == 2) v = re.Mhat;
-      else if (which == 4) v.assign(re.fnode.begin(), re.fnode.end());
-      else return SG_ERR_ARG;
-    }
-  } catch (const std::exception& e) {
-    g_create_err = e.what();
-    return SG_ERR_ARG;
-  }
-  if (out) {
-    if (nbytes != v.size() * sizeof(double)) return SG_ERR_ARG;
-    std::memcpy(out, v.data(), nbytes);
-  }
-  return (int64_t)v.size();
-}
-
-int sg_tabulate(int dim, int degree, int64_t npts, const double* xi, double* phi) {
-  return sg_tabulate_cell(0, dim, degree, npts, xi, phi);
-}
-
-int sg_tabulate_cell(int cell_type, int dim, int degree, int64_t npts, const double* xi, double* phi) {
-  if (dim < 1 || dim > 3 || degree < 1 || degree > 8 || npts < 0 || !xi || !phi) return SG_ERR_ARG;
-  if (cell_type != KIND_SIMPLEX && cell_type != KIND_TENSOR) return SG_ERR_ARG;
-  tabulate(dim, degree, (int)npts, xi, phi, cell_type);
-  return SG_OK;
-}
-
-int sg_mesh_tables(int dim, int degree, int diagonal, const double* h, int32_t* nb, int32_t* nb_node, double* cn,
-                   double* jinv) {
-  if (!h || !nb || !nb_node || !cn || !jinv) return SG_ERR_ARG;
-  try {
-    RefElem re = make_refelem(dim, degree, diagonal == SG_DIAGONAL_QUAD ? KIND_TENSOR : KIND_SIMPLEX);
-    MeshDev md;
-    std::memset(&md, 0, sizeof(md));
-    md.nd = re.nd;
-    md.nf = re.nf;
-    double hh[3] = {1, 1, 1};
-    for (int a = 0; a < dim; ++a) hh[a] = h[a];
-    build_mesh_tables(dim, degree, diagonal, hh, re.fnode.data(), re.lattice.data(), md);
-    for (int c = 0; c < md.ncls; ++c) {
-      for (int f = 0; f < md.nfaces; ++f) {
-        int32_t* o = nb + ((size_t)c * md.nfaces + f) * 5;
-        o[0] = md.nb_axis[c][f];
-        o[1] = md.nb_dir[c][f];
-        o[2] = md.nb_cls[c][f];
-        o[3] = md.nb_face[c][f];
-        o[4] = md.face_ord[c][f];
-        for (int b = 0; b < md.nf; ++b) nb_node[((size_t)c * md.nfaces + f) * md.nf + b] = md.nb_node[c][f][b];
-        for (int j = 0; j < 3; ++j) cn[((size_t)c * md.nfaces + f) * 3 + j] = md.cn[c][f][j];
-      }
-      for (int r = 0; r < 3; ++r)
-        for (int j = 0; j < 3; ++j) jinv[((size_t)c * 3 + r) * 3 + j] = md.Jinv[c][r][j];
-    }
-  } catch (const std::exception& e) {
-    g_create_err = e.what();
-    return SG_ERR_ARG;
-  }
   return SG_OK;
 }
 

@@ -9,9 +9,68 @@
 //     ->  SECOND (other half of the interior) on the second stream, beside the exchange
 // and the next stage's FIRST follows the receives in stream order.  The Python exchanger (seigen_amd/parallel.py)
 // stays for process groups that cannot move device memory (gloo: CPU tests, ranks sharing one GPU).
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound at run time (rccl() below)
 
 #include "handle.hpp"
+
+// RCCL is bound lazily, on the first sg_comm_* call that needs it: libseigen_hip.so loads - and every single-block and
+// device-free entry point works - on a machine without RCCL, and inside a process that has an RCCL already (torch
+// brings its own copy) the calls resolve to THAT copy instead of mixing two versions in one process.  The entry
+// points come from the copy already in the process (RTLD_DEFAULT) or, failing that, from librccl.so of the system.
+namespace {
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  bool ok = false;
+  std::string err;
+};
+
+const RcclApi& rccl() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* lib = RTLD_DEFAULT;
+    if (!dlsym(RTLD_DEFAULT, "ncclCommInitRank")) {
+      lib = nullptr;
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+      }
+      if (!lib) {
+        a.err = "RCCL is not available: librccl.so could not be loaded (multi-GPU runs need it; single blocks do not)";
+        return a;
+      }
+    }
+    bool all = true;
+    auto bind = [&](auto& fn, const char* sym) {
+      fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(lib, sym));
+      if (!fn) {
+        all = false;
+        a.err = std::string("RCCL entry point missing: ") + sym;
+      }
+    };
+    bind(a.GetUniqueId, "ncclGetUniqueId");
+    bind(a.CommInitRank, "ncclCommInitRank");
+    bind(a.CommDestroy, "ncclCommDestroy");
+    bind(a.GetErrorString, "ncclGetErrorString");
+    bind(a.GroupStart, "ncclGroupStart");
+    bind(a.GroupEnd, "ncclGroupEnd");
+    bind(a.Send, "ncclSend");
+    bind(a.Recv, "ncclRecv");
+    bind(a.GetVersion, "ncclGetVersion");
+    a.ok = all;
+    return a;
+  }();
+  return api;
+}
+}  // namespace
 
 struct sg_comm_state {
   ncclComm_t comm = nullptr;
@@ -30,7 +89,7 @@ struct sg_comm_state {
   do {                                                                                           \
     ncclResult_t _r = (expr);                                                                    \
     if (_r != ncclSuccess) {                                                                     \
-      (h)->err = std::string(#expr) + ": " + ncclGetErrorString(_r);                             \
+      (h)->err = std::string(#expr) + ": " + rccl().GetErrorString(_r);                          \
       return SG_ERR_DEVICE;                                                                      \
     }                                                                                            \
   } while (0)
@@ -64,14 +123,18 @@ static int take_event(sg_handle* h, hipEvent_t* e) {
   return SG_OK;
 }
 
-// pack the traces of `field` on every side that has a neighbour and post the sends / receives (main stream)
-static int exchange(sg_handle* h, int field, hipEvent_t* recv_done) {
+// pack the traces of `field` on every side that has a neighbour and post the sends / receives (main stream);
+// pack = false: send what the send buffers hold (sg_comm_selftest)
+static int exchange(sg_handle* h, int field, hipEvent_t* recv_done, bool pack = true) {
   sg_comm_state* c = h->comm;
   const int kind = field_is_stress(field) ? 1 : 0;
-  void* outs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  for (int i = 0; i < c->nsides; ++i) outs[c->sides[i]] = c->send[kind][c->sides[i]];
-  int rc = sg_halo_pack_sides(h, field, outs);
-  if (rc != SG_OK) return rc;
+  int rc = SG_OK;
+  if (pack) {
+    void* outs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < c->nsides; ++i) outs[c->sides[i]] = c->send[kind][c->sides[i]];
+    rc = sg_halo_pack_sides(h, field, outs);
+    if (rc != SG_OK) return rc;
+  }
   const ncclDataType_t ty = h->f32 ? ncclFloat : ncclDouble;
   static const bool dry = std::getenv("SEIGEN_COMM_DRY") != nullptr;   // measurements only: everything but the transport
   if (dry) {
@@ -83,14 +146,24 @@ static int exchange(sg_handle* h, int field, hipEvent_t* recv_done) {
     }
     return SG_OK;
   }
-  NCCLCHECK(h, ncclGroupStart());
-  for (int i = 0; i < c->nsides; ++i) {
-    const int s = c->sides[i];
-    NCCLCHECK(h, ncclSend(c->send[kind][s], c->count[s], ty, c->peers[s], c->comm, h->stream));
-    NCCLCHECK(h, ncclRecv(c->recv[kind][s], c->count[s], ty, c->peers[s], c->comm, h->stream));
+  const RcclApi& nc = rccl();
+  NCCLCHECK(h, nc.GroupStart());
+  // sends in the order of my sides ...
+  for (int s = 0; s < 6; ++s) {
+    if (c->peers[s] < 0) continue;
+    NCCLCHECK(h, nc.Send(c->send[kind][s], c->count[s], ty, c->peers[s], c->comm, h->stream));
     c->stats.bytes_sent += (int64_t)(c->count[s] * (h->f32 ? sizeof(float) : sizeof(double)));
   }
-  NCCLCHECK(h, ncclGroupEnd());
+  // ... receives in the order of the FACING sides: RCCL pairs the sends and receives between two ranks in posting
+  // order, and what belongs on my side s is what the neighbour sent from ITS side s ^ 1.  With one face per pair of
+  // ranks the order is immaterial; with two (a block that is its own neighbour across an axis, two blocks around a
+  // wrapped axis) side s would otherwise receive the peer's side-s trace - the mirror image, silently.
+  for (int t = 0; t < 6; ++t) {
+    const int s = t ^ 1;
+    if (c->peers[s] < 0) continue;
+    NCCLCHECK(h, nc.Recv(c->recv[kind][s], c->count[s], ty, c->peers[s], c->comm, h->stream));
+  }
+  NCCLCHECK(h, nc.GroupEnd());
   c->stats.exchanges += 1;
   if (recv_done) {
     rc = take_event(h, recv_done);
@@ -153,7 +226,7 @@ void comm_release(sg_handle* h) {
     }
   for (hipEvent_t e : c->wait_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
   for (int f = 0; f < 4; ++f)
     for (int s = 0; s < 6; ++s) h->ghost[f][s] = nullptr;
   delete c;
@@ -165,15 +238,31 @@ extern "C" {
 int sg_comm_get_unique_id(void* id, size_t nbytes) {
   if (!id || nbytes != SG_COMM_ID_BYTES) return SG_ERR_ARG;
   static_assert(SG_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "seigen_hip.h and rccl.h disagree on the size of a unique id");
+  if (!rccl().ok) {
+    g_create_err = rccl().err;
+    return SG_ERR_STATE;
+  }
   ncclUniqueId u;
-  if (ncclGetUniqueId(&u) != ncclSuccess) return SG_ERR_DEVICE;
+  if (rccl().GetUniqueId(&u) != ncclSuccess) return SG_ERR_DEVICE;
   std::memcpy(id, u.internal, SG_COMM_ID_BYTES);
   return SG_OK;
 }
 
-int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nranks, const int32_t* peers) {
-  if (!h || !id || !peers || nbytes != SG_COMM_ID_BYTES || nranks < 1 || rank < 0 || rank >= nranks) return SG_ERR_ARG;
+int sg_comm_version(int* version) {
+  if (!version) return SG_ERR_ARG;
+  if (!rccl().ok) {
+    g_create_err = rccl().err;
+    return SG_ERR_STATE;
+  }
+  return rccl().GetVersion(version) == ncclSuccess ? SG_OK : SG_ERR_DEVICE;
+}
+
+// everything sg_comm_init can refuse WITHOUT talking to another rank: the host calls it on every rank and agrees on
+// the outcome before the collective ncclCommInitRank (a rank that failed here alone would leave the others waiting)
+int sg_comm_check(sg_handle* h, int rank, int nranks, const int32_t* peers) {
+  if (!h || !peers || nranks < 1 || rank < 0 || rank >= nranks) return SG_ERR_ARG;
   if (h->comm) return fail(h, SG_ERR_STATE, "sg_comm_init: the handle already has a communicator");
+  if (!rccl().ok) return fail(h, SG_ERR_STATE, rccl().err);
   const int d = h->cfg.dim;
   for (int s = 0; s < 6; ++s) {
     const bool nbr = s < 2 * d && h->md.has_nbr[s];
@@ -181,6 +270,20 @@ int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nran
     if (nbr != (p >= 0) || p >= nranks)
       return fail(h, SG_ERR_ARG, "sg_comm_init: peers[] must name a rank for exactly the sides of sg_config::nbr_mask");
   }
+  // Two sides may lead to the same rank only as the two ends of ONE axis (a wrapped axis one or two blocks wide): the
+  // exchange pairs such sends and receives by facing side (exchange()).  Anything else - one rank behind two different
+  // axes - has no layout of blocks behind it.
+  for (int s = 0; s < 2 * d; ++s)
+    for (int t = s + 1; t < 2 * d; ++t)
+      if (peers[s] >= 0 && peers[s] == peers[t] && (s >> 1) != (t >> 1))
+        return fail(h, SG_ERR_ARG, "sg_comm_init: one rank named as the neighbour across two different axes");
+  return SG_OK;
+}
+
+int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nranks, const int32_t* peers) {
+  if (!h || !id || !peers || nbytes != SG_COMM_ID_BYTES || nranks < 1 || rank < 0 || rank >= nranks) return SG_ERR_ARG;
+  if (int rc = sg_comm_check(h, rank, nranks, peers)) return rc;
+  const int d = h->cfg.dim;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   sg_comm_state* c = new sg_comm_state();
   std::memset(c->send, 0, sizeof(c->send));
@@ -191,11 +294,11 @@ int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nran
   c->nranks = nranks;
   ncclUniqueId u;
   std::memcpy(u.internal, id, SG_COMM_ID_BYTES);
-  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+  ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
   if (r != ncclSuccess) {
     c->comm = nullptr;
     comm_release(h);
-    return fail(h, SG_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    return fail(h, SG_ERR_DEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
   }
   const size_t es = h->f32 ? sizeof(float) : sizeof(double);
   for (int s = 0; s < 2 * d; ++s) {
@@ -244,6 +347,61 @@ int sg_comm_exchange(sg_handle* h, int field) {
   if (!h->comm) return fail(h, SG_ERR_STATE, "no communicator (sg_comm_init)");
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   return exchange(h, field, nullptr);
+}
+
+// Does every side receive what the facing side of its neighbour sent?  Every rank fills its send buffers with a pattern
+// that names (rank, side, kind, position), all exchange WITHOUT packing, and every rank checks what arrived on side s
+// against the pattern of (peers[s], s ^ 1) - known locally, so no second transport is needed as a reference.  A crossed,
+// mis-ordered or mis-addressed exchange shows up as mismatches (collective: every rank of the communicator calls it).
+static double selftest_value(int rank, int side, int kind, size_t i, bool f32) {
+  const long tag = ((long)rank * 8 + side) * 2 + kind;
+  return f32 ? (double)((tag % 4096) * 4096 + (long)(i % 4096)) : (double)(tag * 4294967296.0 + (double)(i % 4294967296ull));
+}
+
+int sg_comm_selftest(sg_handle* h, int64_t* mismatches) {
+  if (!h || !mismatches) return SG_ERR_ARG;
+  if (!h->comm) return fail(h, SG_ERR_STATE, "no communicator (sg_comm_init)");
+  sg_comm_state* c = h->comm;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (int rc = join_second(h)) return rc;
+  const size_t es = h->f32 ? sizeof(float) : sizeof(double);
+  *mismatches = 0;
+  const sg_comm_stats_t keep = c->stats;      // not part of the run's statistics
+  std::vector<double> hd;
+  std::vector<float> hf;
+  for (int kind = 0; kind < 2; ++kind) {
+    for (int s = 0; s < 6; ++s) {
+      if (c->peers[s] < 0) continue;
+      const size_t n = c->count[s];
+      hd.resize(n);
+      hf.resize(n);
+      for (size_t i = 0; i < n; ++i) {
+        hd[i] = selftest_value(c->rank, s, kind, i, h->f32 != 0);
+        hf[i] = (float)hd[i];
+      }
+      HIPCHECK(h, hipMemcpy(c->send[kind][s], h->f32 ? (const void*)hf.data() : (const void*)hd.data(), n * es, hipMemcpyHostToDevice));
+      HIPCHECK(h, hipMemset(c->recv[kind][s], 0xff, n * es));
+    }
+    int rc = exchange(h, kind ? SG_FIELD_S : SG_FIELD_U, nullptr, false);
+    if (rc != SG_OK) return rc;
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int s = 0; s < 6; ++s) {
+      if (c->peers[s] < 0) continue;
+      const size_t n = c->count[s];
+      hd.resize(n);
+      hf.resize(n);
+      HIPCHECK(h, hipMemcpy(h->f32 ? (void*)hf.data() : (void*)hd.data(), c->recv[kind][s], n * es, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) {
+        const double want = selftest_value(c->peers[s], s ^ 1, kind, i, h->f32 != 0);
+        const double got = h->f32 ? (double)hf[i] : hd[i];
+        if (!(got == want)) *mismatches += 1;
+      }
+      HIPCHECK(h, hipMemset(c->send[kind][s], 0, n * es));
+      HIPCHECK(h, hipMemset(c->recv[kind][s], 0, n * es));
+    }
+  }
+  c->stats = keep;
+  return SG_OK;
 }
 
 // DEVICE addresses of the send / receive buffer of a side (tests: what arrived); kind 0 = velocity-like, 1 = stress-like

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/seigen_hip.h"
+#include "hostlogic.hpp"
 #include "kernels.hpp"
 #include "mesh_tables.hpp"
 #include "mfma_tables.hpp"
@@ -133,11 +134,6 @@ struct sg_handle {
   std::string err;
 };
 
-// smallest 2-D block (cells) that takes the MFMA tile kernels instead of the generic kernel: they win at every
-// size measured, 40 x 40 squares included (tools/path_sweep2d.py, profiles/r02/path_sweep2d_tile_v2.txt)
-static constexpr int64_t SG_TILE2D_MIN_CELLS = 0;
-
-extern std::string g_create_err;   // message of the last failed sg_create (api.cpp)
 static_assert(SG_MAX_BOXES == SG_MAX_REGION_BOXES, "kernels.hpp and seigen_hip.h disagree on the box limit");
 
 #define HIPCHECK(h, expr)                                                                        \
@@ -178,28 +174,7 @@ inline hipError_t sync_all(sg_handle* h) {
 // transfer.cpp: make the (i > j) lines of both stress buffers valid again and continue with the full-tensor kernels
 int leave_sym_mode(sg_handle* h);
 
-// stages.cpp
-struct Box {
-  int o[3], n[3];
-};
-struct KernelPath {
-  bool mfma = false, lane = false, tile = false;
-  int gw = 1;
-};
-KernelPath choose_kernel_path(const sg_config& cfg);
-// shell thickness along x: the interleaved layouts put gw consecutive cubes of an x-row on the lanes of one item, so a
-// one-cube shell next to an x side would use one lane in gw of every item it touches AND make the launch that owns the
-// other gw - 1 lanes run the same item again.  With whole groups in the shell no item is cut (2 x 2 x 2).
-// ... unless that would leave the launch that runs beside the exchange less than half of the block's rows to work on
-// (a block with neighbours on both x sides and n[0] <= 2 gw had an EMPTY interior: nothing overlapped the exchange), or
-// the layout is the lane kernels' (64 cubes per item: the shell would swallow blocks up to 128 cubes wide).  Then the
-// shell is one cube thick again and the kernels mask the lanes of the groups it cuts (region_whole = false).
-inline int shell_width_x(int gw, int n0, bool nbr_lo, bool nbr_hi) {
-  if (gw <= 1 || gw >= 64) return 1;
-  const int sides = (nbr_lo ? 1 : 0) + (nbr_hi ? 1 : 0);
-  return 2 * (n0 - sides * gw) >= n0 ? gw : 1;
-}
-void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out, int xw);
+// hostapi.cpp (hostlogic.hpp): kernel-family choice and the regions of a split stage
 inline void region_boxes(const sg_handle* h, int region, std::vector<Box>& out) {
   region_boxes(h->cfg.dim, h->cfg.n, h->md.has_nbr, region, out,
                shell_width_x(h->md.gw, h->cfg.n[0], h->md.has_nbr[0] != 0, h->md.has_nbr[1] != 0));

@@ -776,12 +776,6 @@ static int launch_lane_d(int kind, int P, const StageArgs& a, long nitems, hipSt
   return -1;
 }
 
-// 3-D: only P1/P2 fit a lane's registers (P3/P4 take the MFMA path)
-bool lane_supported(int dim, int P) { return ((dim == 1 || dim == 2) && P >= 1 && P <= 4) || (dim == 3 && (P == 1 || P == 2)); }
-
-// hexahedra: DQ_1 and DQ_2 (27 nodes) fit a lane's registers one component at a time
-bool lane_supported_hex(int dim, int P) { return dim == 3 && (P == 1 || P == 2); }
-
 int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.tensor) {

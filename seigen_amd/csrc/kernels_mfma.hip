@@ -1229,8 +1229,6 @@ static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
   return a.sym ? launch_ps<R, P, 1>(kind, a, s) : launch_ps<R, P, 0>(kind, a, s);
 }
 
-bool mfma_supported(int dim, int P) { return dim == 3 && P >= 1 && P <= 4; }
-
 // resident blocks per CU the persistent grid is sized for: registers and LDS allow exactly two at
 // degrees 3 and 4 (a third block at degree 3 measured slower); the low orders are memory-bound and
 // light (64 / 166 VGPRs, 12 / 28 KB of tiles) and want more waves in flight

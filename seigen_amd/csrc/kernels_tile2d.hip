@@ -498,50 +498,6 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   }
 }
 
-// kernarg copy of what the kernels need from the mesh tables
-T2Const tile2d_const(const MeshDev& md) {
-  T2Const C;
-  C.n0 = md.n[0];
-  C.n1 = md.n[1];
-  C.ncube = (int32_t)md.ncube;
-  C.ngroups = (int32_t)(md.ncube_pad / 16);
-  C.halo_per_cube = md.halo_per_cube;
-  C.gpr = (md.n[0] + 15) / 16 + 1;
-  C.inv_n0 = 1.0 / (double)md.n[0];
-  for (int s = 0; s < 4; ++s) C.has_nbr[s] = md.has_nbr[s];
-  const int ksf = (md.nf + 3) / 4;
-  auto pack = [&](auto entry, int ks) {
-    uint32_t wd = 0;
-    for (int qq = 0; qq < 4; ++qq) {
-      const int bb = (4 * ks + qq < md.nf) ? 4 * ks + qq : 0;  // padded rows meet zero lift columns
-      wd |= (uint32_t)entry(bb) << (8 * qq);
-    }
-    return wd;
-  };
-  std::memset(C.tpw, 0, sizeof(C.tpw));
-  std::memset(C.cls, 0, sizeof(C.cls));
-  for (int f = 0; f < md.nfaces; ++f) {
-    for (int ks = 0; ks < 2; ++ks) C.tpw[f][ks] = ks < ksf ? pack([&](int bb) { return md.fnode[f][bb]; }, ks) : 0u;
-    for (int k = 0; k < md.ncls; ++k) {
-      T2Class& K = C.cls[k];
-      K.nb_axis[f] = md.nb_axis[k][f];
-      K.nb_dir[f] = md.nb_dir[k][f];
-      K.nb_cls[f] = md.nb_cls[k][f];
-      const int ord = md.face_ord[md.nb_cls[k][f]][md.nb_face[k][f]];
-      K.slot_ord[f] = ord < 0 ? 0 : ord;
-      for (int ks = 0; ks < 2; ++ks) {
-        K.tfw[f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_node[k][f][bb]; }, ks) : 0u;
-        K.tgw[f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_fnode[k][f][bb]; }, ks) : 0u;
-      }
-      for (int j = 0; j < 2; ++j) K.cn[f][j] = md.cn[k][f][j];
-    }
-  }
-  for (int k = 0; k < md.ncls; ++k)
-    for (int r = 0; r < 2; ++r)
-      for (int j = 0; j < 2; ++j) C.cls[k].Jinv[r][j] = md.Jinv[k][r][j];
-  return C;
-}
-
 template <int P, int SYM, int GHOST, int TP = 0, typename R = double>
 static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
   long blocks = (nitems + 3) / 4;
@@ -574,9 +530,6 @@ template <int P, int TP = 0>
 static int launch_t2p(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
   return a.f32 ? launch_t2r<P, TP, float>(kind, a, c, nitems, s) : launch_t2r<P, TP, double>(kind, a, c, nitems, s);
 }
-
-bool tile2d_supported(int dim, int P) { return dim == 2 && P >= 1 && P <= 4; }
-bool tile2d_supported_quad(int P) { return P >= 1 && P <= 4; }   // DQ_4 has 25 rows: two row tiles, one after the other
 
 int launch_stage_tile2d(int kind, int P, const StageArgs& a, const T2Const& c, long nitems, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -343,6 +343,50 @@ MfmaConst mfma_const(const MeshDev& md) {
 }
 
 
+// 2-D tile kernels (kernels_tile2d.hip): kernarg copy of what they need from the mesh tables
+T2Const tile2d_const(const MeshDev& md) {
+  T2Const C;
+  C.n0 = md.n[0];
+  C.n1 = md.n[1];
+  C.ncube = (int32_t)md.ncube;
+  C.ngroups = (int32_t)(md.ncube_pad / 16);
+  C.halo_per_cube = md.halo_per_cube;
+  C.gpr = (md.n[0] + 15) / 16 + 1;
+  C.inv_n0 = 1.0 / (double)md.n[0];
+  for (int s = 0; s < 4; ++s) C.has_nbr[s] = md.has_nbr[s];
+  const int ksf = (md.nf + 3) / 4;
+  auto pack = [&](auto entry, int ks) {
+    uint32_t wd = 0;
+    for (int qq = 0; qq < 4; ++qq) {
+      const int bb = (4 * ks + qq < md.nf) ? 4 * ks + qq : 0;  // padded rows meet zero lift columns
+      wd |= (uint32_t)entry(bb) << (8 * qq);
+    }
+    return wd;
+  };
+  std::memset(C.tpw, 0, sizeof(C.tpw));
+  std::memset(C.cls, 0, sizeof(C.cls));
+  for (int f = 0; f < md.nfaces; ++f) {
+    for (int ks = 0; ks < 2; ++ks) C.tpw[f][ks] = ks < ksf ? pack([&](int bb) { return md.fnode[f][bb]; }, ks) : 0u;
+    for (int k = 0; k < md.ncls; ++k) {
+      T2Class& K = C.cls[k];
+      K.nb_axis[f] = md.nb_axis[k][f];
+      K.nb_dir[f] = md.nb_dir[k][f];
+      K.nb_cls[f] = md.nb_cls[k][f];
+      const int ord = md.face_ord[md.nb_cls[k][f]][md.nb_face[k][f]];
+      K.slot_ord[f] = ord < 0 ? 0 : ord;
+      for (int ks = 0; ks < 2; ++ks) {
+        K.tfw[f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_node[k][f][bb]; }, ks) : 0u;
+        K.tgw[f][ks] = ks < ksf ? pack([&](int bb) { return md.nb_fnode[k][f][bb]; }, ks) : 0u;
+      }
+      for (int j = 0; j < 2; ++j) K.cn[f][j] = md.cn[k][f][j];
+    }
+  }
+  for (int k = 0; k < md.ncls; ++k)
+    for (int r = 0; r < 2; ++r)
+      for (int j = 0; j < 2; ++j) C.cls[k].Jinv[r][j] = md.Jinv[k][r][j];
+  return C;
+}
+
 void mfma_trace_offsets(const MeshDev& md, int ncomp, std::vector<int32_t>& tab) {
   tab.assign((size_t)3 * 6 * 4 * 4 * 4, 0);
   const int nf = md.nf;

@@ -4,68 +4,6 @@
 
 // ---- stage launches --------------------------------------------------------------------
 
-void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int region, std::vector<Box>& out, int xw) {
-  out.clear();
-  int lo[3] = {0, 0, 0}, hi[3];
-  for (int a = 0; a < 3; ++a) hi[a] = n[a];
-  if (region == SG_REGION_ALL) {
-    out.push_back(Box{{0, 0, 0}, {hi[0], hi[1], hi[2]}});
-    return;
-  }
-  // interior: peel one cube (along x: one layout group of xw cubes, handle.hpp shell_width_x) off every side
-  // that has a neighbour block
-  int ilo[3] = {0, 0, 0}, ihi[3] = {hi[0], hi[1], hi[2]};
-  for (int a = 0; a < d; ++a) {
-    const int w = (a == 0 && xw > 1) ? xw : 1;
-    if (has_nbr[2 * a]) ilo[a] = w < hi[a] ? w : hi[a];
-    if (has_nbr[2 * a + 1]) ihi[a] = hi[a] - w > 0 ? hi[a] - w : 0;
-    if (ihi[a] < ilo[a]) ihi[a] = ilo[a];
-  }
-  if (region == SG_REGION_INTERIOR) {
-    out.push_back(Box{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}});
-    return;
-  }
-  // FIRST / SECOND: the interior cut in two along the slowest axis (whole runs of the layout)
-  const int ax = d - 1, mid = ilo[ax] + (ihi[ax] - ilo[ax]) / 2;
-  if (region == SG_REGION_SECOND) {
-    Box b{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}};
-    b.o[ax] = mid;
-    b.n[ax] = ihi[ax] - mid;
-    out.push_back(b);
-    return;
-  }
-  if (region == SG_REGION_FIRST) {
-    Box b{{ilo[0], ilo[1], ilo[2]}, {ihi[0] - ilo[0], ihi[1] - ilo[1], ihi[2] - ilo[2]}};
-    b.n[ax] = mid - ilo[ax];
-    out.push_back(b);
-  }
-  // boundary shell = all \ interior, as disjoint slabs: peel axis by axis
-  int clo[3] = {lo[0], lo[1], lo[2]}, chi[3] = {hi[0], hi[1], hi[2]};
-  for (int a = 0; a < d; ++a) {
-    if (ilo[a] > clo[a]) {
-      Box b;
-      for (int k = 0; k < 3; ++k) {
-        b.o[k] = clo[k];
-        b.n[k] = chi[k] - clo[k];
-      }
-      b.n[a] = ilo[a] - clo[a];
-      out.push_back(b);
-      clo[a] = ilo[a];
-    }
-    if (ihi[a] < chi[a] && ihi[a] >= clo[a]) {
-      Box b;
-      for (int k = 0; k < 3; ++k) {
-        b.o[k] = clo[k];
-        b.n[k] = chi[k] - clo[k];
-      }
-      b.o[a] = ihi[a];
-      b.n[a] = chi[a] - ihi[a];
-      out.push_back(b);
-      chi[a] = ihi[a];
-    }
-  }
-}
-
 static bool source_active(const sg_handle* h) {
   return h->src_nnz != 0 && (h->src_static || h->src_step < h->src_nsteps);
 }
@@ -619,26 +557,6 @@ int sg_stage_kernel_name(sg_handle* h, int stage, int region, char* buf, size_t 
   if (rc != SG_OK) return rc;
   std::snprintf(buf, n, "%s", name.c_str());
   return SG_OK;
-}
-
-int sg_region_boxes(const sg_config* cfg, int region, int32_t* boxes, int max_boxes) {
-  if (!cfg || !boxes || cfg->dim < 1 || cfg->dim > 3 || region < 0 || region > 4 || max_boxes < 0) return SG_ERR_ARG;
-  int32_t n[3] = {1, 1, 1}, has_nbr[6] = {0, 0, 0, 0, 0, 0};
-  for (int a = 0; a < cfg->dim; ++a) n[a] = cfg->n[a];
-  for (int s2 = 0; s2 < 2 * cfg->dim; ++s2) has_nbr[s2] = (cfg->nbr_mask >> s2) & 1;
-  std::vector<Box> out;
-  region_boxes(cfg->dim, n, has_nbr, region, out, shell_width_x(choose_kernel_path(*cfg).gw, n[0], has_nbr[0] != 0, has_nbr[1] != 0));
-  int cnt = 0;
-  for (const Box& b : out) {
-    if (b.n[0] <= 0 || b.n[1] <= 0 || b.n[2] <= 0) continue;
-    if (cnt < max_boxes)
-      for (int k = 0; k < 3; ++k) {
-        boxes[6 * cnt + k] = b.o[k];
-        boxes[6 * cnt + 3 + k] = b.n[k];
-      }
-    cnt += 1;
-  }
-  return cnt;
 }
 
 }  // extern "C"

@@ -69,15 +69,64 @@ class NativeExchanger(object):
     native = True
 
     def __init__(self, block, partition, group=None):
+        """Collective over `group`.  The ranks agree on the outcome of every phase BEFORE the next collective starts, so
+        that a failure on one rank (no RCCL, a bad argument, a communicator that did not come up, an exchange that
+        delivers the wrong traces) raises on ALL ranks - which then fall back together (ElasticLF4.setup) - instead of
+        leaving the others waiting inside a broadcast or ncclCommInitRank."""
         import torch
         import torch.distributed as dist
         from .backend import comm_unique_id
         self.block, self.part = block, partition
         self.sides = [s for s in range(2 * partition.dim) if partition.neighbour(s) is not None]
         rank, nranks = dist.get_rank(group), dist.get_world_size(group)
-        box = [comm_unique_id() if rank == 0 else None]
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+        def agree(failed, what):
+            t = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=group)
+            if t.item() > 0:
+                raise RuntimeError("native halo exchange: %s failed on %d rank(s)%s" % (what, int(t.item()), (": %s" % failed) if failed else ""))
+
+        peers = [partition.neighbour(s) for s in range(2 * partition.dim)]
+        # phase 1: what can be refused locally (RCCL present, peers against the block's neighbour mask)
+        err = None
+        try:
+            block.comm_check(rank, nranks, peers)
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        agree(err, "the argument check")
+        # phase 2: the unique id - made by rank 0, travelling together with its error, if any
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = (comm_unique_id(), None)
+            except Exception as e:      # noqa: BLE001
+                box[0] = (None, repr(e))
         dist.broadcast_object_list(box, src=0, group=group)
-        block.comm_init(box[0], rank, nranks, [partition.neighbour(s) for s in range(2 * partition.dim)])
+        uid, err = box[0]
+        if uid is None:
+            raise RuntimeError("native halo exchange: rank 0 could not make an RCCL unique id: %s" % err)
+        # phase 3: the communicator (collective inside the library)
+        err = None
+        try:
+            block.comm_init(uid, rank, nranks, peers)
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        try:
+            agree(err, "ncclCommInitRank")
+            # phase 4: does every side receive the trace of its neighbour's facing side?  (pattern exchange, sg_comm_selftest)
+            bad, err = 0, None
+            try:
+                bad = block.comm_selftest()
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)
+            agree(err or (("%d values arrived from the wrong place" % bad) if bad else None), "the exchange self-test")
+        except Exception:
+            try:
+                block.comm_finalize()
+            except Exception:      # noqa: BLE001
+                pass
+            raise
         self._sent0 = 0
         self.timing = False
 
@@ -219,11 +268,15 @@ class HaloExchanger(object):
         return (kind, self.dist.batch_isend_irecv(self._ops(kind, self.send, self.recv)))
 
     def _ops(self, kind, wire_out, wire_in):
+        """sends in the order of my sides, receives in the order of the FACING sides: transfers between two ranks are
+        paired in posting order, and what belongs on my side s is what the neighbour sent from its side s ^ 1.  It only
+        matters when two sides lead to one rank (a block that is its own neighbour across an axis): side s then gets
+        the facing side's trace - the periodic image - not its own (csrc/comm.cpp exchange does the same)."""
         ops = []
         for s in self.sides:
-            peer = self.part.neighbour(s)
-            ops.append(self.dist.P2POp(self.dist.isend, wire_out[(kind, s)], peer, self.group))
-            ops.append(self.dist.P2POp(self.dist.irecv, wire_in[(kind, s)], peer, self.group))
+            ops.append(self.dist.P2POp(self.dist.isend, wire_out[(kind, s)], self.part.neighbour(s), self.group))
+        for s in sorted(self.sides, key=lambda side: side ^ 1):
+            ops.append(self.dist.P2POp(self.dist.irecv, wire_in[(kind, s)], self.part.neighbour(s), self.group))
         return ops
 
     def finish(self, pending):

@@ -61,17 +61,22 @@ def main():
             b.set_source(nodes, sv)
             b.set_absorption(sigma, 4)
         nat.comm_init(comm_unique_id(), 0, 1, [None, None, None, None, 0, 0])
-        # one exchange on its own: the buffer received for a side is the one packed for it (RCCL pairs the sends and
-        # receives of one peer in posting order), and the two sides differ
+        # the pattern self-test of the exchange (what NativeExchanger runs before it trusts the communicator)
+        assert nat.comm_selftest() == 0
+        assert nat.comm_stats()["exchanges"] == 0 and nat.comm_stats()["bytes_sent"] == 0
+        # one exchange on its own: a side receives what the FACING side of its neighbour packed - here, the block being
+        # its own neighbour across z, side 5 gets the trace of side 4 and vice versa (receives are posted in the order
+        # of the facing sides: RCCL pairs the sends and receives of one peer in posting order) - and the two differ
         for field, kind in ((_lib.FIELD_S, 1), (_lib.FIELD_U, 0)):
             nat.comm_exchange(field)
             nat.sync()
-            got = {}
+            sent, got = {}, {}
             for s in (4, 5):
                 sp, rp, nb = nat.comm_buffers(kind, s)
-                sent, got[s] = dev_bytes(sp, nb), dev_bytes(rp, nb)
-                assert nb == nat.halo_bytes(field, s) and sent.any()
-                assert np.array_equal(sent, got[s]), "traces received for side %d differ from those sent" % s
+                sent[s], got[s] = dev_bytes(sp, nb), dev_bytes(rp, nb)
+                assert nb == nat.halo_bytes(field, s) and sent[s].any()
+            for s in (4, 5):
+                assert np.array_equal(got[s], sent[s ^ 1]), "side %d did not receive the trace of the facing side" % s
             assert not np.array_equal(got[4], got[5])
         assert nat.comm_stats(reset=True)["exchanges"] == 2
         # whole steps: one C-ABI call, against the host-driven exchanger on the twin block

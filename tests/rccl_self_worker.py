@@ -50,11 +50,12 @@ def main():
             blk.sync()
             torch.cuda.synchronize()
             for s in (4, 5):
-                # both sides talk to the same peer (this rank): RCCL pairs the sends and receives of one
-                # peer in posting order, so the buffer received for side s is the one packed for side s
-                sent, got = ex.send[(kind, s)], ex.recv[(kind, s)]
+                # both sides talk to the same peer (this rank): RCCL pairs the sends and receives of one peer in posting
+                # order, and the exchanger posts its receives in the order of the FACING sides - side s receives what
+                # was packed for side s ^ 1 (the block is its own periodic image across z)
+                sent, got = ex.send[(kind, s ^ 1)], ex.recv[(kind, s)]
                 assert float(sent.abs().max()) > 0
-                assert torch.equal(sent, got), "traces received for side %d differ from those sent" % s
+                assert torch.equal(sent, got), "side %d did not receive the trace of the facing side" % s
             assert not torch.equal(ex.recv[(kind, 4)], ex.recv[(kind, 5)])
         ex.step(3)                                         # the pipelined schedule, three whole steps
         blk.sync()

@@ -226,3 +226,63 @@ def test_halo_exchange_world8_bench_grid():
     assert _factor_grid(8, 3, (16, 64, 64)) == (1, 2, 4) and _factor_grid(6, 2, (4, 100)) == (1, 6)
     mp.spawn(_worker, args=(8, _free_port(), 3, (4, 4, 4), 1, grid), nprocs=8, join=True)
     mp.spawn(_worker, args=(8, _free_port(), 3, (2, 4, 8), 1, (1, 2, 4)), nprocs=8, join=True)
+
+
+class _TagBlock(object):
+    """The least a HaloExchanger needs, packing a tag that names (rank, side, field) into every trace value."""
+
+    def __init__(self, rank, sides):
+        self.rank, self.sides, self.ghost = rank, sides, {}
+
+    def halo_bytes(self, field, side):
+        return 8 * (5 + side)                    # a different size per axis end is NOT needed; sizes per side pair up
+
+    def halo_pack_sides(self, field, ptrs):
+        for side, ptr in ptrs.items():
+            n = self.halo_bytes(field, side) // 8
+            buf = np.frombuffer((C.c_double * n).from_address(ptr), dtype=np.float64)
+            buf[:] = 1000.0 * self.rank + 10.0 * side + field + np.arange(n) * 1e-3
+
+    def halo_attach(self, field, side, ptr):
+        self.ghost[(field, side)] = ptr
+
+    def received(self, field, side):
+        n = self.halo_bytes(field, side) // 8
+        return np.frombuffer((C.c_double * n).from_address(self.ghost[(field, side)]), dtype=np.float64).copy()
+
+
+def _wrapped_axis_worker(rank, world, port):
+    """Two ranks around a WRAPPED z axis: both z sides of a rank lead to the other rank.  Transfers between two ranks
+    are paired in posting order, so the exchanger must post its receives in the order of the facing sides: side s gets
+    what the peer packed for ITS side s ^ 1, not the mirror image (the case a one-rank test cannot see)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seigen_amd import _lib
+        from seigen_amd.mesh import Partition
+        from seigen_amd.parallel import HaloExchanger
+
+        class Wrapped(Partition):
+            def neighbour(self, side):
+                return 1 - self.rank if side >> 1 == 2 else None
+
+        part = Wrapped((4, 4, 8), rank, world, (1, 1, 2))
+        blk = _TagBlock(rank, [4, 5])
+        blk.halo_bytes = lambda field, side: 8 * 7          # both ends of an axis have the same size
+        ex = HaloExchanger(blk, part, torch.device("cpu"))
+        assert ex.sides == [4, 5]
+        for field in (_lib.FIELD_S, _lib.FIELD_U):
+            ex.finish(ex.start(field))
+            for s in (4, 5):
+                want = 1000.0 * (1 - rank) + 10.0 * (s ^ 1) + field + np.arange(7) * 1e-3
+                got = blk.received(field, s)
+                assert np.array_equal(got, want), (rank, field, s, got, want)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_faces_between_one_pair_of_ranks_are_paired_by_facing_side():
+    import torch.multiprocessing as mp
+    mp.spawn(_wrapped_axis_worker, args=(2, _free_port()), nprocs=2, join=True)
