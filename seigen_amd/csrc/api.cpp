@@ -110,6 +110,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
   h->use_mfma = kp.mfma;
   h->use_lane = kp.lane;
   h->use_tile = kp.tile;
+  h->use_hexm = kp.hexm;
   if (cfg->dtype != 0 && cfg->dtype != 1) return fail(h, SG_ERR_ARG, "dtype must be 0 (f64) or 1 (f32)");
   h->f32 = cfg->dtype;
   if (h->f32 && !h->use_mfma && !h->use_tile)
@@ -172,6 +173,10 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
       }
     }
     if (worst > 1e-11) return fail(h, SG_ERR_ARG, "hexahedral element: the operator tables do not factorise");
+    if (h->use_hexm) {     // kernels_hexm.hip: line operators with the own-trace half folded in, x-pass A operands
+      const std::vector<double> d1l(Dt);
+      Dt = hexm_table(cfg->degree, d1l.data(), d1l.data() + (size_t)n1 * n1, h->md);
+    }
   } else if (h->use_lane) {
     // lane path: E_r = D_r - (L_0 R_0 - L_{r+1} R_{r+1}) / (2 (d-1)!) row-major (own-trace half of the
     // central flux folded into the volume operator, see mfma_tables.cpp), and L_f row-major
@@ -277,7 +282,7 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
       HIPCHECK(h, hipMemcpy(h->fragP, fP.data(), fP.size() * sizeof(double), hipMemcpyHostToDevice));
     }
   }
-  if (h->use_mfma || h->use_lane || h->use_tile) {
+  if (h->use_mfma || h->use_lane || h->use_tile || h->use_hexm) {
     // symmetric-stress mode: fields start at zero, g only produces symmetric tensors;
     // left for good as soon as the user uploads a non-symmetric stress or source (SEIGEN_HIP_SYM=0: never entered)
     const char* sym_env = std::getenv("SEIGEN_HIP_SYM");
@@ -297,7 +302,8 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     // some of its own slots taken would run the late blocks' static shares one after the other.
     hipDeviceProp_t prop;
     HIPCHECK(h, hipGetDeviceProperties(&prop, cfg->device));
-    const int slots = (h->use_mfma ? mfma_blocks_per_cu(cfg->degree, h->f32) : 2) * prop.multiProcessorCount;
+    const int slots = (h->use_mfma ? mfma_blocks_per_cu(cfg->degree, h->f32) : (h->use_hexm ? hexm_blocks_per_cu(cfg->degree) : 2)) *
+                      prop.multiProcessorCount;
     h->grid_full = slots / 8 * 8;
     h->grid_blocks = (cfg->nbr_mask != 0 ? slots - slots / 16 : slots) / 8 * 8;
     if (const char* gb = std::getenv("SEIGEN_HIP_GRID_BLOCKS")) h->grid_blocks = std::max(8, std::atoi(gb) / 8 * 8);

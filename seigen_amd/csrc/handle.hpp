@@ -39,6 +39,7 @@ struct sg_handle {
   bool use_mfma = false;
   bool use_lane = false;
   bool use_tile = false;    // 2-D MFMA tile kernels (kernels_tile2d.hip), gw = 16
+  bool use_hexm = false;    // hexahedra DQ_3 / DQ_4 (kernels_hexm.hip), gw = 16
   int f32 = 0;              // sg_config.dtype = 1: fields, halo buffers, operator tiles and arithmetic are float (MFMA path)
   bool sym = false;         // MFMA path: all stress fields symmetric -> kernels touch only the i <= j lines
   int* sym_flag = nullptr;  // device word set by an upload that is not symmetric

@@ -29,7 +29,11 @@ KernelPath choose_kernel_path(const sg_config& cfg) {
     const bool fl = pe && std::strcmp(pe, "lane") == 0;
     kp.lane = cfg.dim == 3 && lane_supported_hex(cfg.dim, cfg.degree) && !fg &&
               (fl || (int64_t)cfg.n[0] * cfg.n[1] * cfg.n[2] >= SG_HEX_LANE_MIN_CELLS(cfg.degree));
-    kp.gw = kp.tile ? 16 : (kp.lane ? 64 : 1);
+    // hexahedra DQ_3 / DQ_4: lines in registers, x lines on the matrix pipe (kernels_hexm.hip) at every size;
+    // SEIGEN_HIP_PATH=generic: the thread-per-node kernel
+    const bool fh = pe && std::strcmp(pe, "hexm") == 0;
+    kp.hexm = cfg.dim == 3 && hexm_supported(cfg.dim, cfg.degree) && !fg && (fh || cfg.degree == 3);   // DQ_4: on request, until it wins
+    kp.gw = (kp.tile || kp.hexm) ? 16 : (kp.lane ? 64 : 1);
     return kp;
   }
   const int ncls = cfg.dim == 1 ? 1 : (cfg.dim == 2 ? 2 : 6);
@@ -68,6 +72,7 @@ bool mfma_supported(int dim, int P) { return dim == 3 && P >= 1 && P <= 4; }
 bool lane_supported(int dim, int P) { return ((dim == 1 || dim == 2) && P >= 1 && P <= 4) || (dim == 3 && (P == 1 || P == 2)); }
 // hexahedra: DQ_1 and DQ_2 (27 nodes) fit a lane's registers one component at a time
 bool lane_supported_hex(int dim, int P) { return dim == 3 && (P == 1 || P == 2); }
+bool hexm_supported(int dim, int P) { return dim == 3 && (P == 3 || P == 4); }
 bool tile2d_supported(int dim, int P) { return dim == 2 && P >= 1 && P <= 4; }
 bool tile2d_supported_quad(int P) { return P >= 1 && P <= 4; }   // DQ_4 has 25 rows: two row tiles, one after the other
 }  // namespace sg

@@ -21,7 +21,7 @@ struct Box {
   int o[3], n[3];
 };
 struct KernelPath {
-  bool mfma = false, lane = false, tile = false;
+  bool mfma = false, lane = false, tile = false, hexm = false;
   int gw = 1;
 };
 KernelPath choose_kernel_path(const sg_config& cfg);

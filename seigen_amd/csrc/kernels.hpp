@@ -183,6 +183,12 @@ bool lane_supported(int dim, int P);
 #define SG_HEX_LANE_MIN_CELLS(degree) 24000
 #endif
 bool lane_supported_hex(int dim, int P);   // a.tensor: hexahedra (sum-factorised; a.Dt = {D1, lift1})
+// hexahedra DQ_3 / DQ_4 with the lines of a cube in registers and the x lines on the matrix pipe (kernels_hexm.hip; fields
+// in the gw = 16 interleaved layout; a.Dt = hexm_table(): line operators E_k, trace lifts, x-pass A operands)
+bool hexm_supported(int dim, int P);
+int hexm_blocks_per_cu(int P);
+std::vector<double> hexm_table(int P, const double* D1, const double* lift1, const MeshDev& md_host);
+int launch_stage_hexm(int kind, int P, const StageArgs& a, long nitems, void* stream);
 int launch_stage_lane(int kind, int dim, int P, const StageArgs& a, long nitems, void* stream);
 
 // 2-D MFMA tile path (P1..P4; fields in the gw = 16 interleaved layout; a.fragV / a.fragL = tile2d_frags_*).

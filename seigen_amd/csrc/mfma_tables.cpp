@@ -343,6 +343,42 @@ MfmaConst mfma_const(const MeshDev& md) {
 }
 
 
+// Hexahedra DQ_3 / DQ_4 (kernels_hexm.hip): the line operators of the sum-factorised element on a block's cubes.
+//   E[k][a'][a] = -D1[a'][a] / h_k + 1/2 (c n)_{2k} lift1[0][a'] [a == 0] + 1/2 (c n)_{2k+1} lift1[1][a'] [a == P]
+//                 (the own-trace half of the central flux folded onto the line's end nodes),
+//   lw[k][s][a'] = 1/2 (c n)_{2k+s} lift1[s][a']   (what the neighbour's value across facet 2k + s is lifted with),
+// then the A operands of the x pass in lane order (v_mfma_f64_4x4x4_4b: lane l holds row l & 3, column l >> 4 of a
+// 4x4 block, the same for its four blocks): AX[k'][k][l] = E[0][4k' + (l & 3)][4k + (l >> 4)] and, for the extra
+// k-step that carries the two x-facet traces (lane group 0: facet 0, group 1: facet 1), AT[k'][l] = lw[0][l >> 4][4k' + (l & 3)].
+std::vector<double> hexm_table(int P, const double* D1, const double* lift1, const MeshDev& md) {
+  const int n1 = P + 1, ksx = (n1 + 3) / 4;
+  const int off_lw = 3 * n1 * n1, off_ax = off_lw + 6 * n1, off_at = off_ax + ksx * ksx * 64;
+  std::vector<double> t((size_t)off_at + (size_t)ksx * 64, 0.0);
+  auto E = [&](int k, int ap, int a) -> double& { return t[(size_t)(k * n1 + ap) * n1 + a]; };
+  auto LW = [&](int k, int s2, int ap) -> double& { return t[(size_t)off_lw + (size_t)(k * 2 + s2) * n1 + ap]; };
+  for (int k = 0; k < 3; ++k) {
+    const double ih = md.Jinv[0][k][k];
+    const double c0 = md.cn[0][2 * k][k], c1 = md.cn[0][2 * k + 1][k];
+    for (int ap = 0; ap < n1; ++ap) {
+      LW(k, 0, ap) = 0.5 * c0 * lift1[ap];
+      LW(k, 1, ap) = 0.5 * c1 * lift1[n1 + ap];
+      for (int a = 0; a < n1; ++a) E(k, ap, a) = -ih * D1[ap * n1 + a];
+      E(k, ap, 0) += LW(k, 0, ap);
+      E(k, ap, P) += LW(k, 1, ap);
+    }
+  }
+  for (int kp = 0; kp < ksx; ++kp)
+    for (int l = 0; l < 64; ++l) {
+      const int row = 4 * kp + (l & 3);
+      for (int ks = 0; ks < ksx; ++ks) {
+        const int col = 4 * ks + (l >> 4);
+        t[(size_t)off_ax + (size_t)(kp * ksx + ks) * 64 + l] = (row < n1 && col < n1) ? E(0, row, col) : 0.0;
+      }
+      t[(size_t)off_at + (size_t)kp * 64 + l] = (row < n1 && (l >> 4) < 2) ? LW(0, l >> 4, row) : 0.0;
+    }
+  return t;
+}
+
 // 2-D tile kernels (kernels_tile2d.hip): kernarg copy of what they need from the mesh tables
 T2Const tile2d_const(const MeshDev& md) {
   T2Const C;

@@ -90,7 +90,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   }
   std::vector<Box> boxes;
   region_boxes(h, region, boxes);
-  if (h->use_mfma || h->use_lane || h->use_tile) {
+  if (h->use_mfma || h->use_lane || h->use_tile || h->use_hexm) {
     // one launch for the whole region: the kernels scan all cell groups and mask lanes by box
     a.nbox = 0;
     for (const Box& b : boxes) {
@@ -149,10 +149,11 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
       }
       a.item_list = list;
       a.nlist = nlist;
-      if (h->use_mfma && h->region_whole[region] && !h->no_whole) a.all_active = 1;
+      if ((h->use_mfma || h->use_hexm) && h->region_whole[region] && !h->no_whole) a.all_active = 1;
     }
     a.nitems = a.item_list ? a.nlist : (int32_t)std::min<int64_t>((h->md.ncube_pad / h->md.gw) * h->ncls, INT32_MAX);
     int rc = h->use_mfma   ? launch_stage_mfma(kind, h->cfg.degree, a, h->stream)
+             : h->use_hexm ? launch_stage_hexm(kind, h->cfg.degree, a, (long)(h->md.ncube_pad / 16), h->stream)
              : h->use_tile ? launch_stage_tile2d(kind, h->cfg.degree, a, h->t2c, (long)(h->md.ncube_pad / 16) * h->ncls, h->stream)
                            : launch_stage_lane(kind, h->cfg.dim, h->cfg.degree, a, (long)(h->md.ncube_pad / 64) * h->ncls, h->stream);
     if (rc != 0) return fail(h, SG_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc));
