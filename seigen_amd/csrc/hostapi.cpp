@@ -31,8 +31,7 @@ KernelPath choose_kernel_path(const sg_config& cfg) {
               (fl || (int64_t)cfg.n[0] * cfg.n[1] * cfg.n[2] >= SG_HEX_LANE_MIN_CELLS(cfg.degree));
     // hexahedra DQ_3 / DQ_4: lines in registers, x lines on the matrix pipe (kernels_hexm.hip) at every size;
     // SEIGEN_HIP_PATH=generic: the thread-per-node kernel
-    const bool fh = pe && std::strcmp(pe, "hexm") == 0;
-    kp.hexm = cfg.dim == 3 && hexm_supported(cfg.dim, cfg.degree) && !fg && (fh || cfg.degree == 3);   // DQ_4: on request, until it wins
+    kp.hexm = cfg.dim == 3 && hexm_supported(cfg.dim, cfg.degree) && !fg;
     kp.gw = (kp.tile || kp.hexm) ? 16 : (kp.lane ? 64 : 1);
     return kp;
   }

@@ -86,6 +86,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
     i0c[ks] = i0ok[ks] ? q + 4 * ks : 0;
   }
 
+  // degree 4, G stages: the component held through the whole item (u_2) lives in LDS (a wave-private 16 KB), not in 100
+  // registers: with it the three phases of G fit the register file without spilling
+  constexpr bool U2_LDS = KIND == 1 && P >= 4;
+  __shared__ double sU2[U2_LDS ? 4 * ND * 16 : 1];
+  (void)sU2;
+
   const long ncube = md->ncube;
   const long ngroups = md->ncube_pad >> 4;
   const bool listed = A.item_list != nullptr;
@@ -123,192 +129,218 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
       active = valid && inb;
     }
     if (!__any(active)) continue;
-    const double* own = in + (g * (long)ND) * NC * 16 + w;
+    const double* const ug = in + (g * (long)ND) * NC * 16;   // wave-uniform: the group's cell data ([node][comp][16 cubes])
     const long e = valid ? c : 0;
+    // index of the lane's own node (i0c[ks], 0, 0), component 0; node (., i1, i2) is a compile-time distance further on
+    int lown[KSX];
+#pragma unroll
+    for (int ks = 0; ks < KSX; ++ks) lown[ks] = i0c[ks] * NC * 16 + w;
+    constexpr int D1N = N1 * NC * 16, D2N = N1 * N1 * NC * 16;   // one step in i1 / i2 inside a cell
 
-    // where each facet's neighbour trace lives: the neighbour cube's cell, a packed remote trace ([cube on the side][facet
-    // node][3]: the velocity, or T_i,axis of a stress), or - on the domain boundary - the own cell
-    const double* np[6];
-    bool gh[6], ph[6];
+    // Where each facet's neighbour values live: the neighbour cube's cell, a packed remote trace ([cube on the side][facet
+    // node][3]: the velocity, or T_i,axis of a stress), or - on the domain boundary - the own cell, whose value counts
+    // with the sign SGN.  Per lane and facet: a pointer to the facet node with the lane's own transverse position (and
+    // second transverse index 0), the distance to the next facet node along the second (third) transverse index, and how a
+    // component is reached - all three differ between a field and a remote record, so they are lane VALUES, not branches.
+    const double* pf[6][KSX];   // facets 2..5 (y, z): transverse position (i0c[ks], tt = 0); facets 0, 1 see below
+    int st[6];                  // distance from tt to tt + 1
+    double sg[6];
+    bool gh[6];
+    const double* pxl = nullptr;   // x facets: lane group 0 reads facet 0, lane group 1 facet 1 (groups 2, 3: any finite value)
+    int stx1 = 0, stx2 = 0;
+    double sgx = 1.0;
+    bool ghx = false;
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
       const int axis = f >> 1, dir = (f & 1) ? 1 : -1;
-      const int cn = cc[axis] + dir;
+      const int cnb = cc[axis] + dir;
       const int nax = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
-      const bool inside = valid && cn >= 0 && cn < nax;
+      const bool inside = valid && cnb >= 0 && cnb < nax;
       const long stride = axis == 0 ? 1 : (axis == 1 ? (long)n0 : (long)n0 * n1);
       const long nc = inside ? c + dir * stride : (valid ? c : 0);
-      np[f] = in + ((nc >> 4) * (long)ND) * NC * 16 + (nc & 15);
-      gh[f] = false;
-      ph[f] = !inside;
-      if (!inside && valid && md->has_nbr[f]) {
-        const long c2 = axis == 0 ? (cc[1] + (long)n1 * cc[2]) : (axis == 1 ? (cc[0] + (long)n0 * cc[2]) : (cc[0] + (long)n0 * cc[1]));
-        np[f] = A.ghost[f] + c2 * NF * 3;
-        gh[f] = true;
-        ph[f] = false;
+      const double* cell = in + ((nc >> 4) * (long)ND) * NC * 16 + (nc & 15);
+      const bool ghost = !inside && valid && md->has_nbr[f] != 0;
+      const bool phys = !inside && !ghost;
+      // the facet node's index along the facet's own axis: the far end of the neighbour, the near end of the own cell
+      const int fix = phys ? ((f & 1) ? P : 0) : ((f & 1) ? 0 : P);
+      const long c2 = axis == 0 ? (cc[1] + (long)n1 * cc[2]) : (axis == 1 ? (cc[0] + (long)n0 * cc[2]) : (cc[0] + (long)n0 * cc[1]));
+      const double* rec = ghost ? A.ghost[f] + c2 * NF * 3 : nullptr;
+      gh[f] = ghost;
+      sg[f] = phys ? SGN : 1.0;
+      if (axis == 0) {
+        if ((q & 1) == (f & 1)) {
+          pxl = ghost ? rec : cell + fix * NC * 16;
+          stx1 = ghost ? 3 : D1N;
+          stx2 = ghost ? N1 * 3 : D2N;
+          sgx = sg[f];
+          ghx = ghost;
+        }
+      } else {
+        st[f] = ghost ? N1 * 3 : (axis == 1 ? D2N : D1N);
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks)
+          pf[f][ks] = ghost ? rec + i0c[ks] * 3 : cell + (i0c[ks] + (axis == 1 ? N1 * fix : N1 * N1 * fix)) * NC * 16;
       }
     }
-    // x facets: lane group 0 reads facet 0, lane group 1 facet 1 (the extra k-step of the x pass), groups 2 and 3 nothing
-    const double* const npx = (q & 1) ? np[1] : np[0];
-    const bool ghx = (q & 1) ? gh[1] : gh[0], phx = (q & 1) ? ph[1] : ph[0];
-    const int x_own = (q & 1) ? P : 0, x_acr = (q & 1) ? 0 : P;
 
-    // ---- operand access
-    // component cf of the cell's own nodes -> U[ks][i1][i2]
-    auto load_comp = [&](int cf, double (&U)[KSX][N1][N1]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-        for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-          for (int ks = 0; ks < KSX; ++ks) U[ks][i1][i2] = own[((i0c[ks] + N1 * (i1 + N1 * i2)) * NC + cf) * 16];
-    };
-    // neighbour values across the two x facets at facet node (i1, i2), as the B operand of the extra k-step
-    auto trace_x = [&](int i1, int i2, int cf, int cg) __attribute__((always_inline)) -> double {
-      const int off = ghx ? (i1 + N1 * i2) * 3 + cg : (((phx ? x_own : x_acr) + N1 * (i1 + N1 * i2)) * NC + cf) * 16;
-      double v = 0.0;
-      if (q < 2) {
-        v = npx[off];
-        v = phx ? SGN * v : v;
-      }
+    // ---- operand access.  A PLANE is the nodes with one value of the third index i2: per lane KSX x N1 values (ks, i1).
+    //      The lines along x and y lie inside a plane, only the lines along z cross planes - so a stage holds ONE whole
+    //      component (the one differentiated along z) in registers and streams everything else plane by plane: few live
+    //      values, several planes of requests in flight.
+    // (Every access below starts from a base made OPAQUE at that point: the offsets of an item's loads are item-invariant
+    // lane values, and the optimiser otherwise computes all of them once, in front of the item loop, and keeps hundreds of
+    // registers of addresses alive through the whole kernel - or spills them.)
+    auto opq = [](int v) __attribute__((always_inline)) -> int {
+      asm volatile("" : "+v"(v));
       return v;
     };
-    // ... across a y facet (f = 2, 3) at facet node (i0, i2), across a z facet (f = 4, 5) at facet node (i0, i1): tt = the
-    // second transverse index
-    auto trace_yz = [&](int f, int ks, int tt, int cf, int cg) __attribute__((always_inline)) -> double {
-      const int axis = f >> 1;
-      const int fo = (f & 1) ? P : 0, fa = (f & 1) ? 0 : P;
-      const int node_own = axis == 1 ? i0c[ks] + N1 * (fo + N1 * tt) : i0c[ks] + N1 * (tt + N1 * fo);
-      const int node_acr = axis == 1 ? i0c[ks] + N1 * (fa + N1 * tt) : i0c[ks] + N1 * (tt + N1 * fa);
-      const int off = gh[f] ? (i0c[ks] + N1 * tt) * 3 + cg : ((ph[f] ? node_own : node_acr) * NC + cf) * 16;
-      const double v = np[f][off];
-      return ph[f] ? SGN * v : v;
+    auto opqp = [](const double* p) __attribute__((always_inline)) -> const double* {
+      asm volatile("" : "+v"(p));
+      return p;
     };
-
-    // ---- the three line passes: acc += line_k(U) with the traces of component (cf in a field, cg in a remote record)
-    auto pass_x = [&](double (&acc)[KSX][N1][N1], const double (&U)[KSX][N1][N1], int cf, int cg) __attribute__((always_inline)) {
-      double tv[N1][N1];
+    auto load_full = [&](int cf, double (&U)[KSX][N1][N1]) __attribute__((always_inline)) {
+      int lo[KSX];
 #pragma unroll
-      for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-        for (int i1 = 0; i1 < N1; ++i1) tv[i1][i2] = trace_x(i1, i2, cf, cg);
+      for (int ks = 0; ks < KSX; ++ks) lo[ks] = opq(lown[ks]) + cf * 16;
 #pragma unroll
       for (int i2 = 0; i2 < N1; ++i2)
 #pragma unroll
         for (int i1 = 0; i1 < N1; ++i1)
 #pragma unroll
-          for (int kp = 0; kp < KSX; ++kp) {
-            double r = acc[kp][i1][i2];
-#pragma unroll
-            for (int ks = 0; ks < KSX; ++ks) r = HXM_MFMA4(ax[kp][ks], U[ks][i1][i2], r);
-            acc[kp][i1][i2] = HXM_MFMA4(at[kp], tv[i1][i2], r);
-          }
+          for (int ks = 0; ks < KSX; ++ks) U[ks][i1][i2] = ug[lo[ks] + i1 * D1N + i2 * D2N];
     };
-    auto pass_y = [&](double (&acc)[KSX][N1][N1], const double (&U)[KSX][N1][N1], int cf, int cg) __attribute__((always_inline)) {
-      double t0[KSX][N1], t1[KSX][N1];
+    auto load_plane = [&](int cf, int i2, double (&V)[KSX][N1]) __attribute__((always_inline)) {
+      int lo[KSX];
 #pragma unroll
-      for (int i2 = 0; i2 < N1; ++i2)
+      for (int ks = 0; ks < KSX; ++ks) lo[ks] = opq(lown[ks]) + cf * 16 + i2 * D2N;
 #pragma unroll
-        for (int ks = 0; ks < KSX; ++ks) {
-          t0[ks][i2] = trace_yz(2, ks, i2, cf, cg);
-          t1[ks][i2] = trace_yz(3, ks, i2, cf, cg);
+      for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) V[ks][i1] = ug[lo[ks] + i1 * D1N];
+    };
+    // neighbour values across the x facets at the facet nodes (i1, i2) of a plane (lane group 0: facet 0, group 1: facet 1)
+    auto xtr_plane = [&](int cf, int cg, int i2, double (&t)[N1]) __attribute__((always_inline)) {
+      const double* pb = opqp(pxl) + (ghx ? cg : cf * 16) + i2 * stx2;
+#pragma unroll
+      for (int i1 = 0; i1 < N1; ++i1) t[i1] = pb[i1 * stx1];
+    };
+    // ... across the y facets at the facet nodes (i0, i2) of a plane
+    auto ytr_plane = [&](int cf, int cg, int i2, double (&t0)[KSX], double (&t1)[KSX]) __attribute__((always_inline)) {
+      const int c0 = gh[2] ? cg : cf * 16, c1 = gh[3] ? cg : cf * 16;
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) {
+        t0[ks] = opqp(pf[2][ks])[c0 + i2 * st[2]];
+        t1[ks] = opqp(pf[3][ks])[c1 + i2 * st[3]];
+      }
+    };
+    // ... across the z facets at all their facet nodes (i0, i1)
+    auto ztr_full = [&](int cf, int cg, double (&t0)[KSX][N1], double (&t1)[KSX][N1]) __attribute__((always_inline)) {
+      const int c0 = gh[4] ? cg : cf * 16, c1 = gh[5] ? cg : cf * 16;
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) {
+        const double* p0 = opqp(pf[4][ks]) + c0;
+        const double* p1 = opqp(pf[5][ks]) + c1;
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1) {
+          t0[ks][i1] = p0[i1 * st[4]];
+          t1[ks][i1] = p1[i1 * st[5]];
         }
+      }
+    };
+    // ---- the line operators on a plane: o += line_k(V)
+    auto X_plane = [&](double (&o)[KSX][N1], const double (&V)[KSX][N1], const double (&t)[N1]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i1 = 0; i1 < N1; ++i1) {
+        const double tvs = sgx * t[i1];
+#pragma unroll
+        for (int kp = 0; kp < KSX; ++kp) {
+          double r = o[kp][i1];
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks) r = HXM_MFMA4(ax[kp][ks], V[ks][i1], r);
+          o[kp][i1] = HXM_MFMA4(at[kp], tvs, r);
+        }
+      }
+    };
+    auto Y_plane = [&](double (&o)[KSX][N1], const double (&V)[KSX][N1], const double (&t0)[KSX], const double (&t1)[KSX]) __attribute__((always_inline)) {
 #pragma unroll
       for (int ap = 0; ap < N1; ++ap) {
 #pragma unroll
         for (int a = 0; a < N1; ++a) {
           const double cE = E(1, ap, a);
 #pragma unroll
-          for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-            for (int ks = 0; ks < KSX; ++ks) acc[ks][ap][i2] += cE * U[ks][a][i2];
+          for (int ks = 0; ks < KSX; ++ks) o[ks][ap] += cE * V[ks][a];
         }
         const double l0 = LW(1, 0, ap), l1 = LW(1, 1, ap);
 #pragma unroll
-        for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-          for (int ks = 0; ks < KSX; ++ks) acc[ks][ap][i2] += l0 * t0[ks][i2] + l1 * t1[ks][i2];
+        for (int ks = 0; ks < KSX; ++ks) o[ks][ap] += l0 * (sg[2] * t0[ks]) + l1 * (sg[3] * t1[ks]);
       }
     };
-    auto pass_z = [&](double (&acc)[KSX][N1][N1], const double (&U)[KSX][N1][N1], int cf, int cg) __attribute__((always_inline)) {
-      double t0[KSX][N1], t1[KSX][N1];
+    // plane i2 of line_z(U): every line along z has one node in the plane
+    auto Z_plane = [&](double (&o)[KSX][N1], const double (&U)[KSX][N1][N1], int i2, const double (&t0)[KSX][N1],
+                       const double (&t1)[KSX][N1]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < N1; ++a) {
+        const double cE = E(2, i2, a);
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks) o[ks][i1] += cE * U[ks][i1][a];
+      }
+      const double l0 = LW(2, 0, i2), l1 = LW(2, 1, i2);
+#pragma unroll
+      for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) o[ks][i1] += l0 * (sg[4] * t0[ks][i1]) + l1 * (sg[5] * t1[ks][i1]);
+    };
+    auto clear_plane = [&](double (&o)[KSX][N1]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1) o[ks][i1] = 0.0;
+    };
+    // the arithmetic that produced v is complete HERE (the optimiser otherwise sinks it to its first use, past the
+    // requests that follow, and everything requested meanwhile stays live: kernels_lane.hip hex_stage)
+    auto pin_plane = [&](double (&v)[KSX][N1]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1) asm volatile("" : "+v"(v[ks][i1]));
+    };
+#define HXM_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // ---- results: plane i2 of component `cmp` of the output field (nco components per node)
+    auto old_plane = [&](int nco, int cmp, int i2, double (&po)[KSX][N1], double (&pa)[KSX][N1]) __attribute__((always_inline)) {
+      const long gbase = (g * (long)ND) * nco * 16;
+      int lo[KSX];
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) lo[ks] = opq(i0c[ks] * 16) * nco + w + cmp * 16 + i2 * (N1 * N1) * nco * 16;
 #pragma unroll
       for (int i1 = 0; i1 < N1; ++i1)
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
-          t0[ks][i1] = trace_yz(4, ks, i1, cf, cg);
-          t1[ks][i1] = trace_yz(5, ks, i1, cf, cg);
+          const int o = lo[ks] + i1 * N1 * nco * 16;
+          po[ks][i1] = HXM_LDS(&out[gbase + o]);
+          pa[ks][i1] = HXM_LDS(&aux[gbase + o]);
         }
+    };
+    // one branch around all of a k-step's stores (a branch per store would end the scheduling region at every store)
+    auto store_plane = [&](int nco, int cmp, int i2, const double (&v)[KSX][N1]) __attribute__((always_inline)) {
+      double* const og = out + (g * (long)ND) * nco * 16;
+      if (active) {
 #pragma unroll
-      for (int ap = 0; ap < N1; ++ap) {
+        for (int ks = 0; ks < KSX; ++ks)
+          if (ks == 0 || i0ok[ks]) {
+            const int lo = opq(i0c[ks] * 16) * nco + w + cmp * 16 + i2 * (N1 * N1) * nco * 16;
 #pragma unroll
-        for (int a = 0; a < N1; ++a) {
-          const double cE = E(2, ap, a);
-#pragma unroll
-          for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-            for (int ks = 0; ks < KSX; ++ks) acc[ks][i1][ap] += cE * U[ks][i1][a];
-        }
-        const double l0 = LW(2, 0, ap), l1 = LW(2, 1, ap);
-#pragma unroll
-        for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-          for (int ks = 0; ks < KSX; ++ks) acc[ks][i1][ap] += l0 * t0[ks][i1] + l1 * t1[ks][i1];
+            for (int i1 = 0; i1 < N1; ++i1) HXM_ST(&og[lo + i1 * N1 * nco * 16], v[ks][i1]);
+          }
       }
-    };
-    auto clear = [&](double (&acc)[KSX][N1][N1]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ks = 0; ks < KSX; ++ks)
-#pragma unroll
-        for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-          for (int i2 = 0; i2 < N1; ++i2) acc[ks][i1][i2] = 0.0;
-    };
-    // the arithmetic that produced v is complete HERE (the optimiser otherwise sinks it to its first use, past the
-    // requests that follow: kernels_lane.hip hex_stage)
-    auto pin = [&](double (&v)[KSX][N1][N1]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ks = 0; ks < KSX; ++ks)
-#pragma unroll
-        for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-          for (int i2 = 0; i2 < N1; ++i2) asm volatile("" : "+v"(v[ks][i1][i2]));
-    };
-    // results -> component `cmp` of the output field (NCO components per node); MODE 1: out = cs out + ca aux + cn v
-    auto finish = [&](double (&v)[KSX][N1][N1], int nco, int cmp, double cs, double ca, double cn) __attribute__((always_inline)) {
-      const long obase = (g * (long)ND) * nco * 16 + w;
-      if (MODE == 1) {
-        double po[KSX][N1][N1], pa[KSX][N1][N1];
-#pragma unroll
-        for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-          for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-            for (int ks = 0; ks < KSX; ++ks) {
-              const long o = obase + ((long)(i0c[ks] + N1 * (i1 + N1 * i2)) * nco + cmp) * 16;
-              po[ks][i1][i2] = HXM_LDS(&out[o]);
-              pa[ks][i1][i2] = HXM_LDS(&aux[o]);
-            }
-#pragma unroll
-        for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-          for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-            for (int ks = 0; ks < KSX; ++ks) v[ks][i1][i2] = cs * po[ks][i1][i2] + ca * pa[ks][i1][i2] + cn * v[ks][i1][i2];
-        pin(v);
-      }
-#pragma unroll
-      for (int i2 = 0; i2 < N1; ++i2)
-#pragma unroll
-        for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-          for (int ks = 0; ks < KSX; ++ks)
-            if (active && i0ok[ks]) HXM_ST(&out[obase + ((long)(i0c[ks] + N1 * (i1 + N1 * i2)) * nco + cmp) * 16], v[ks][i1][i2]);
     };
     auto cix = [](int i, int j) { return (SYM && i > j) ? j * 3 + i : i * 3 + j; };
 
     if (KIND == 0) {
-      // ---- F: uh_i = sum_j line_j(T_ij) - sponge (elastic.py:204-209); one result component at a time
+      // ---- F: uh_i = line_x(T_i0) + line_y(T_i1) + line_z(T_i2) - sponge (elastic.py:204-209), one result component at
+      //      a time (a rolled loop: the code of an item stays small).  T_i2 is held whole; T_i0 and T_i1 stream through
+      //      plane by plane, the next plane requested while this one is worked on.
       int sslot = -1;
       if (A.sponge_slot != nullptr && active) sslot = A.sponge_slot[e];
       const bool any_sponge = A.sponge_slot != nullptr && __any(sslot >= 0);
@@ -320,142 +352,279 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
       }
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
-        double acc[KSX][N1][N1];
-        clear(acc);
-        {
-          double U[KSX][N1][N1];
-          load_comp(cix(i, 0), U);
-          pass_x(acc, U, cix(i, 0), i);
-        }
-        {
-          double U[KSX][N1][N1];
-          load_comp(cix(i, 1), U);
-          pass_y(acc, U, cix(i, 1), i);
-        }
-        {
-          double U[KSX][N1][N1];
-          load_comp(cix(i, 2), U);
-          pass_z(acc, U, cix(i, 2), i);
-        }
-        if (any_sponge) {
-          // - sum_b B_e[a][b] u_abs[b][i] on the lanes whose cube carries sigma (rare: a layer of cells)
-          if (sslot >= 0) {
-            const double* B = A.sponge_B + (long)sslot * ND * ND;
-            const double* ua = A.uabs + (g * (long)ND) * 3 * 16 + w;
+        const int c0 = cix(i, 0), c1 = cix(i, 1), c2 = cix(i, 2);
+        double Uz[KSX][N1][N1], tz0[KSX][N1], tz1[KSX][N1];
+        double Va[2][KSX][N1], Vb[2][KSX][N1], xt[2][N1], y0[2][KSX], y1[2][KSX], po[KSX][N1], pa[KSX][N1];
+        auto request = [&](int i2, int s2) __attribute__((always_inline)) {
+          xtr_plane(c0, i, i2, xt[s2]);
+          load_plane(c0, i2, Va[s2]);
+          ytr_plane(c1, i, i2, y0[s2], y1[s2]);
+          load_plane(c1, i2, Vb[s2]);
+        };
+        constexpr bool AHEAD = !(MODE == 1 && P >= 4);   // (the fused stage at degree 4: no room for a second set of plane operands)
+        HXM_FENCE();
+        ztr_full(c2, i, tz0, tz1);
+        load_full(c2, Uz);
+        if (AHEAD) request(0, 0);
+        HXM_FENCE();
 #pragma unroll
-            for (int i2 = 0; i2 < N1; ++i2)
+        for (int i2 = 0; i2 < N1; ++i2) {
+          const int s2 = AHEAD ? (i2 & 1) : 0;
+          if (AHEAD) {
+            if (i2 + 1 < N1) request(i2 + 1, s2 ^ 1);
+          } else {
+            request(i2, 0);
+          }
+          if (MODE == 1) old_plane(3, i, i2, po, pa);     // (behind the plane operands: needed last)
+          HXM_FENCE();
+          double o[KSX][N1];
+          clear_plane(o);
+          Z_plane(o, Uz, i2, tz0, tz1);
+          X_plane(o, Va[s2], xt[s2]);
+          Y_plane(o, Vb[s2], y0[s2], y1[s2]);
+          if (any_sponge) {
+            // - sum_b B_e[a][b] u_abs[b][i] on the lanes whose cube carries sigma (rare: a layer of cells)
+            if (sslot >= 0) {
+              const double* B = A.sponge_B + (long)sslot * ND * ND;
+              const double* ua = A.uabs + (g * (long)ND) * 3 * 16 + w;
 #pragma unroll
               for (int i1 = 0; i1 < N1; ++i1)
 #pragma unroll
                 for (int ks = 0; ks < KSX; ++ks) {
                   const int a = i0c[ks] + N1 * (i1 + N1 * i2);
-                  double s = 0.0;
-                  for (int b = 0; b < ND; ++b) s += B[(long)a * ND + b] * ua[(b * 3 + i) * 16];
-                  acc[ks][i1][i2] -= s;
+                  double sp = 0.0;
+#pragma unroll 1
+                  for (int b = 0; b < ND; ++b) sp += B[(long)a * ND + b] * ua[(b * 3 + i) * 16];
+                  o[ks][i1] -= sp;
                 }
+            }
           }
+          if (MODE == 1) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+              for (int i1 = 0; i1 < N1; ++i1) o[ks][i1] = cs * po[ks][i1] + ca * pa[ks][i1] + cn * o[ks][i1];
+          }
+          pin_plane(o);
+          HXM_FENCE();
+          store_plane(3, i, i2, o);
+          HXM_FENCE();
         }
-        finish(acc, 3, i, cs, ca, cn);
       }
     } else {
       // ---- G: W_ik = line_k(u_i); sh_ii = 2 mu W_ii + lam tr W, sh_ij = mu (W_ij + W_ji) (elastic.py:211-219)
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
-      constexpr bool HOLD = P <= 3;     // the three velocity components stay in registers from sweep A to sweep B
-      double UH[HOLD ? 3 : 1][KSX][N1][N1];
-      {
-        // sweep A: the diagonal
-        double wd[3][KSX][N1][N1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) clear(wd[k]);
-        if (HOLD) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) load_comp(k, UH[HOLD ? k : 0]);
-          pass_x(wd[0], UH[0], 0, 0);
-          pass_y(wd[1], UH[HOLD ? 1 : 0], 1, 1);
-          pass_z(wd[2], UH[HOLD ? 2 : 0], 2, 2);
-        } else {
-          {
-            double U[KSX][N1][N1];
-            load_comp(0, U);
-            pass_x(wd[0], U, 0, 0);
-          }
-          {
-            double U[KSX][N1][N1];
-            load_comp(1, U);
-            pass_y(wd[1], U, 1, 1);
-          }
-          {
-            double U[KSX][N1][N1];
-            load_comp(2, U);
-            pass_z(wd[2], U, 2, 2);
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KSX; ++ks)
-#pragma unroll
-          for (int i1 = 0; i1 < N1; ++i1)
-#pragma unroll
-            for (int i2 = 0; i2 < N1; ++i2) {
-              const double tr = lam * (wd[0][ks][i1][i2] + wd[1][ks][i1][i2] + wd[2][ks][i1][i2]);
-#pragma unroll
-              for (int k = 0; k < 3; ++k) wd[k][ks][i1][i2] = 2.0 * mu * wd[k][ks][i1][i2] + tr;
-            }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) finish(wd[k], 9, 4 * k, A.c_self, A.c_aux, A.c_new);
-      }
-      {
-        // sweep B: the pairs (0,1), (0,2), (1,2): component i feeds the two pairs it belongs to, along the other two axes
-        double pr[3][KSX][N1][N1];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) clear(pr[p]);
-        if (HOLD) {
-          pass_y(pr[0], UH[0], 0, 0);                  // W_01
-          pass_z(pr[1], UH[0], 0, 0);                  // W_02
-          pass_x(pr[0], UH[HOLD ? 1 : 0], 1, 1);       // W_10
-          pass_z(pr[2], UH[HOLD ? 1 : 0], 1, 1);       // W_12
-          pass_x(pr[1], UH[HOLD ? 2 : 0], 2, 2);       // W_20
-          pass_y(pr[2], UH[HOLD ? 2 : 0], 2, 2);       // W_21
-        } else {
-          {
-            double U[KSX][N1][N1];
-            load_comp(0, U);
-            pass_y(pr[0], U, 0, 0);
-            pass_z(pr[1], U, 0, 0);
-          }
-          {
-            double U[KSX][N1][N1];
-            load_comp(1, U);
-            pass_x(pr[0], U, 1, 1);
-            pass_z(pr[2], U, 1, 1);
-          }
-          {
-            double U[KSX][N1][N1];
-            load_comp(2, U);
-            pass_x(pr[1], U, 2, 2);
-            pass_y(pr[2], U, 2, 2);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const int i = p == 2 ? 1 : 0, j = p == 0 ? 1 : 2;
+      const double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      auto emit = [&](int cmp, int i2, double (&v)[KSX][N1], const double (&po)[KSX][N1], const double (&pa)[KSX][N1]) __attribute__((always_inline)) {
+        if (MODE == 1) {
 #pragma unroll
           for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
-            for (int i1 = 0; i1 < N1; ++i1)
+            for (int i1 = 0; i1 < N1; ++i1) v[ks][i1] = cs * po[ks][i1] + ca * pa[ks][i1] + cn * v[ks][i1];
+        }
+        pin_plane(v);
+      };
+      // -- phase A: u_2 held whole (its lines along z give W_22); u_0 and u_1 stream through plane by plane and give W_00,
+      //    W_11 and the pair (0,1) on the way: sh_00, sh_11, sh_22, sh_01 of every plane leave together
+      double U2[U2_LDS ? 1 : KSX][U2_LDS ? 1 : N1][U2_LDS ? 1 : N1];
+      double* const su2 = sU2 + (U2_LDS ? (size_t)wave * ND * 16 + w : 0);
+      // u_2 at the lane's node (ks, i1, a): a register, or the wave's LDS copy (a padded row reads a valid slot)
+      auto u2 = [&](int ks, int i1, int a) __attribute__((always_inline)) -> double {
+        if constexpr (U2_LDS)
+          return su2[(i0c[ks] + N1 * (i1 + N1 * a)) * 16];
+        else
+          return U2[U2_LDS ? 0 : ks][U2_LDS ? 0 : i1][U2_LDS ? 0 : a];
+      };
+      auto Z_plane_u2 = [&](double (&o)[KSX][N1], int i2, const double (&t0)[KSX][N1], const double (&t1)[KSX][N1]) __attribute__((always_inline)) {
 #pragma unroll
-              for (int i2 = 0; i2 < N1; ++i2) pr[p][ks][i1][i2] *= mu;
-          if (!SYM) {      // the mirror entry has its own old values (asymmetric user data, rare)
-            double m2[KSX][N1][N1];
+        for (int a = 0; a < N1; ++a) {
+          const double cE = E(2, i2, a);
 #pragma unroll
-            for (int ks = 0; ks < KSX; ++ks)
+          for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) o[ks][i1] += cE * u2(ks, i1, a);
+        }
+        const double l0 = LW(2, 0, i2), l1 = LW(2, 1, i2);
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks) o[ks][i1] += l0 * (sg[4] * t0[ks][i1]) + l1 * (sg[5] * t1[ks][i1]);
+      };
+      {
+        double tz0[KSX][N1], tz1[KSX][N1];
+        double V0[2][KSX][N1], V1[2][KSX][N1], x0[2][N1], x1[2][N1], y00[2][KSX], y01[2][KSX], y10[2][KSX], y11[2][KSX];
+        double po[4][KSX][N1], pa[4][KSX][N1];
+        constexpr int OC[4] = {0, 4, 8, 1};
+        // the fused stage has no room for a second set of plane operands beside the old values of four results: it requests
+        // a plane when it gets to it
+        constexpr bool AHEAD = MODE == 0;
+        auto request = [&](int i2, int s2) __attribute__((always_inline)) {
+          xtr_plane(0, 0, i2, x0[s2]);
+          xtr_plane(1, 1, i2, x1[s2]);
+          load_plane(0, i2, V0[s2]);
+          load_plane(1, i2, V1[s2]);
+          ytr_plane(0, 0, i2, y00[s2], y01[s2]);
+          ytr_plane(1, 1, i2, y10[s2], y11[s2]);
+        };
+        HXM_FENCE();
+        ztr_full(2, 2, tz0, tz1);
+        if constexpr (U2_LDS) {
+          double T[KSX][N1][N1];
+          load_full(2, T);
+          if (AHEAD) request(0, 0);
+          HXM_FENCE();
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks)
+            if (ks == 0 || i0ok[ks]) {
 #pragma unroll
               for (int i1 = 0; i1 < N1; ++i1)
 #pragma unroll
-                for (int i2 = 0; i2 < N1; ++i2) m2[ks][i1][i2] = pr[p][ks][i1][i2];
-            finish(m2, 9, j * 3 + i, A.c_self, A.c_aux, A.c_new);
+                for (int a = 0; a < N1; ++a) su2[(i0c[ks] + N1 * (i1 + N1 * a)) * 16] = T[ks][i1][a];
+            }
+        } else {
+          double (&Ur)[KSX][N1][N1] = reinterpret_cast<double (&)[KSX][N1][N1]>(U2);
+          load_full(2, Ur);
+          if (AHEAD) request(0, 0);
+        }
+        HXM_FENCE();
+#pragma unroll
+        for (int i2 = 0; i2 < N1; ++i2) {
+          const int s2 = AHEAD ? (i2 & 1) : 0;
+          if (AHEAD) {
+            if (i2 + 1 < N1) request(i2 + 1, s2 ^ 1);
+          } else {
+            request(i2, 0);
           }
-          finish(pr[p], 9, i * 3 + j, A.c_self, A.c_aux, A.c_new);
+          if (MODE == 1) {      // old values of two of the four results: behind the next plane's operands (needed last) ...
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4) old_plane(9, OC[c4], i2, po[c4], pa[c4]);
+          }
+          HXM_FENCE();
+          double w00[KSX][N1], w11[KSX][N1], w22[KSX][N1], w01[KSX][N1];
+          clear_plane(w00);
+          clear_plane(w11);
+          clear_plane(w22);
+          clear_plane(w01);
+          Z_plane_u2(w22, i2, tz0, tz1);
+          X_plane(w00, V0[s2], x0[s2]);
+          Y_plane(w11, V1[s2], y10[s2], y11[s2]);
+          Y_plane(w01, V0[s2], y00[s2], y01[s2]);
+          X_plane(w01, V1[s2], x1[s2]);
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+            for (int i1 = 0; i1 < N1; ++i1) {
+              const double tr = lam * (w00[ks][i1] + w11[ks][i1] + w22[ks][i1]);
+              w00[ks][i1] = 2.0 * mu * w00[ks][i1] + tr;
+              w11[ks][i1] = 2.0 * mu * w11[ks][i1] + tr;
+              w22[ks][i1] = 2.0 * mu * w22[ks][i1] + tr;
+              w01[ks][i1] = mu * w01[ks][i1];
+            }
+          double w10[SYM ? 1 : KSX][SYM ? 1 : N1];      // the mirror entry (1,0) (asymmetric user data, rare): own old values
+          if (!SYM) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+              for (int i1 = 0; i1 < N1; ++i1) w10[SYM ? 0 : ks][SYM ? 0 : i1] = w01[ks][i1];
+          }
+          if (MODE == 1) {      // ... and of the other two once this plane's operands have left the registers
+            pin_plane(w00);
+            pin_plane(w11);
+            pin_plane(w22);
+            pin_plane(w01);
+            HXM_FENCE();
+#pragma unroll
+            for (int c4 = 2; c4 < 4; ++c4) old_plane(9, OC[c4], i2, po[c4], pa[c4]);
+            HXM_FENCE();
+          }
+          emit(0, i2, w00, po[0], pa[0]);
+          emit(4, i2, w11, po[1], pa[1]);
+          emit(8, i2, w22, po[2], pa[2]);
+          emit(1, i2, w01, po[3], pa[3]);
+          if constexpr (!SYM) {
+            if (MODE == 1) {      // (not requested ahead)
+              double qo[KSX][N1], qa[KSX][N1];
+              old_plane(9, 3, i2, qo, qa);
+#pragma unroll
+              for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+                for (int i1 = 0; i1 < N1; ++i1) w10[SYM ? 0 : ks][SYM ? 0 : i1] = cs * qo[ks][i1] + ca * qa[ks][i1] + cn * w10[SYM ? 0 : ks][SYM ? 0 : i1];
+            }
+            HXM_FENCE();
+            double (&m10)[KSX][N1] = reinterpret_cast<double (&)[KSX][N1]>(w10);
+            pin_plane(m10);
+            store_plane(9, 3, i2, m10);
+          }
+          HXM_FENCE();
+          store_plane(9, 0, i2, w00);
+          store_plane(9, 4, i2, w11);
+          store_plane(9, 8, i2, w22);
+          store_plane(9, 1, i2, w01);
+          HXM_FENCE();
+        }
+      }
+      // -- phases B1, B2: the pairs (0,2) and (1,2) = line_z of u_0 / u_1 (held whole, one after the other) + line_x /
+      //    line_y of u_2 (still held): plane by plane out of registers, only old values and traces come from memory
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double Ui[KSX][N1][N1], tz0[KSX][N1], tz1[KSX][N1];
+        double xt[2][N1], y0[2][KSX], y1[2][KSX], po[KSX][N1], pa[KSX][N1];
+        const int cmp = i * 3 + 2;
+        auto request = [&](int i2, int s2) __attribute__((always_inline)) {
+          if (i == 0)
+            xtr_plane(2, 2, i2, xt[s2]);
+          else
+            ytr_plane(2, 2, i2, y0[s2], y1[s2]);
+        };
+        HXM_FENCE();
+        ztr_full(i, i, tz0, tz1);
+        load_full(i, Ui);
+        request(0, 0);
+        HXM_FENCE();
+#pragma unroll
+        for (int i2 = 0; i2 < N1; ++i2) {
+          const int s2 = i2 & 1;
+          if (i2 + 1 < N1) request(i2 + 1, s2 ^ 1);
+          if (MODE == 1) old_plane(9, cmp, i2, po, pa);
+          HXM_FENCE();
+          double pr[KSX][N1], V2[KSX][N1];
+          clear_plane(pr);
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+            for (int i1 = 0; i1 < N1; ++i1) V2[ks][i1] = u2(ks, i1, i2);
+          Z_plane(pr, Ui, i2, tz0, tz1);                  // W_i2
+          if (i == 0)
+            X_plane(pr, V2, xt[s2]);                      // W_20
+          else
+            Y_plane(pr, V2, y0[s2], y1[s2]);              // W_21
+#pragma unroll
+          for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+            for (int i1 = 0; i1 < N1; ++i1) pr[ks][i1] *= mu;
+          if (!SYM) {
+            double m2[KSX][N1];
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+              for (int i1 = 0; i1 < N1; ++i1) m2[ks][i1] = pr[ks][i1];
+            if (MODE == 1) {
+              double qo[KSX][N1], qa[KSX][N1];
+              old_plane(9, 6 + i, i2, qo, qa);
+#pragma unroll
+              for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+                for (int i1 = 0; i1 < N1; ++i1) m2[ks][i1] = cs * qo[ks][i1] + ca * qa[ks][i1] + cn * m2[ks][i1];
+            }
+            pin_plane(m2);
+            HXM_FENCE();
+            store_plane(9, 6 + i, i2, m2);
+          }
+          emit(cmp, i2, pr, po, pa);
+          HXM_FENCE();
+          store_plane(9, cmp, i2, pr);
+          HXM_FENCE();
         }
       }
     }
