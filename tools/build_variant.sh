@@ -9,5 +9,5 @@ cd "$(dirname "$0")/../seigen_amd/csrc"
 mkdir -p ../../build_tools
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $SRC.hip -o /tmp/kernels_mfma_$NAME.o
 OBJS=$(ls *.o | grep -v $SRC.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_tools/libseigen_hip_$NAME.so $OBJS /tmp/kernels_mfma_$NAME.o -L/opt/rocm/lib -lrccl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_tools/libseigen_hip_$NAME.so $OBJS /tmp/kernels_mfma_$NAME.o -ldl
 echo built build_tools/libseigen_hip_$NAME.so
