@@ -67,11 +67,13 @@ def test_eigenmode_on_hexahedra_converges(gpu):
         assert math.log2(errs[0][k] / errs[1][k]) > 1.8 and math.log2(errs[1][k] / errs[2][k]) > 2.0, errs
 
 
-@pytest.mark.parametrize("P,path", [(1, "generic"), (1, "lane"), (2, "generic"), (2, "lane"), (3, "generic"), (4, "generic")])
+@pytest.mark.parametrize("P,path", [(1, "generic"), (1, "lane"), (2, "generic"), (2, "lane"), (3, "generic"), (4, "generic"),
+                                    (3, "hexm"), (4, "hexm")])
 def test_sponge_source_and_material_on_hexahedra(gpu, monkeypatch, P, path):
     """The extras of the explosive-source set-up on hexahedral cells: DG4 sponge (elastic.py:207-208; 125 nodal values
     per cube), a nodal source table (:217-218) and per-cell lambda / mu, twelve steps against the oracle - on the
-    table-driven generic kernels (what a block this small runs by default) and on the sum-factorised lane kernels."""
+    table-driven generic kernels (what a DQ_1 / DQ_2 block this small runs by default), on the sum-factorised lane kernels
+    and - degrees 3 and 4, their default at every size - on the plane-by-plane matrix kernels (kernels_hexm.hip)."""
     monkeypatch.setenv("SEIGEN_HIP_PATH", path)
     from seigen_amd import _lib
     from seigen_amd.backend import HipBlock
@@ -176,6 +178,75 @@ def test_hexahedral_lane_kernels_stage_parity_with_the_oracle(gpu, monkeypatch, 
     assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, 0.7, 0.3)) < 1e-12
 
 
+@pytest.mark.parametrize("P", [3, 4])
+@pytest.mark.parametrize("n", [(7, 5, 3), (35, 3, 2), (1, 1, 1), (16, 2, 1), (3, 4, 5)])
+def test_hexahedral_matrix_kernels_agree_with_the_generic_kernels(gpu, monkeypatch, P, n):
+    """DQ_3 / DQ_4 on the plane-by-plane matrix kernels (kernels_hexm.hip: 16 cubes per wave, x lines through
+    v_mfma_f64_4x4x4, one component held, the rest streamed) against the thread-per-node generic kernels on ragged blocks -
+    cell groups of 16 straddling rows and layers, a single cube, a row of exactly one group - with sponge, source,
+    per-cell material and per-cell physical density; symmetric-stress storage and (a non-symmetric state) the full tensor."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    rng = np.random.default_rng(P * 100 + n[0])
+    h = [0.7, 1.3, 0.9]
+    for symmetric in (True, False):
+        res = {}
+        for path in ("generic", "hexm"):
+            monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+            blk = HipBlock(3, P, n, h, [0.0] * 3, "quadrilateral")
+            nc, nd = blk.ncells, blk.nd
+            assert ("hexm_stage" in blk.stage_kernel_name(0)) == (path == "hexm")
+            if path == "generic":
+                lam, mu, rho = rng.uniform(0.4, 0.8, nc), rng.uniform(0.2, 0.4, nc), rng.uniform(0.8, 1.6, nc)
+                sigma = np.where(rng.uniform(size=(nc, 125)) > 0.7, 20.0, 0.0)
+                nodes = np.unique(rng.integers(0, nc * nd, size=min(30, nc * nd)))
+                vals = rng.uniform(-1, 1, (5, len(nodes), 3, 3))
+                u0 = seeded(blk.field_shape(_lib.FIELD_U), 1)
+                s0 = seeded(blk.field_shape(_lib.FIELD_S), 2)
+                if symmetric:
+                    vals = 0.5 * (vals + np.swapaxes(vals, -1, -2))
+                    s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+            blk.set_params(1.0, 0.01 * min(h) / P ** 2, lam, mu)
+            blk.set_density(rho, physical=True)
+            blk.set_absorption(sigma, 4)
+            blk.set_source(nodes, vals)
+            blk.set_field(_lib.FIELD_U, u0)
+            blk.set_field(_lib.FIELD_S, s0)
+            assert blk.is_sym() == (symmetric and path == "hexm")
+            blk.step(5)
+            res[path] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S), blk.get_field(_lib.FIELD_UH),
+                         blk.get_field(_lib.FIELD_SH))
+            blk.close()
+        # two formulations of the same sums (the matrix kernels fold the own-trace half of the central flux into the line
+        # operators, lift entries ~ (P + 1)^2; the generic kernel adds flux terms one by one) through five steps and the
+        # derivative-like stage fields: round-off times the operators' amplification, measured 1e-11 .. 5e-11
+        for a, b in zip(res["hexm"], res["generic"]):
+            assert rel_err(a, b) < 2e-10
+
+
+@pytest.mark.parametrize("P", [3, 4])
+def test_hexahedral_matrix_kernels_stage_parity_with_the_oracle(gpu, P):
+    """apply_F / apply_G (un-fused stage entry points) of the DQ_3 / DQ_4 matrix kernels against the oracle's assembled
+    operators (seigen/elastic.py:204-219 by quadrature)."""
+    from oracle.forms import ElasticOperators
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    n, L = (3, 2, 4), (1.0, 1.5, 0.8)
+    blk = HipBlock(3, P, n, [L[a] / n[a] for a in range(3)], [0.0] * 3, "quadrilateral")
+    assert "hexm_stage<%d, 0, 0, 1>" % P in blk.stage_kernel_name(0)
+    E = ElasticOperators(omesh.structured(3, n, L, quadrilateral=True), P)
+    T = seeded(blk.field_shape(_lib.FIELD_S), 0)
+    T = 0.5 * (T + np.swapaxes(T, -1, -2))
+    u = seeded(blk.field_shape(_lib.FIELD_U), 1)
+    blk.set_params(1.0, 0.01, 0.7, 0.3)
+    blk.set_field(_lib.FIELD_S, T)
+    blk.set_field(_lib.FIELD_U, u)
+    blk.apply_F(_lib.FIELD_S, _lib.FIELD_U, _lib.FIELD_UH)
+    assert rel_err(blk.get_field(_lib.FIELD_UH), E.apply_F(T, u)) < 1e-12
+    blk.apply_G(_lib.FIELD_U, _lib.FIELD_SH)
+    assert rel_err(blk.get_field(_lib.FIELD_SH), E.apply_G(u, 0.7, 0.3)) < 1e-12
+
+
 def test_hexahedral_blocks_equal_the_single_block_on_the_lane_kernels(gpu, monkeypatch):
     monkeypatch.setenv("SEIGEN_HIP_PATH", "lane")
     from tests.test_harness_gpu import _multiblock_case
@@ -196,6 +267,9 @@ def test_hexahedral_blocks_equal_the_single_block(gpu):
     _multiblock_case(3, 2, (6, 2, 3), (2, 1, 1), True, extras=True, separable=True, diagonal="quadrilateral")
     _multiblock_case(3, 3, (4, 2, 3), (2, 1, 3), True, extras=True, diagonal="quadrilateral")
     _multiblock_case(3, 4, (2, 4, 2), (1, 2, 2), False, extras=True, diagonal="quadrilateral")
+    # DQ_3 / DQ_4 run the matrix kernels (kernels_hexm.hip): x sides with rows wider than a cell group, all three axes split
+    _multiblock_case(3, 3, (36, 4, 2), (2, 2, 1), True, extras=True, diagonal="quadrilateral")
+    _multiblock_case(3, 4, (6, 4, 4), (2, 2, 2), True, extras=True, separable=True, diagonal="quadrilateral")
 
 
 def test_graph_replay_and_repeated_calls_on_hexahedra(gpu, monkeypatch):
