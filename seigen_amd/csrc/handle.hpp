@@ -50,7 +50,7 @@ struct sg_handle {
   double* fragF = nullptr;  // MFMA operator fragment tables (device)
   double* fragG = nullptr;
   double* fragL = nullptr;
-  // G stages with the factorised volume term (kernels_mfma.hip mfma_stage_GQ; double, degrees 3 and 4;
+  // G stages with the factorised volume term (kernels_mfma.hip mfma_stage_G<.., FACT = 1>; double, degrees 3 and 4;
   // SEIGEN_HIP_GQ): the Q tiles and the P_r tiles, or null
   double* fragQ = nullptr;
   double* fragP = nullptr;

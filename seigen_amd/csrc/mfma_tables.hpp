@@ -51,7 +51,7 @@ std::vector<double> mfma_frags_G(const RefElem& re);
 // (the 1/2 of the central flux average: both kernels lift +-1/2 of a neighbour trace)
 std::vector<double> mfma_frags_L(const RefElem& re);
 
-// Factorised G volume (kernels_mfma.hip mfma_stage_GQ).  The three D_r = Mhat^-1 Shat_r of degree p have rank
+// Factorised G volume (kernels_mfma.hip mfma_stage_G<.., FACT = 1>).  The three D_r = Mhat^-1 Shat_r of degree p have rank
 // dim P_{p-1} (they differentiate: 20 of 35 at degree 4, 10 of 20 at degree 3) and SHARE their row space, so
 //     D_r = P_r Q,   Q [rk x nd] an orthonormal basis of that row space,   P_r = D_r Q^T [nd x rk]:
 // y_i = Q u_i once per velocity component, then z_ri = P_r y_i per direction, instead of three dense D_r u_i:

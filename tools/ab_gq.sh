@@ -8,7 +8,7 @@ SEIGEN_HIP_GQ=1 timeout -k 10 900 python -m pytest tests/test_parity_gpu.py test
 tail -3 $out/pytest_gq.txt | tee -a $out/log.txt
 for rep in 1 2; do
 for t in 0 1; do
-  SEIGEN_HIP_GQ=$t timeout -k 10 300 python bench.py --steps 60 --no-cpu-baseline > $out/bench_gq${t}_$rep.json 2>$out/bench_gq${t}_$rep.err || { tail -20 $out/bench_gq${t}_$rep.err; exit 1; }
+  SEIGEN_HIP_GQ=$t timeout -k 10 300 python bench.py --steps 60 --no-cpu-baseline --configs none > $out/bench_gq${t}_$rep.json 2>$out/bench_gq${t}_$rep.err || { tail -20 $out/bench_gq${t}_$rep.err; exit 1; }
   python - <<PY | tee -a $out/log.txt
 import json
 d=json.loads(open("$out/bench_gq${t}_$rep.json").read().strip().splitlines()[-1])

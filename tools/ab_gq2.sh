@@ -3,7 +3,7 @@
 for rep in 1 2; do
 for t in 0 1; do
   for args in "--degree 3" "--workload c4 --steps 10 --warmup 2"; do
-    SEIGEN_HIP_GQ=$t timeout -k 10 400 python bench.py --steps 40 --no-cpu-baseline $args > gpurun_out/gq2.json 2> gpurun_out/gq2.err || { tail -5 gpurun_out/gq2.err; continue; }
+    SEIGEN_HIP_GQ=$t timeout -k 10 400 python bench.py --steps 40 --no-cpu-baseline --configs none $args > gpurun_out/gq2.json 2> gpurun_out/gq2.err || { tail -5 gpurun_out/gq2.err; continue; }
     python - "$t" "$args" <<PY
 import json, sys
 d=json.loads(open("gpurun_out/gq2.json").read().strip().splitlines()[-1])

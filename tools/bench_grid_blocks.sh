@@ -1,7 +1,7 @@
 #!/bin/bash
 # ms per stage of config 3 against the size of the persistent grid:  tools/bench_grid_blocks.sh 512 480 448 ...
 for v in "$@"; do
-  SEIGEN_HIP_GRID_BLOCKS=$v timeout -k 10 200 python bench.py --no-cpu-baseline --steps ${STEPS:-100} > gpurun_out/bench_var.json 2> gpurun_out/bench_var.err
+  SEIGEN_HIP_GRID_BLOCKS=$v timeout -k 10 200 python bench.py --no-cpu-baseline --configs none --steps ${STEPS:-100} > gpurun_out/bench_var.json 2> gpurun_out/bench_var.err
   python - "$v" <<PY
 import json, sys
 try:

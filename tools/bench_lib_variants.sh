@@ -3,7 +3,7 @@
 # (STEPS=60 by default; extra environment, e.g. SEIGEN_HIP_ORDER_CHUNK, is passed through)
 for v in "$@"; do
   lib=""; [ "$v" != "default" ] && lib="$PWD/build_tools/libseigen_hip_$v.so"
-  SEIGEN_HIP_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --steps ${STEPS:-60} > gpurun_out/bench_var.json 2> gpurun_out/bench_var.err
+  SEIGEN_HIP_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --configs none --steps ${STEPS:-60} > gpurun_out/bench_var.json 2> gpurun_out/bench_var.err
   python - "$v" <<PY
 import json, sys
 try:

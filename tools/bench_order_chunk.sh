@@ -1,7 +1,7 @@
 #!/bin/bash
 # ms per stage of config 3 for several SEIGEN_HIP_ORDER_CHUNK values:  tools/bench_order_chunk.sh 0 96 192 ...
 for v in "$@"; do
-  SEIGEN_HIP_ORDER_CHUNK=$v timeout -k 10 200 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/bench_var.json 2> gpurun_out/bench_var.err
+  SEIGEN_HIP_ORDER_CHUNK=$v timeout -k 10 200 python bench.py --no-cpu-baseline --configs none --steps 60 > gpurun_out/bench_var.json 2> gpurun_out/bench_var.err
   python - "$v" <<PY
 import json, sys
 try:

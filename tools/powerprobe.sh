@@ -8,5 +8,5 @@ mkdir -p gpurun_out
    sleep 0.25
  done) > gpurun_out/power_samples.txt &
 SPID=$!
-python bench.py --steps 600 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-220
+python bench.py --steps 600 --warmup 2 --no-cpu-baseline --configs none 2>&1 | tail -1 | cut -c1-220
 wait $SPID
