@@ -435,9 +435,11 @@ def main():
                     help="multi-GPU weak-scaling runs: persistent-grid sizes (SEIGEN_HIP_GRID_BLOCKS) of the launches that "
                          "overlap an exchange to time after the main measurement, reported as halo.grid_blocks_sweep "
                          "(empty string: none)")
-    ap.add_argument("--configs", default="c1,c2,c5,c4_share,ref_strong_2d_N256_P4_T2",
+    ap.add_argument("--configs", default=None,
                     help="one GPU, default headline: the other single-GPU configurations of BASELINE.json and the reference's "
-                         "own benchmark protocol, measured after the headline and reported as \"configs\" (\"none\": skip)")
+                         "own benchmark protocol, measured after the headline and reported as \"configs\": a comma-separated list "
+                         "of c1, c2, c5, c4_share, ref_strong_2d_N256_P4_T2 (default: all of them with the default headline, "
+                         "else none; \"none\": skip)")
     ap.add_argument("--config-timeout", type=float, default=75.0, help="deadline of each entry of --configs, seconds")
     ap.add_argument("--timeout", type=float, default=900.0,
                     help="seconds after which a rank that has not finished dumps its stacks and exits non-zero")
@@ -638,8 +640,11 @@ def main():
     want_c4 = args.workload is None and world == 8 and P == 4 and not os.environ.get("SEIGEN_BENCH_NO_C4")
     # one GPU, the default headline: every other single-GPU configuration of BASELINE.json and the reference's own
     # benchmark protocol, driver-timed in the same job (--configs none: skip)
-    want_configs = (world == 1 and args.workload is None and n == 64 and P == 4 and args.dtype == "f64" and
-                    args.configs != "none")
+    # (--configs given explicitly: whatever the headline's size is - tests use a small one)
+    default_headline = n == 64 and P == 4 and args.dtype == "f64"
+    if args.configs is None:
+        args.configs = "c1,c2,c5,c4_share,ref_strong_2d_N256_P4_T2" if default_headline else "none"
+    want_configs = world == 1 and args.workload is None and args.configs != "none"
     if want_sweep or want_c4 or want_configs:
         faulthandler.cancel_dump_traceback_later()
         elastic._exchanger = None

@@ -82,9 +82,9 @@ def config4_share(nsteps, n=128, degree=4):
     return el, "c4s: one rank's share of config 4: %d^3 cubes x 6 tets, P%d, box-Ricker source" % (n, degree)
 
 
-def config3_hex(nsteps, P):
+def config3_hex(nsteps, P, N=None):
     """tests/eigenmode/eigenmode_3d.py on UnitCubeMesh(N, N, N, hexahedral=True): the analytic mode as initial state"""
-    N = {1: 96, 2: 96, 3: 48, 4: 40}[P]
+    N = N or {1: 96, 2: 96, 3: 48, 4: 40}[P]
     em = Eigenmode3DLF4(N, P, 0.5 * (1.0 / N) / 2.0 ** (P - 1), output=False, hexahedral=True)
     el = em.elastic
     el.u0.assign(Function(el.U).interpolate(em._u(0)))

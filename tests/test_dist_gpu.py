@@ -182,3 +182,27 @@ def test_bench_config4_workload_on_ranks_sharing_one_gpu(gpu):
     assert len(out["halo"]["kernel_ms_per_step"]) == 4 and "host_blocked_ms_per_step" in out["halo"]
     # every stage counted once per step although split stages are two concurrent launches
     assert sum(out["roofline"]["stage_avg_ms"]) <= out["ms_per_step"] * 1.5
+
+
+def test_bench_line_carries_the_other_configs(gpu):
+    """One GPU: the bench line's "configs" object - BASELINE configs measured in the same job as the
+    headline, each with value, ms_per_step, steps and the algorithmic and physical roofline fractions, the kernels named by
+    the library; here configs 1 and 5 behind a small headline (the default run adds c2, config 4's share and the
+    reference's 2-D N = 256 protocol), without the CPU baselines."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "8", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--configs", "c1,c5"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "cpu_baseline" not in out
+    assert out["roofline"]["kernel"].startswith("sg::mfma_stage_") and out["roofline"]["kernel"] in out["roofline"]["kernels"]
+    assert sorted(out["configs"]) == ["c1", "c5"]
+    for key, cells in (("c1", 3200), ("c5", 92686)):
+        c = out["configs"][key]
+        assert "error" not in c, c
+        assert c["cells"] == cells and c["value"] > 0 and c["ms_per_step"] > 0 and c["steps"] > 0
+        rf = c["roofline"]
+        assert 0 < rf["frac_physical"] < rf["frac"] < 1 and rf["bound"] == "hbm"
+        assert rf["dominant_kernel"].startswith("sg::tile2d_stage<") and len(rf["kernels"]) == 4
+        assert "cpu_baseline" not in c

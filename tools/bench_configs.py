@@ -89,8 +89,11 @@ def config4_share(steps, warmup, n=128):
     return timed(lambda ns: bc.config4_share(ns, n=n), steps, warmup)
 
 
+HEX_N = None
+
+
 def config3_hex(steps, warmup, P):
-    return timed(lambda ns: bc.config3_hex(ns, P), steps, warmup)
+    return timed(lambda ns: bc.config3_hex(ns, P, HEX_N), steps, warmup)
 
 
 def config1(steps, warmup):
@@ -102,9 +105,11 @@ if __name__ == "__main__":
     ap.add_argument("configs", nargs="*", default=["c2", "c5", "c1"])
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--hex-n", type=int, default=None, help="c3h*: cubes per axis instead of the default 96 / 96 / 48 / 40")
     ap.add_argument("--stages", action="store_true", help="also report device microseconds per stage (UH1 STEMP U1 SH1 UTEMP S1)")
     args = ap.parse_args()
     STAGES = args.stages
+    HEX_N = args.hex_n
     for c in args.configs:
         r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share,
              "c2q": config2_quad,
