@@ -207,6 +207,46 @@ def test_config3_full_size_mfma_vs_generic(gpu, monkeypatch):
         assert np.abs(a - b).max() / scale[f] < tol[f], (f, c0, np.abs(a - b).max() / scale[f])
 
 
+@pytest.mark.parametrize("P,n", [(3, 48), (4, 40)])
+def test_config3_on_hexahedra_full_size_matrix_vs_generic(gpu, monkeypatch, P, n):
+    """Config 3's eigenmode on HEXAHEDRA at the sizes the bench quotes (DQ_3 48^3, DQ_4 40^3): three LF4 steps on
+    the production path (kernels_hexm.hip: plane by plane, x lines on the matrix pipe, gw = 16 layout, symmetric storage)
+    against the independently written thread-per-node generic kernels (host layout, full tensor), sampled over the whole
+    block, and against the analytic mode the run started from (eigenmode_3d.py:30-40).  Tolerances as for the tetrahedra:
+    the stage fields carry the operators' round-off amplification."""
+    _quiet()
+    from seigen_amd import Function, _lib
+    from seigen_amd.harness.eigenmode import Eigenmode3DLF4
+    import seigen_amd.harness.eigenmode as he
+    monkeypatch.setattr(he, "log", lambda s: None)
+    steps, samples, exact = 3, {}, {}
+    for path in ("generic", "hexm"):
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        em = Eigenmode3DLF4(n, P, 0.5 * (1.0 / n) / 2.0 ** (P - 1), output=False, hexahedral=True)
+        el = em.elastic
+        el.u0.assign(Function(el.U).interpolate(em._u(0)))
+        el.s0.assign(Function(el.S).interpolate(em._s(el.dt / 2)))
+        el.setup()
+        blk = el.block
+        assert ("hexm_stage" in blk.stage_kernel_name(0)) == (path == "hexm")
+        blk.set_source([], None)
+        blk.step(steps)
+        samples[path] = [(f, c0, blk.get_field_range(f, c0, nc)) for f in (_lib.FIELD_U, _lib.FIELD_S, _lib.FIELD_UH, _lib.FIELD_SH)
+                         for c0, nc in _sample_ranges(blk.ncells, per=64, count=9)]
+        if path == "hexm":
+            ue = Function(el.U).interpolate(em._u(steps * el.dt)).dat.data_cells
+            exact = {c0: ue[c0:c0 + nc] for f, c0, a in samples[path] if f == _lib.FIELD_U for nc in (a.shape[0],)}
+        blk.close()
+        del el, em
+    tol = {_lib.FIELD_U: 1e-11, _lib.FIELD_S: 1e-11, _lib.FIELD_SH: 1e-9, _lib.FIELD_UH: 1e-7}
+    scale = {f: max(np.abs(b).max() for g, _, b in samples["generic"] if g == f) for f in tol}
+    assert all(v > 1e-3 for v in scale.values()), scale
+    for (f, c0, a), (_, _, b) in zip(samples["hexm"], samples["generic"]):
+        assert np.abs(a - b).max() / scale[f] < tol[f], (f, c0, np.abs(a - b).max() / scale[f])
+        if f == _lib.FIELD_U:       # three steps of a degree-3 / 4 scheme on this mesh stay within 1e-6 of the analytic mode
+            assert np.abs(a - exact[c0]).max() < 1e-6, (c0, np.abs(a - exact[c0]).max())
+
+
 def test_config4_share_full_size_properties(gpu):
     """One rank's share of BASELINE config 4 (3-D 256^3 on 8 GPUs): a 128^3-cube block, P4, 12.6 M cells, 5.3 G DoF,
     85 GB resident.  g of a linear velocity field = the constant Hooke stress everywhere (sampled), and exact time
