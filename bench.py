@@ -21,6 +21,14 @@ state, box-Ricker stress source, block-split over the ranks: fixed global size, 
 tests/eigenmode/README.md:7-13); it needs 4 or 8 GPUs (676 GB of fields; on one GPU it runs one rank's 128^3 share).
 With 8 ranks and no --workload the weak-scaling line carries an extra object "config4" measured in the same job.
 
+One GPU, default headline: the same JSON line carries "configs" - every other single-GPU configuration of BASELINE.json and
+the reference's own benchmark protocol, measured after the headline in the same job (seigen_amd/harness/baseline_configs.py):
+c1 (2-D eigenmode 40 x 40, P1), c2 (2-D explosive source 512^2, P2), c5 (Marmousi, P3), c4_share (one rank's 128^3 share of
+config 4), ref_strong_2d_N256_P4_T2 (tests/eigenmode/README.md:7-13 through the solver class) - each with value, ms_per_step,
+steps, the algorithmic and physical roofline fractions, the kernels as the library names them, and for c1 / c2 / c5 a CPU
+baseline of the oracle's C port (oracle/baselines.py).  Each entry runs under its own deadline; none can lose
+the headline.  The whole default run takes under a minute.
+
 Watchdogs: every rank arms faulthandler.dump_traceback_later(--timeout): a rank that hangs in init or in an exchange
 dumps its stacks and exits non-zero; the self-launching parent (which never touches a GPU) additionally kills the
 child process group --timeout + 30 s after starting it.
