@@ -596,3 +596,24 @@ def test_node_coordinates_do_not_depend_on_the_partition():
     cube = (ax[0][None, None, :] + n[0] * (ax[1][None, :, None] + n[1] * ax[2][:, None, None])).reshape(-1)
     cells = (cube[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
     assert np.array_equal(X, full[cells])
+
+
+def test_partition_peers_satisfy_the_native_exchange_preconditions():
+    """What sg_comm_check (csrc/comm.cpp) demands of the peers[] a rank hands to sg_comm_init, for every block grid
+    mesh._factor_grid picks for 2, 4, 6 and 8 ranks (bench.py's weak-scaling and config-4 layouts among them): a peer on
+    exactly the sides of nbr_mask, never the rank itself, no rank behind two different axes, and the relation is mutual -
+    my peer across side s names me across side s ^ 1 (the pairing the exchange relies on when it posts its receives)."""
+    from seigen_amd.mesh import Partition, _factor_grid
+    for world, n in ((2, (64, 64, 64)), (4, (64, 64, 64)), (8, (64, 64, 64)), (8, (256, 256, 256)), (6, (4, 100)), (8, (16, 64, 64))):
+        dim = len(n)
+        grid = _factor_grid(world, dim, n)
+        gn = tuple(n[a] * grid[a] for a in range(dim))
+        parts = [Partition(gn, r, world, grid) for r in range(world)]
+        for r, p in enumerate(parts):
+            peers = [p.neighbour(s) for s in range(2 * dim)]
+            assert p.nbr_mask == sum(1 << s for s in range(2 * dim) if peers[s] is not None)
+            named = [(s, q) for s, q in enumerate(peers) if q is not None]
+            assert all(q != r and 0 <= q < world for _, q in named)
+            for s, q in named:
+                assert parts[q].neighbour(s ^ 1) == r, (world, grid, r, s, q)
+                assert all((s >> 1) == (t >> 1) for t, q2 in named if q2 == q), "one rank behind two axes"
