@@ -55,9 +55,14 @@ enum sg_stage {
   SG_STAGE_STEMP = 1, /* stemp = Minv g(uh1)                              :293 */
   SG_STAGE_U1 = 2,    /* u1 = rho*u0 + dt*uh1 + dt^3/24 * Minv f(stemp; u0); u0<-u1   :294-296 */
   SG_STAGE_SH1 = 3,   /* sh1   = Minv g(u1)                               :300 */
-  SG_STAGE_UTEMP = 4, /* utemp = Minv f(sh1; u1)                          :301 */
-  SG_STAGE_S1 = 5     /* s1 = s0 + dt*sh1 + dt^3/24 * Minv g(utemp); s0<-s1           :302-304 */
+  SG_STAGE_UTEMP = 4, /* utemp = Minv f(sh1; u1)                          :301   - left in UH as w = dt*u1 + dt^3/24*utemp */
+  SG_STAGE_S1 = 5     /* s1 = s0 + dt*sh1 + dt^3/24 * Minv g(utemp); s0<-s1           :302-304 - computed as s0 + Minv g(w) */
 };
+/* g is linear in the velocity, and utemp has no other consumer than sh2 = Minv g(utemp): dt*sh1 + dt^3/24*sh2 =
+ * Minv g(dt*u1 + dt^3/24*utemp) (+ (dt + dt^3/24) S with a source).  Stage UTEMP therefore leaves that ONE velocity w in
+ * the UH buffer (its fused epilogue reads u1 beside its result) and stage S1 reads w and s0 only - neither sh1 nor a
+ * second right-hand side: 6 of the 21 words per node the stress update moved.  (u1, s1) are the reference's to round-off;
+ * what a caller finds in SG_FIELD_UH after a step is w, not utemp.  SG_FIELD_SH holds sh1 as before. */
 
 /* which cubes of the block a stage launch covers (halo overlap) */
 enum sg_region {

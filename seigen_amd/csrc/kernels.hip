@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
           ca *= A.rho2[2 * g2 + 1];
           cn *= A.rho2[2 * g2 + 1];
         }
-        A.out[o] = cs * A.out[o] + ca * A.aux[o] + cn * sOut[idx];
+        // (a fused G stage has no second operand: out = c_self out + c_new rhs, stages.cpp)
+        A.out[o] = KIND == 0 ? cs * A.out[o] + ca * A.aux[o] + cn * sOut[idx] : cs * A.out[o] + cn * sOut[idx];
       }
     }
   };
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
             else if (A.mode == 0)
               A.out[o + i * DIM + j] = v;
             else
-              A.out[o + i * DIM + j] = A.c_self * A.out[o + i * DIM + j] + A.c_aux * A.aux[o + i * DIM + j] + A.c_new * v;
+              A.out[o + i * DIM + j] = A.c_self * A.out[o + i * DIM + j] + A.c_new * v;
           }
       }
       if (SF) write_back();

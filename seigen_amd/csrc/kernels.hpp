@@ -114,11 +114,12 @@ struct StageArgs {
   const double* lam;           // per-cell (per_cell=1) or null
   const double* mu;
   double lam0, mu0;
-  double c_self, c_aux, c_new;  // mode 1: out = c_self*out + c_aux*aux + c_new*rhs
+  double c_self, c_aux, c_new;  // mode 1, F stages: out = c_self*out + c_aux*aux + c_new*rhs;  G stages: out = c_self*out + c_new*rhs
+                                // (no second operand: the one fused G stage, S1, gets dt sh1 + dt^3/24 sh2 as ONE G, stages.cpp)
   // F, mode 1, per-cell density: rho2[cell][2] = {factor replacing c_self, factor multiplying c_aux and c_new}
   // (reference update: {rho, 1}; physical update: {1, 1/rho}); null: the scalars above
   const double* rho2;
-  int32_t mode;                 // 0: out = rhs
+  int32_t mode;                 // 0: out = rhs; 1: fused (see c_self ..); 2 (F stages): fused without the self term, out = c_aux*aux + c_new*rhs
   int32_t per_cell;
   int32_t box_o[3], box_n[3];   // region of cubes covered by this launch (generic kernel: one box per launch)
   // MFMA / lane kernels: one launch covers up to SG_MAX_BOXES disjoint boxes (a boundary shell + half an interior); `spread` deals
@@ -147,6 +148,7 @@ struct StageArgs {
   const int32_t* src_idx;
   const double* src_vals;
   double src_scale;          // factor on src_vals (a separable source's weight of this step, else 1)
+  double src_coef;           // ... and on the scaled, rounded value as it enters the right-hand side (stage S1: dt + dt^3/24, else 1)
   SrcStep src_step;          // graph replay: slice and weight from the device-side step counter (ctr != null)
   int32_t src_bump;          // 2-D tile path, first stage of a step (an F stage): bump that counter (one thread)
 };

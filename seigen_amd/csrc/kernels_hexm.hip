@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
     };
 #define HXM_FENCE() __builtin_amdgcn_sched_barrier(0)
     // ---- results: plane i2 of component `cmp` of the output field (nco components per node)
+    // (a fused G stage has no second operand: out = c_self out + c_new rhs, stages.cpp - pa is then left alone)
     auto old_plane = [&](int nco, int cmp, int i2, double (&po)[KSX][N1], double (&pa)[KSX][N1]) __attribute__((always_inline)) {
       const long gbase = (g * (long)ND) * nco * 16;
       int lo[KSX];
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
           const int o = lo[ks] + i1 * N1 * nco * 16;
-          po[ks][i1] = HXM_LDS(&out[gbase + o]);
-          pa[ks][i1] = HXM_LDS(&aux[gbase + o]);
+          if (!(KIND == 0 && MODE == 2)) po[ks][i1] = HXM_LDS(&out[gbase + o]);     // (F, MODE 2: no self term)
+          if (KIND == 0) pa[ks][i1] = HXM_LDS(&aux[gbase + o]);
         }
     };
     // one branch around all of a k-step's stores (a branch per store would end the scheduling region at every store)
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
           ytr_plane(c1, i, i2, y0[s2], y1[s2]);
           load_plane(c1, i2, Vb[s2]);
         };
-        constexpr bool AHEAD = !(MODE == 1 && P >= 4);   // (the fused stage at degree 4: no room for a second set of plane operands)
+        constexpr bool AHEAD = !(MODE >= 1 && P >= 4);   // (the fused F stages at degree 4: no room for a second set of plane operands)
         HXM_FENCE();
         ztr_full(c2, i, tz0, tz1);
         load_full(c2, Uz);
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
           } else {
             request(i2, 0);
           }
-          if (MODE == 1) old_plane(3, i, i2, po, pa);     // (behind the plane operands: needed last)
+          if (MODE >= 1) old_plane(3, i, i2, po, pa);     // (behind the plane operands: needed last)
           HXM_FENCE();
           double o[KSX][N1];
           clear_plane(o);
@@ -399,11 +400,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
                 }
             }
           }
-          if (MODE == 1) {
+          if (MODE >= 1) {     // (MODE 2, stage UTEMP: out = c_aux aux + c_new rhs, stages.cpp)
 #pragma unroll
             for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
-              for (int i1 = 0; i1 < N1; ++i1) o[ks][i1] = cs * po[ks][i1] + ca * pa[ks][i1] + cn * o[ks][i1];
+              for (int i1 = 0; i1 < N1; ++i1) o[ks][i1] = MODE == 1 ? cs * po[ks][i1] + ca * pa[ks][i1] + cn * o[ks][i1] : ca * pa[ks][i1] + cn * o[ks][i1];
           }
           pin_plane(o);
           HXM_FENCE();
@@ -415,13 +416,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
       // ---- G: W_ik = line_k(u_i); sh_ii = 2 mu W_ii + lam tr W, sh_ij = mu (W_ij + W_ji) (elastic.py:211-219)
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
-      const double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      const double cs = A.c_self, cn = A.c_new;
       auto emit = [&](int cmp, int i2, double (&v)[KSX][N1], const double (&po)[KSX][N1], const double (&pa)[KSX][N1]) __attribute__((always_inline)) {
         if (MODE == 1) {
 #pragma unroll
           for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
-            for (int i1 = 0; i1 < N1; ++i1) v[ks][i1] = cs * po[ks][i1] + ca * pa[ks][i1] + cn * v[ks][i1];
+            for (int i1 = 0; i1 < N1; ++i1) v[ks][i1] = cs * po[ks][i1] + cn * v[ks][i1];
         }
         pin_plane(v);
       };
@@ -456,9 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
         double V0[2][KSX][N1], V1[2][KSX][N1], x0[2][N1], x1[2][N1], y00[2][KSX], y01[2][KSX], y10[2][KSX], y11[2][KSX];
         double po[4][KSX][N1], pa[4][KSX][N1];
         constexpr int OC[4] = {0, 4, 8, 1};
-        // the fused stage has no room for a second set of plane operands beside the old values of four results: it requests
-        // a plane when it gets to it
-        constexpr bool AHEAD = MODE == 0;
+        constexpr bool AHEAD = true;      // (the next plane's operands are requested while this plane is worked on)
         auto request = [&](int i2, int s2) __attribute__((always_inline)) {
           xtr_plane(0, 0, i2, x0[s2]);
           xtr_plane(1, 1, i2, x1[s2]);
@@ -549,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
 #pragma unroll
               for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
-                for (int i1 = 0; i1 < N1; ++i1) w10[SYM ? 0 : ks][SYM ? 0 : i1] = cs * qo[ks][i1] + ca * qa[ks][i1] + cn * w10[SYM ? 0 : ks][SYM ? 0 : i1];
+                for (int i1 = 0; i1 < N1; ++i1) w10[SYM ? 0 : ks][SYM ? 0 : i1] = cs * qo[ks][i1] + cn * w10[SYM ? 0 : ks][SYM ? 0 : i1];
             }
             HXM_FENCE();
             double (&m10)[KSX][N1] = reinterpret_cast<double (&)[KSX][N1]>(w10);
@@ -615,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
 #pragma unroll
               for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
-                for (int i1 = 0; i1 < N1; ++i1) m2[ks][i1] = cs * qo[ks][i1] + ca * qa[ks][i1] + cn * m2[ks][i1];
+                for (int i1 = 0; i1 < N1; ++i1) m2[ks][i1] = cs * qo[ks][i1] + cn * m2[ks][i1];
             }
             pin_plane(m2);
             HXM_FENCE();
@@ -649,6 +648,8 @@ static int launch_hexm_p(int kind, const StageArgs& a, long nitems, hipStream_t 
   if (kind == 0) {
     if (a.mode == 0)
       SG_HEXM_LAUNCH(0, 0);
+    else if (a.mode == 2)
+      SG_HEXM_LAUNCH(0, 2);
     else
       SG_HEXM_LAUNCH(0, 1);
   } else {

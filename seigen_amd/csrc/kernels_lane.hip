@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       const double lam = A.per_cell ? A.lam[e] : A.lam0;
       const double mu = A.per_cell ? A.mu[e] : A.mu0;
       const long sbase = ((g * NCLS + k) * (long)ND) * DIM * DIM * 64 + lane;
-      double po[DIM * DIM], pa[DIM * DIM];   // in-place combine operands, one node ahead
+      double po[DIM * DIM];   // in-place combine operand, one node ahead (a fused G stage: out = c_self out + c_new rhs)
       // Fused stage: loads and stores share one counter and complete out of order with each
       // other, so a wait for a load with stores in flight waits for every store's acknowledgement
       // (kernels_mfma.hip).  Where the cell's results fit in registers they are all kept until the
@@ -277,10 +277,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < DIM * DIM; ++c)
-          if (!SYM || (c / DIM) <= (c % DIM)) {
-            po[c] = out[sbase + c * 64];
-            pa[c] = aux[sbase + c * 64];
-          }
+          if (!SYM || (c / DIM) <= (c % DIM)) po[c] = out[sbase + c * 64];
       }
 #pragma unroll
       for (int a = 0; a < ND; ++a) {
@@ -333,15 +330,12 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
           for (int j = 0; j < DIM; ++j) {
             v[i * DIM + j] = mu * (W[i][j] + W[j][i]) + ((i == j) ? lam * trc : 0.0);
             if (MODE == 1 && (!SYM || i <= j))
-              v[i * DIM + j] = A.c_self * po[i * DIM + j] + A.c_aux * pa[i * DIM + j] + A.c_new * v[i * DIM + j];
+              v[i * DIM + j] = A.c_self * po[i * DIM + j] + A.c_new * v[i * DIM + j];
           }
         if (MODE == 1 && a + 1 < ND) {
 #pragma unroll
           for (int c = 0; c < DIM * DIM; ++c)
-            if (!SYM || (c / DIM) <= (c % DIM)) {
-              po[c] = out[sbase + ((a + 1) * DIM * DIM + c) * 64];
-              pa[c] = aux[sbase + ((a + 1) * DIM * DIM + c) * 64];
-            }
+            if (!SYM || (c / DIM) <= (c % DIM)) po[c] = out[sbase + ((a + 1) * DIM * DIM + c) * 64];
         }
         if (DEFER) {
 #pragma unroll
@@ -563,16 +557,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
             }
           }
       };
-      auto load_old = [&](int c, double (&po)[ND], double (&pa)[ND]) __attribute__((always_inline)) {
+      // (a fused G stage: out = c_self out + c_new rhs, no second operand - stages.cpp)
+      auto load_old = [&](int c, double (&po)[ND]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int a = 0; a < ND; ++a) {
-          po[a] = out[sbase + (a * DIM * DIM + c) * 64];
-          pa[a] = aux[sbase + (a * DIM * DIM + c) * 64];
-        }
+        for (int a = 0; a < ND; ++a) po[a] = out[sbase + (a * DIM * DIM + c) * 64];
       };
-      auto combine = [&](double (&v)[ND], const double (&po)[ND], const double (&pa)[ND]) __attribute__((always_inline)) {
+      auto combine = [&](double (&v)[ND], const double (&po)[ND]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int a = 0; a < ND; ++a) v[a] = A.c_self * po[a] + A.c_aux * pa[a] + A.c_new * v[a];
+        for (int a = 0; a < ND; ++a) v[a] = A.c_self * po[a] + A.c_new * v[a];
       };
       auto store = [&](int c, const double (&v)[ND]) __attribute__((always_inline)) {
         if (L.active) {
@@ -587,23 +579,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
 #pragma unroll
         for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(v[a]));
       };
-      // Three finished results -> components c0, c1, c2 of a fused stage: the old values of two results are read first
-      // and combined, the third's are requested before those two are stored (no load behind a store): two exposed
-      // load latencies instead of three.
+      // Three finished results -> components c0, c1, c2 of a fused stage: all old values are requested before the first
+      // store (no load behind a store): one exposed load latency.
       auto combine3 = [&](int c0, int c1, int c2, double (&v0)[ND], double (&v1)[ND], double (&v2)[ND]) __attribute__((always_inline)) {
-        double po[ND], pa[ND], po1[ND], pa1[ND];
-        load_old(c0, po, pa);
-        load_old(c1, po1, pa1);
-        combine(v0, po, pa);
-        combine(v1, po1, pa1);
+        double po[ND], po1[ND], po2[ND];
+        load_old(c0, po);
+        load_old(c1, po1);
+        load_old(c2, po2);
+        combine(v0, po);
+        combine(v1, po1);
+        combine(v2, po2);
         pin(v0);
         pin(v1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_old(c2, po, pa);
+        pin(v2);
         __builtin_amdgcn_sched_barrier(0);
         store(c0, v0);
         store(c1, v1);
-        combine(v2, po, pa);
         store(c2, v2);
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -690,9 +681,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
 #pragma unroll
           for (int a = 0; a < ND; ++a) w2[a] = pr[p][a];
           if (MODE == 1) {
-            double po[ND], pa[ND];
-            load_old(j * DIM + i, po, pa);
-            combine(w2, po, pa);
+            double po[ND];
+            load_old(j * DIM + i, po);
+            combine(w2, po);
           }
           store(j * DIM + i, w2);
         }

@@ -425,9 +425,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
   typedef __attribute__((address_space(4))) const MeshDev cMeshDev;
   const cMeshDev* md = (const cMeshDev*)(unsigned long long)A.md;
   const R* __restrict__ in = reinterpret_cast<const R*>(A.in);
-  const R* __restrict__ aux = reinterpret_cast<const R*>(A.aux);
   R* __restrict__ out = reinterpret_cast<R*>(A.out);
-  const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
+  const R c_self = (R)A.c_self, c_new = (R)A.c_new;
   const long ngroups = sMd.ncube_pad >> 4;
   const ItemRange ir = item_range(A.item_list ? (long)A.nlist : ngroups * 6, wave, A.spread, A.order_chunk);
 
@@ -733,7 +732,8 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
 
     SG_PRIO(SG_PRIO_EPI);
     STAMP(st3);
-    // ---- stress and epilogue (MODE 1: s = c_self*s + c_aux*sh1 + c_new*rhs in place, elastic.py:348-352)
+    // ---- stress and epilogue (MODE 1: s = c_self*s + c_new*rhs in place - the rhs being G(dt u1 + dt^3/24 utemp),
+    //      which is dt sh1 + dt^3/24 sh2 of elastic.py:348-352 in one application of the linear g, stages.cpp)
     //      vmcnt counts loads and stores together and the two kinds complete out of order with
     //      each other, so any wait for a load (or a scratch reload) with stores in flight becomes a
     //      wait for every store's acknowledgement.  Hence: finish ALL loads first, building the
@@ -752,15 +752,12 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
       if constexpr (SYM || MODE == 0) {
         constexpr int NL = SYM ? 6 : 9;  // SYM: the lines (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
         constexpr int PDE = 4;           // row-quads of old values in flight (MODE 1)
-        R po[PDE][6], pa[PDE][6];
+        R po[PDE][6];
         auto line = [](int c) { return SYM ? (c < 3 ? c : (c < 5 ? c + 1 : 8)) : c; };
         auto fetch_old = [&](int m) {
           const long o1 = orow(m);
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            po[m % PDE][c] = LD_STREAM(&out[o1 + line(c) * 16]);
-            pa[m % PDE][c] = LD_STREAM(&aux[o1 + line(c) * 16]);
-          }
+          for (int c = 0; c < 6; ++c) po[m % PDE][c] = LD_STREAM(&out[o1 + line(c) * 16]);
         };
         if (MODE == 1) {
 #pragma unroll
@@ -776,12 +773,12 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
           }
           if (MODE == 1) {
             // line order of the six slots: Sd0 So0 So1 Sd1 So2 Sd2
-            Sd[0][m] = c_self * po[m % PDE][0] + c_aux * pa[m % PDE][0] + c_new * Sd[0][m];
-            So[0][m] = c_self * po[m % PDE][1] + c_aux * pa[m % PDE][1] + c_new * So[0][m];
-            So[1][m] = c_self * po[m % PDE][2] + c_aux * pa[m % PDE][2] + c_new * So[1][m];
-            Sd[1][m] = c_self * po[m % PDE][3] + c_aux * pa[m % PDE][3] + c_new * Sd[1][m];
-            So[2][m] = c_self * po[m % PDE][4] + c_aux * pa[m % PDE][4] + c_new * So[2][m];
-            Sd[2][m] = c_self * po[m % PDE][5] + c_aux * pa[m % PDE][5] + c_new * Sd[2][m];
+            Sd[0][m] = c_self * po[m % PDE][0] + c_new * Sd[0][m];
+            So[0][m] = c_self * po[m % PDE][1] + c_new * So[0][m];
+            So[1][m] = c_self * po[m % PDE][2] + c_new * So[1][m];
+            Sd[1][m] = c_self * po[m % PDE][3] + c_new * Sd[1][m];
+            So[2][m] = c_self * po[m % PDE][4] + c_new * So[2][m];
+            Sd[2][m] = c_self * po[m % PDE][5] + c_new * Sd[2][m];
             if (m + PDE < S4) fetch_old(m + PDE);
           }
 #pragma unroll
@@ -821,7 +818,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
           s[2] = s[6] = mu * So[1][m];
           s[5] = s[7] = mu * So[2][m];
 #pragma unroll
-          for (int ij = 0; ij < 9; ++ij) s[ij] = c_self * out[o + ij * 16] + c_aux * aux[o + ij * 16] + c_new * s[ij];
+          for (int ij = 0; ij < 9; ++ij) s[ij] = c_self * out[o + ij * 16] + c_new * s[ij];
           if (L.active && a < ND) {
 #pragma unroll
             for (int ij = 0; ij < 9; ++ij) out[o + ij * 16] = s[ij];
@@ -842,7 +839,7 @@ template <typename R, int P, int MODE, int SYM, int GHOST>
 __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
-  constexpr int PRIO3 = MODE ? SG_PRIO_F1 : SG_PRIO_F0;
+  constexpr int PRIO3 = MODE == 1 ? SG_PRIO_F1 : SG_PRIO_F0;    // (MODE 2, stage UTEMP, waits for the matrix pipe like the plain stage)
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
   __shared__ R sAV[M::NFRAG_F * 64];
   __shared__ R sAL[M::NFRAG_L * 64];
@@ -916,7 +913,10 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
     // F<4,0>).  Rounding: the sum is formed at the scale of u / c_new, i.e. with the absolute error the final u carries
     // anyway.  c_new = 0 (dt = 0) keeps the late form.
     // (double only: in float u / c_new could leave the exponent range for small dt)
-    const bool early = MODE == 1 && sizeof(R) == 8 && uniform_nonzero(c_new);
+    // MODE 2: the same without the self term, out = c_aux aux + c_new rhs (stage UTEMP leaves w = dt u1 + dt^3/24 utemp,
+    // stages.cpp): no old value of `out` is read.
+    constexpr bool FUSED = MODE >= 1, SELF = MODE == 1;
+    const bool early = FUSED && sizeof(R) == 8 && uniform_nonzero(c_new);
     R cs = c_self, ca = c_aux, cn = c_new;
     if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
       cs = (R)A.rho2[2 * e];
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
           const long o = row_ok ? ub_q + (long)(16 * t + 4 * reg) * 3 * 16 : ubase;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            po[t][reg][i] = LD_STREAM(&out[o + i * 16]);
+            po[t][reg][i] = SELF ? LD_STREAM(&out[o + i * 16]) : R(0);
             pa[t][reg][i] = LD_STREAM(&aux[o + i * 16]);
           }
         }
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
         const long o = (a < ND) ? ub_q + (long)(16 * MTF + 4 * t) * 3 * 16 : ubase;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          pos[t][i] = LD_STREAM(&out[o + i * 16]);
+          pos[t][i] = SELF ? LD_STREAM(&out[o + i * 16]) : R(0);
           pas[t][i] = LD_STREAM(&aux[o + i * 16]);
         }
       }
@@ -958,11 +958,11 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) acc[i][t][reg] = (cs * po[t][reg][i] + ca * pa[t][reg][i]) * icn;
+          for (int i = 0; i < 3; ++i) acc[i][t][reg] = SELF ? (cs * po[t][reg][i] + ca * pa[t][reg][i]) * icn : (ca * pa[t][reg][i]) * icn;
 #pragma unroll
       for (int t = 0; t < NSM; ++t)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) accs[i][t] = (cs * pos[t][i] + ca * pas[t][i]) * icn;
+        for (int i = 0; i < 3; ++i) accs[i][t] = SELF ? (cs * pos[t][i] + ca * pas[t][i]) * icn : (ca * pas[t][i]) * icn;
     } else {
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
 
     // ---- epilogue (MODE 1: u = c_self*u + c_aux*uh1 + c_new*rhs in place, elastic.py:341-345).
     //      All loads first (results built in place in the accumulators), all stores last: see G.
-    if (MODE == 1 && early) {
+    if (FUSED && early) {
 #pragma unroll
       for (int t = 0; t < MTF; ++t)
 #pragma unroll
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       for (int t = 0; t < NSM; ++t)
 #pragma unroll
         for (int i = 0; i < 3; ++i) accs[i][t] = cn * accs[i][t];
-    } else if (MODE == 1) {
+    } else if (FUSED) {
       // one memory latency per item instead of one per row tile (the lifts' registers are free by now)
       fetch_old();
 #pragma unroll
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            R v = cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg];
+            R v = SELF ? cs * po[t][reg][i] + ca * pa[t][reg][i] + cn * acc[i][t][reg] : ca * pa[t][reg][i] + cn * acc[i][t][reg];
             asm volatile("" : "+v"(v));
             acc[i][t][reg] = v;
           }
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(St
       for (int t = 0; t < NSM; ++t)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          accs[i][t] = cs * pos[t][i] + ca * pas[t][i] + cn * accs[i][t];
+          accs[i][t] = SELF ? cs * pos[t][i] + ca * pas[t][i] + cn * accs[i][t] : ca * pas[t][i] + cn * accs[i][t];
           asm volatile("" : "+v"(accs[i][t]));
         }
     }
@@ -1200,6 +1200,11 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
         SG_LAUNCH((mfma_stage_F<R, P, 0, SYM, 1>), grid, block, s, a, a);
       else
         SG_LAUNCH((mfma_stage_F<R, P, 0, SYM, 0>), grid, block, s, a, a);
+    } else if (a.mode == 2) {
+      if (ghosts)
+        SG_LAUNCH((mfma_stage_F<R, P, 2, SYM, 1>), grid, block, s, a, a);
+      else
+        SG_LAUNCH((mfma_stage_F<R, P, 2, SYM, 0>), grid, block, s, a, a);
     } else {
       if (ghosts)
         SG_LAUNCH((mfma_stage_F<R, P, 1, SYM, 1>), grid, block, s, a, a);

@@ -339,15 +339,16 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       for (int tile = 0; tile < MT; ++tile) {
       if constexpr (MT > 1) load_frags(tile);
       // in-place combine operands, requested before the arithmetic
+      // (MODE 2: no self term, out = c_aux aux + c_new rhs - stage UTEMP leaves w = dt u1 + dt^3/24 utemp, stages.cpp)
       R po[S4T][2], pa[S4T][2];
-      if (MODE == 1) {
+      if (MODE >= 1) {
 #pragma unroll
         for (int m = 0; m < S4T; ++m) {
           const int a = 16 * tile + 4 * m + q;
           const unsigned ro = (unsigned)((((a < ND) ? a : 0) * 2 * 16 + w) * EBY);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            po[m][i] = t2_ld(outb, ro + i * LB);
+            po[m][i] = MODE == 1 ? t2_ld(outb, ro + i * LB) : R(0);
             pa[m][i] = t2_ld(auxb, ro + i * LB);
           }
         }
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
         for (int i = 0; i < 2; ++i) {
           R v = acc[i][m];
           if (MODE == 1) v = cs * po[m][i] + ca * pa[m][i] + cnw * v;
+          if (MODE == 2) v = ca * pa[m][i] + cnw * v;
           if (active && a < ND) t2_st(outb, ro + i * LB, v);
         }
       }
@@ -400,14 +402,16 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       // ---- G ---------------------------------------------------------------------------------
       const R lam = (R)(A.per_cell ? A.lam[e] : A.lam0);
       const R mu = (R)(A.per_cell ? A.mu[e] : A.mu0);
-      const R c_self = (R)A.c_self, c_aux = (R)A.c_aux, c_new = (R)A.c_new;
+      // fused form of a G stage: out = c_self out + c_new rhs - no second operand (stage S1 gets dt sh1 + dt^3/24 sh2 as one
+      // G of dt u1 + dt^3/24 utemp, stages.cpp); the source enters with src_coef = dt + dt^3/24 there
+      const R c_self = (R)A.c_self, c_new = (R)A.c_new;
+      const R src_coef = (R)A.src_coef;
       const long sbase = ((long)item * ND) * 4 * 16;
       R* outb = out + sbase;            // wave-uniform
-      const R* auxb = aux + sbase;
 #pragma unroll
       for (int tile = 0; tile < MT; ++tile) {
       if constexpr (MT > 1) load_frags(tile);
-      R po[S4T][3], pa[S4T][3], pl[S4T], pal[S4T];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
+      R po[S4T][3], pl[S4T];  // old values of the lines (0,0) (0,1) (1,1), and (1,0)
       if (MODE == 1) {
 #pragma unroll
         for (int m = 0; m < S4T; ++m) {
@@ -416,13 +420,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           po[m][0] = t2_ld(outb, ro + 0 * LB);
           po[m][1] = t2_ld(outb, ro + 1 * LB);
           po[m][2] = t2_ld(outb, ro + 3 * LB);
-          pa[m][0] = t2_ld(auxb, ro + 0 * LB);
-          pa[m][1] = t2_ld(auxb, ro + 1 * LB);
-          pa[m][2] = t2_ld(auxb, ro + 3 * LB);
-          if (!SYM) {
-            pl[m] = t2_ld(outb, ro + 2 * LB);
-            pal[m] = t2_ld(auxb, ro + 2 * LB);
-          }
+          if (!SYM) pl[m] = t2_ld(outb, ro + 2 * LB);
         }
       }
       // W_00, W_11 and W_01 + W_10 per row-quad
@@ -474,17 +472,17 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           }
           if (ix >= 0 && son) {
             const double* sv = svb + (long)ix * 4;
-            v00 += (R)sg_mul_rounded(ssc, sv[0]);   // rounded product first: bitwise = a table of the products
-            v01 += (R)sg_mul_rounded(ssc, sv[1]);
-            v10 += (R)sg_mul_rounded(ssc, sv[2]);
-            v11 += (R)sg_mul_rounded(ssc, sv[3]);
+            v00 += src_coef * (R)sg_mul_rounded(ssc, sv[0]);   // rounded product first: bitwise = a table of the products
+            v01 += src_coef * (R)sg_mul_rounded(ssc, sv[1]);
+            v10 += src_coef * (R)sg_mul_rounded(ssc, sv[2]);
+            v11 += src_coef * (R)sg_mul_rounded(ssc, sv[3]);
           }
         }
         if (MODE == 1) {
-          v00 = c_self * po[m][0] + c_aux * pa[m][0] + c_new * v00;
-          v11 = c_self * po[m][2] + c_aux * pa[m][2] + c_new * v11;
-          if (!SYM) v10 = c_self * pl[m] + c_aux * pal[m] + c_new * v10;
-          v01 = c_self * po[m][1] + c_aux * pa[m][1] + c_new * v01;
+          v00 = c_self * po[m][0] + c_new * v00;
+          v11 = c_self * po[m][2] + c_new * v11;
+          if (!SYM) v10 = c_self * pl[m] + c_new * v10;
+          v01 = c_self * po[m][1] + c_new * v01;
         }
         if (active && a < ND) {
           t2_st(outb, ro + 0 * LB, v00);
@@ -508,6 +506,8 @@ static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems
   if (kind == 0) {
     if (a.mode == 0)
       SG_LAUNCH((tile2d_stage<P, 0, 0, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
+    else if (a.mode == 2)
+      SG_LAUNCH((tile2d_stage<P, 0, 2, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
     else
       SG_LAUNCH((tile2d_stage<P, 0, 1, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
   } else {

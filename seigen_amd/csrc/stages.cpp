@@ -28,7 +28,8 @@ static double source_scale(const sg_handle* h) {
 }
 
 static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mode, double c_self, double c_aux,
-                  double c_new, int region, int uabs_f = SG_FIELD_U, bool with_source = false) {
+                  double c_new, int region, int uabs_f = SG_FIELD_U, bool with_source = false, bool density = false,
+                  double src_coef = 1.0) {
   StageArgs a;
   std::memset(&a, 0, sizeof(a));
   a.in = h->field[in_f];
@@ -66,7 +67,8 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.lam0 = h->lam0;
   a.mu0 = h->mu0;
   a.per_cell = h->per_cell;
-  a.rho2 = (kind == 0 && mode == 1) ? h->rho2_d : nullptr;
+  a.rho2 = (kind == 0 && mode == 1 && density) ? h->rho2_d : nullptr;   // stage U1 only
+  a.src_coef = src_coef;
   a.mode = mode;
   a.c_self = c_self;
   a.c_aux = c_aux;
@@ -208,7 +210,7 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
     case SG_STAGE_U1:
       // explicit mode keeps only rhs(form_u1): u1 = rho*u0 + dt*uh1 + dt^3/24*uh2 (elastic.py:341-345, :354-356);
       // sg_set_density(physical = 1): u1 = u0 + (dt*uh1 + dt^3/24*uh2)/rho; per-cell density: factors in rho2
-      if (h->rho2_d) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt, c3, region);
+      if (h->rho2_d) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt, c3, region, SG_FIELD_U, false, true);
       if (h->rho_physical) return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, 1.0, dt / h->rho, c3 / h->rho, region);
       return run_op(h, 0, SG_FIELD_SH, SG_FIELD_U, SG_FIELD_UH, 1, h->rho, dt, c3, region);
     case SG_STAGE_SH1:
@@ -216,10 +218,18 @@ static int run_stage_impl(sg_handle* h, int stage, int region) {
       if (rc == SG_OK) rc = add_source(h, SG_FIELD_SH, 1.0, region);
       return rc;
     case SG_STAGE_UTEMP:
-      return run_op(h, 0, SG_FIELD_SH, SG_FIELD_UH, -1, 0, 0, 0, 0, region);
+      // utemp = F(sh1; u1) has one consumer, sh2 = G(utemp) in the stress update s1 = s0 + dt sh1 + dt^3/24 sh2 with
+      // sh1 = G(u1) + S (elastic.py:300-303, :348-352) - and g is LINEAR in the velocity: dt G(u1) + dt^3/24 G(utemp) =
+      // G(dt u1 + dt^3/24 utemp).  So this stage leaves w = dt u1 + dt^3/24 utemp in UH (one more operand in its fused
+      // epilogue, on a stage that waits for the matrix pipe, not for memory) and stage S1 reads w and s0 ONLY: no sh1, no
+      // second right-hand side - 6 of its 21 words per node gone (the halo exchanged after this stage is w's).
+      // (mode 2: the fused form without the self term, out = c_aux aux + c_new rhs; kernel families without an instantiation
+      // of their own run their mode-1 kernels with c_self = 0)
+      return run_op(h, 0, SG_FIELD_SH, SG_FIELD_UH, SG_FIELD_U, 2, 0.0, dt, c3, region);
     case SG_STAGE_S1:
-      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, SG_FIELD_SH, 1, 1.0, dt, c3, region, SG_FIELD_U, true);
-      if (rc == SG_OK) rc = add_source(h, SG_FIELD_S, c3, region);
+      // s1 = s0 + G(w) + (dt + dt^3/24) S   (G stage kernels, fused form: out = c_self out + c_new rhs, no second operand)
+      rc = run_op(h, 1, SG_FIELD_UH, SG_FIELD_S, -1, 1, 1.0, 0.0, 1.0, region, SG_FIELD_U, true, false, dt + c3);
+      if (rc == SG_OK) rc = add_source(h, SG_FIELD_S, dt + c3, region);
       return rc;
   }
   return fail(h, SG_ERR_ARG, "unknown stage");

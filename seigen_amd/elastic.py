@@ -13,6 +13,11 @@ Differences, all documented in DESIGN.md:
   * ``uh2`` and ``sh2`` are never materialised (fused into the combine stages);
     ``u0``/``u1`` (``s0``/``s1``) share one device buffer because
     ``u0.assign(u1)`` (``:296``) is an in-place update.
+  * ``utemp`` has one consumer, ``sh2 = g(utemp)`` in the stress update ``s1 = s0 + dt sh1 + dt^3/24 sh2`` (``:302-303``),
+    and ``g`` is linear: the library leaves ``w = dt u1 + dt^3/24 utemp`` in the buffer behind ``uh1`` / ``utemp`` and
+    computes ``s1 = s0 + g(w)`` - one application of ``g`` that reads neither ``sh1`` nor a second right-hand side
+    (include/seigen_hip.h, ``enum sg_stage``).  After a step ``elastic.utemp`` therefore holds ``w``; ``(u1, s1)`` are
+    unchanged to round-off.
   * ``solver='implicit'`` (``:318-332``): the reference hands every form to a PETSc KSP; all eight
     systems are DG mass matrices (block diagonal), so the solve IS the element-wise inverse the
     explicit path applies, up to the KSP tolerance.  Here it runs the same six launches with the

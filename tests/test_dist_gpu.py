@@ -204,5 +204,6 @@ def test_bench_line_carries_the_other_configs(gpu):
         assert c["cells"] == cells and c["value"] > 0 and c["ms_per_step"] > 0 and c["steps"] > 0
         rf = c["roofline"]
         assert 0 < rf["frac_physical"] < rf["frac"] < 1 and rf["bound"] == "hbm"
-        assert rf["dominant_kernel"].startswith("sg::tile2d_stage<") and len(rf["kernels"]) == 4
+        # five kernels: F plain (UH1), F fused (U1), F fused without the self term (UTEMP), G plain (STEMP, SH1), G fused (S1)
+        assert rf["dominant_kernel"].startswith("sg::tile2d_stage<") and len(rf["kernels"]) == 5
         assert "cpu_baseline" not in c

@@ -202,7 +202,7 @@ def test_config3_full_size_mfma_vs_generic(gpu, monkeypatch):
         del el
     tol = {_lib.FIELD_U: 1e-11, _lib.FIELD_S: 1e-11, _lib.FIELD_SH: 1e-9, _lib.FIELD_UH: 1e-7}
     scale = {f: max(np.abs(b).max() for g, _, b in samples["generic"] if g == f) for f in tol}   # per field, over all samples
-    assert all(v > 1e-3 for v in scale.values()), scale
+    assert all(v > 1e-4 for v in scale.values()), scale      # (UH holds w = dt u1 + dt^3/24 utemp: of the size of dt)
     for (f, c0, a), (_, _, b) in zip(samples["mfma"], samples["generic"]):
         assert np.abs(a - b).max() / scale[f] < tol[f], (f, c0, np.abs(a - b).max() / scale[f])
 
@@ -240,7 +240,7 @@ def test_config3_on_hexahedra_full_size_matrix_vs_generic(gpu, monkeypatch, P, n
         del el, em
     tol = {_lib.FIELD_U: 1e-11, _lib.FIELD_S: 1e-11, _lib.FIELD_SH: 1e-9, _lib.FIELD_UH: 1e-7}
     scale = {f: max(np.abs(b).max() for g, _, b in samples["generic"] if g == f) for f in tol}
-    assert all(v > 1e-3 for v in scale.values()), scale
+    assert all(v > 1e-4 for v in scale.values()), scale      # (UH holds w = dt u1 + dt^3/24 utemp: of the size of dt)
     for (f, c0, a), (_, _, b) in zip(samples["hexm"], samples["generic"]):
         assert np.abs(a - b).max() / scale[f] < tol[f], (f, c0, np.abs(a - b).max() / scale[f])
         if f == _lib.FIELD_U:       # three steps of a degree-3 / 4 scheme on this mesh stay within 1e-6 of the analytic mode

@@ -92,8 +92,9 @@ def test_library_names_the_kernels_it_runs(gpu, monkeypatch, gq, fact):
     blk = make_block(4, (16, 2, 2), (1.0, 1.0, 1.0))
     blk.set_params(1.0, 0.01, 0.5, 0.25)
     names = [blk.stage_kernel_name(st) for st in range(6)]
-    assert names[0] == names[4] == "sg::mfma_stage_F<double, 4, 0, 1, 0>"
+    assert names[0] == "sg::mfma_stage_F<double, 4, 0, 1, 0>"
     assert names[2] == "sg::mfma_stage_F<double, 4, 1, 1, 0>"
+    assert names[4] == "sg::mfma_stage_F<double, 4, 2, 1, 0>"      # UTEMP leaves w = dt u1 + dt^3/24 utemp: fused, no self term
     assert names[1] == names[3] == "sg::mfma_stage_G<double, 4, 0, 1, %d>" % fact
     assert names[5] == "sg::mfma_stage_G<double, 4, 1, 1, %d>" % fact
     full = blk.stage_kernel_name(1, short=False)

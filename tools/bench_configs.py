@@ -117,6 +117,11 @@ if __name__ == "__main__":
              "c3h3": lambda st, w: config3_hex(st, w, 3), "c3h4": lambda st, w: config3_hex(st, w, 4),
              "c2f32": lambda st, w: config2(st, w, dtype="f32"),
              "c2qf32": lambda st, w: config2(st, w, quadrilateral=True, dtype="f32")}[c](args.steps, args.warmup)
-        r["algorithmic_GBps"] = r["value"] * 1e6 * r.get("bytes_per_dof_update", 64) / 1e9
+        # bytes per DoF-update of this step (bench.py stage_accounting): 60 in 3-D, 61.3 in 2-D (FP32: half)
+        bpu = r.get("bytes_per_dof_update") or (60.0 if c.startswith(("c3h", "c4")) else 184.0 / 3.0)
+        if r.get("bytes_per_dof_update") == 32:
+            bpu = 0.5 * 184.0 / 3.0
+        r["bytes_per_dof_update"] = bpu
+        r["algorithmic_GBps"] = r["value"] * 1e6 * bpu / 1e9
         r["hbm_frac"] = r["algorithmic_GBps"] / 8000.0
         print(json.dumps(r))
