@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
           cn *= A.rho2[2 * g2 + 1];
         }
         // (a fused G stage has no second operand: out = c_self out + c_new rhs, stages.cpp)
-        A.out[o] = KIND == 0 ? cs * A.out[o] + ca * A.aux[o] + cn * sOut[idx] : cs * A.out[o] + cn * sOut[idx];
+        // (a.mode 2 - UTEMP, no self term - does not read `out`)
+        A.out[o] = KIND == 0 ? (A.mode == 2 ? 0.0 : cs * A.out[o]) + ca * A.aux[o] + cn * sOut[idx] : cs * A.out[o] + cn * sOut[idx];
       }
     }
   };
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageArgs A) {
             cn *= A.rho2[2 * g + 1];
           }
 #pragma unroll
-          for (int i = 0; i < DIM; ++i) A.out[o + i] = cs * A.out[o + i] + ca * A.aux[o + i] + cn * acc[i];
+          for (int i = 0; i < DIM; ++i) A.out[o + i] = (A.mode == 2 ? 0.0 : cs * A.out[o + i]) + ca * A.aux[o + i] + cn * acc[i];
         }
       }
     } else {

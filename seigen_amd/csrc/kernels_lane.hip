@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
       const bool any_sponge = __any(sslot >= 0);
       const long ubase = ((g * NCLS + k) * (long)ND) * DIM * 64 + lane;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      const bool self = A.c_self != 0.0 || A.rho2 != nullptr;     // uniform
       if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
         cs = A.rho2[2 * e];
         ca *= A.rho2[2 * e + 1];
@@ -209,10 +210,10 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
           for (int b = 0; b < ND; ++b) ua[b] = A.uabs[ubase + (b * DIM + i) * 64];
         }
         double po[ND], pa[ND];
-        if (MODE == 1) {
+        if (MODE == 1) {     // a.mode 2 (UTEMP: no self term) arrives here with c_self = 0 and `out` is not read
 #pragma unroll
           for (int a = 0; a < ND; ++a) {
-            po[a] = out[ubase + (a * DIM + i) * 64];
+            po[a] = self ? out[ubase + (a * DIM + i) * 64] : 0.0;
             pa[a] = aux[ubase + (a * DIM + i) * 64];
           }
         }
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
       const bool any_sponge = __any(sslot >= 0);
       const long ubase = (g * (long)ND) * DIM * 64 + lane;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
+      const bool self = A.c_self != 0.0 || A.rho2 != nullptr;     // uniform
       if (MODE == 1 && A.rho2 != nullptr) {
         cs = A.rho2[2 * e];
         ca *= A.rho2[2 * e + 1];
@@ -501,10 +503,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
           }
         }
         if (MODE == 1) {
-          double po[ND], pa[ND];
+          double po[ND], pa[ND];     // a.mode 2 (UTEMP: no self term) arrives here with c_self = 0 and `out` is not read
 #pragma unroll
           for (int a = 0; a < ND; ++a) {
-            po[a] = out[ubase + (a * DIM + i) * 64];
+            po[a] = self ? out[ubase + (a * DIM + i) * 64] : 0.0;
             pa[a] = aux[ubase + (a * DIM + i) * 64];
           }
 #pragma unroll

@@ -261,6 +261,40 @@ def test_every_kernel_family(gpu, monkeypatch, path, dim, degree, n, L, diagonal
     assert rel_err(blk.get_field(_lib.FIELD_S), orc.s1) < 10 * TOL
 
 
+@pytest.mark.parametrize("path", [None, "generic", "lane"])
+@pytest.mark.parametrize("dim,degree,n,L,diagonal", [
+    (2, 1, (5, 3), (1.0, 1.0), "left"),
+    (2, 3, (4, 4), (1.0, 1.0), "left"),
+    (2, 2, (4, 3), (1.0, 1.5), "quadrilateral"),
+    (3, 1, (3, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 4, (2, 2, 2), (1.0, 1.0, 1.0), "left"),
+    (3, 2, (2, 3, 2), (1.0, 0.9, 0.5), "quadrilateral"),
+    (3, 3, (2, 2, 3), (1.0, 0.8, 0.9), "quadrilateral"),
+])
+def test_stage_utemp_overwrites_uh_without_reading_it(gpu, monkeypatch, path, dim, degree, n, L, diagonal):
+    """Stage UTEMP writes w = dt u1 + dt^3/24 Minv f(sh1) into UH (include/seigen_hip.h, enum sg_stage) and has no
+    self term: whatever UH held before - here NaN - must not reach the result, in any kernel family."""
+    from seigen_amd import _lib
+    if path:
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+    blk = make_block(dim, degree, n, L, diagonal)
+    dt = 0.05 * min(L[a] / n[a] for a in range(dim)) / degree ** 2
+    blk.set_params(1.0, dt, 0.5, 0.25)
+    u1 = seeded(blk.field_shape(_lib.FIELD_U), 51)
+    sh1 = seeded(blk.field_shape(_lib.FIELD_S), 52)
+    sh1 = 0.5 * (sh1 + np.swapaxes(sh1, -1, -2))
+    results = []
+    for fill in (0.0, np.nan):
+        blk.set_field(_lib.FIELD_U, u1)
+        blk.set_field(_lib.FIELD_SH, sh1)
+        blk.set_field(_lib.FIELD_UH, np.full(blk.field_shape(_lib.FIELD_UH), fill))
+        blk.run_stage(_lib.STAGE_UTEMP)
+        results.append(blk.get_field(_lib.FIELD_UH))
+    assert np.isfinite(results[1]).all()
+    assert np.array_equal(results[0], results[1])
+    blk.close()
+
+
 def test_error_behaviour(gpu):
     """Every entry point returns a negative code with a message instead of launching on bad input
     (the reference raises Python exceptions: seigen/elastic.py:64, :234-242)."""
