@@ -50,6 +50,15 @@ struct RT<float> {
   static __device__ __forceinline__ float small(float, float, float c) { return c; }  // never reached (NSM = 0)
 };
 
+// Resident blocks per CU every instantiation of a (type, degree) must fit (launch bound) and the persistent grid is
+// sized for (mfma_blocks_per_cu): registers and LDS allow exactly two at degrees 3 and 4 (a third block at degree 3 measured
+// slower); the low orders are memory-bound and light (12 / 28 KB of tiles) and want more waves in flight.  One number for
+// both: a grid sized for more blocks than a fused instantiation can hold runs a second, partly empty round.
+template <typename R, int P>
+constexpr int mfma_resident_blocks() {
+  return sizeof(R) == 4 ? 3 : (P == 1 ? 4 : (P == 2 ? 3 : 2));   // float kernels: at most 168 VGPRs and half the table bytes
+}
+
 template <int P, typename R>
 struct MG {
   static constexpr int ND = ElemDims<3, P>::ND;
@@ -399,7 +408,7 @@ __device__ __forceinline__ float ndot<float>(float c0, float c1, float c2, float
 //  only W_ii and W_ij + W_ji are accumulated (6 * S4 values).
 // --------------------------------------------------------------------------------------------
 template <typename R, int P, int MODE, int SYM, int FACT>
-__global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(StageArgs A) {
+__global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stage_G(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
   constexpr int PRIO3 = MODE ? SG_PRIO_G1 : SG_PRIO_G0;
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_G(St
 //  F: uh_i = -sum_r D_r (Jinv_rj T_ij) + sum_f L_f [ (c n)_j {T_ij} ] - sponge
 // --------------------------------------------------------------------------------------------
 template <typename R, int P, int MODE, int SYM, int GHOST>
-__global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void mfma_stage_F(StageArgs A) {
+__global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stage_F(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
   constexpr int PRIO3 = MODE == 1 ? SG_PRIO_F1 : SG_PRIO_F0;    // (MODE 2, stage UTEMP, waits for the matrix pipe like the plain stage)
@@ -1234,12 +1243,9 @@ static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
   return a.sym ? launch_ps<R, P, 1>(kind, a, s) : launch_ps<R, P, 0>(kind, a, s);
 }
 
-// resident blocks per CU the persistent grid is sized for: registers and LDS allow exactly two at
-// degrees 3 and 4 (a third block at degree 3 measured slower); the low orders are memory-bound and
-// light (64 / 166 VGPRs, 12 / 28 KB of tiles) and want more waves in flight
 int mfma_blocks_per_cu(int P, int f32) {
-  if (f32) return 3;   // float kernels: at most 168 VGPRs (launch bound) and half the table bytes
-  return P == 1 ? 4 : (P == 2 ? 3 : 2);
+  if (f32) return mfma_resident_blocks<float, 4>();
+  return P == 1 ? mfma_resident_blocks<double, 1>() : (P == 2 ? mfma_resident_blocks<double, 2>() : mfma_resident_blocks<double, 4>());
 }
 
 int launch_stage_mfma(int kind, int P, const StageArgs& a, void* stream) {
