@@ -100,7 +100,9 @@ struct MG {
 // phase, instead of both waves queueing at equal priority: round 2's 0x330 -> 0x120 is 2-4 % on the step
 // (profiles/r03/priority_sweep.txt: plain stages 1.22-1.28 -> 1.17-1.20 ms; the fused G stage does not care; the
 // fused F stage, bandwidth-bound, wants the opposite order once the neighbours come from the table: 0x320).
-constexpr int SG_PRIO_F0 = 0x120, SG_PRIO_F1 = 0x320, SG_PRIO_G0 = 0x120, SG_PRIO_G1 = 0x120;
+// Round 5: stage UTEMP (F, MODE 2: reads u1 beside its result) sides with the fused F stage, 1.284 -> 1.270 ms; the fused G
+// stage (S1 = s0 + g(w)) still does not care (0x320 / 0x210: +2 % on that stage).
+constexpr int SG_PRIO_F0 = 0x120, SG_PRIO_F1 = 0x320, SG_PRIO_F2 = 0x320, SG_PRIO_G0 = 0x120, SG_PRIO_G1 = 0x120;
 #define SG_PRIO_VOL ((PRIO3 >> 8) & 3)
 #define SG_PRIO_LIFT ((PRIO3 >> 4) & 3)
 #define SG_PRIO_EPI (PRIO3 & 3)
@@ -848,7 +850,7 @@ template <typename R, int P, int MODE, int SYM, int GHOST>
 __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stage_F(StageArgs A) {
   using M = MG<P, R>;
   typedef typename RT<R>::v4 d4;
-  constexpr int PRIO3 = MODE == 1 ? SG_PRIO_F1 : SG_PRIO_F0;    // (MODE 2, stage UTEMP, waits for the matrix pipe like the plain stage)
+  constexpr int PRIO3 = MODE == 1 ? SG_PRIO_F1 : (MODE == 2 ? SG_PRIO_F2 : SG_PRIO_F0);
   constexpr int ND = M::ND, NF = M::NF, KS = M::KS, KSF = M::KSF, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT;
   __shared__ R sAV[M::NFRAG_F * 64];
   __shared__ R sAL[M::NFRAG_L * 64];
