@@ -271,7 +271,7 @@ def test_every_kernel_family(gpu, monkeypatch, path, dim, degree, n, L, diagonal
     (3, 2, (2, 3, 2), (1.0, 0.9, 0.5), "quadrilateral"),
     (3, 3, (2, 2, 3), (1.0, 0.8, 0.9), "quadrilateral"),
 ])
-def test_stage_utemp_overwrites_uh_without_reading_it(gpu, monkeypatch, path, dim, degree, n, L, diagonal):
+def test_stages_utemp_and_s1_read_only_their_operands(gpu, monkeypatch, path, dim, degree, n, L, diagonal):
     """Stage UTEMP writes w = dt u1 + dt^3/24 Minv f(sh1) into UH (include/seigen_hip.h, enum sg_stage) and has no
     self term: whatever UH held before - here NaN - must not reach the result, in any kernel family."""
     from seigen_amd import _lib
@@ -290,6 +290,18 @@ def test_stage_utemp_overwrites_uh_without_reading_it(gpu, monkeypatch, path, di
         blk.set_field(_lib.FIELD_UH, np.full(blk.field_shape(_lib.FIELD_UH), fill))
         blk.run_stage(_lib.STAGE_UTEMP)
         results.append(blk.get_field(_lib.FIELD_UH))
+    assert np.isfinite(results[1]).all()
+    assert np.array_equal(results[0], results[1])
+    # ... and stage S1 = s0 + Minv g(w) reads UH (w) and S only: SH (sh1) is no operand of it any more
+    w = results[0]
+    s0 = 0.5 * (sh1 + 0.25)
+    results = []
+    for fill in (0.0, np.nan):
+        blk.set_field(_lib.FIELD_UH, w)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.set_field(_lib.FIELD_SH, np.full(blk.field_shape(_lib.FIELD_SH), fill))
+        blk.run_stage(_lib.STAGE_S1)
+        results.append(blk.get_field(_lib.FIELD_S))
     assert np.isfinite(results[1]).all()
     assert np.array_equal(results[0], results[1])
     blk.close()
