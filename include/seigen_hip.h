@@ -44,7 +44,7 @@ extern "C" {
  * u0.assign(u1) / s0.assign(s1) (elastic.py:296,304) are in-place updates. */
 enum sg_field {
   SG_FIELD_U = 0,  /* VelocityOld / VelocityNew   (u0, u1)      */
-  SG_FIELD_UH = 1, /* VelocityHalf1 / VelocityTemp (uh1, utemp) */
+  SG_FIELD_UH = 1, /* VelocityHalf1 / VelocityTemp (uh1; after stage UTEMP: w = dt u1 + dt^3/24 utemp, see enum sg_stage) */
   SG_FIELD_S = 2,  /* StressOld / StressNew       (s0, s1)      */
   SG_FIELD_SH = 3  /* StressTemp / StressHalf1    (stemp, sh1)  */
 };
