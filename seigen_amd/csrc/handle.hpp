@@ -114,7 +114,7 @@ struct sg_handle {
   int order_chunk = 0;  // MFMA path: items per XCD chunk of whole-block launches (StageArgs::order_chunk)
   int grid_full = 0;    // ... and otherwise (every block slot of the device)
   T2Const t2c;          // 2-D tile kernels: kernarg copy of the mesh tables
-  int tile_grid = 0;    // 2-D tile kernels: cap of the grid in blocks of four waves (SEIGEN_HIP_TILE_GRID)
+  int tile_grid = 0, tile_grid_sponge = 0;    // 2-D tile kernels: cap of the grid in blocks of four waves, without / with a sponge (SEIGEN_HIP_TILE_GRID)
   // small blocks are launch-bound (config 1: six 5-us launches per step): sg_step replays captured
   // hipGraphs of one and of eight steps there; any setter that changes kernel arguments bumps the epoch
   bool graph_ok = false;

@@ -5,6 +5,7 @@
   c1: 2-D eigenmode 40x40, P1 (launch-overhead bound)
   c4s: one rank's share of config 4 (3-D explosive source 256^3 on 8 GPUs): a 128^3-cube block, P4,
        box-Ricker stress source, zero initial state - 85 GB resident on one device
+  ref2d: the 2-D eigenmode N = 256, P4 of the reference's benchmark protocol, per step and stage
   c3h1..c3h4: config 3's eigenmode on HEXAHEDRA, DQ_1 / DQ_2 (96^3 cubes), DQ_3 (48^3), DQ_4 (40^3)
 Prints one JSON line per config: M DoF-updates/s and ms/step (device time, hipEvents)."""
 import argparse
@@ -100,19 +101,38 @@ def config1(steps, warmup):
     return timed(bc.config1, steps, warmup)
 
 
+REF2D_DEGREE = 4
+
+
+def ref2d(steps, warmup, N=None, degree=None):
+    """the mesh and element of the reference's own benchmark protocol (2-D eigenmode N = 256, P4: bench.py times the whole
+    run(T = 2.0) of it; here: device time per step and per stage)"""
+    N = N or HEX_N or 256       # --hex-n overrides the squares per axis here too
+    degree = degree or REF2D_DEGREE
+    def build(ns):
+        em = _he.Eigenmode2DLF4(N, degree, 0.5 * (1.0 / N) / 2.0 ** (degree - 1), output=False)
+        el = em.elastic
+        el.u0.assign(seigen_amd.Function(el.U).interpolate(em._u(0)))
+        el.s0.assign(seigen_amd.Function(el.S).interpolate(em._s(el.dt / 2)))
+        return bc.ready(el, ns), "ref2d: 2D eigenmode %dx%d squares x 2 triangles, P%d" % (N, N, degree)
+    return timed(build, steps, warmup)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="*", default=["c2", "c5", "c1"])
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--hex-n", type=int, default=None, help="c3h*: cubes per axis instead of the default 96 / 96 / 48 / 40")
+    ap.add_argument("--hex-n", type=int, default=None, help="c3h*: cubes per axis instead of the default 96 / 96 / 48 / 40; ref2d: squares per axis instead of 256")
+    ap.add_argument("--degree", type=int, default=4, help="ref2d: polynomial degree instead of 4")
     ap.add_argument("--stages", action="store_true", help="also report device microseconds per stage (UH1 STEMP U1 SH1 UTEMP S1)")
     args = ap.parse_args()
     STAGES = args.stages
     HEX_N = args.hex_n
+    REF2D_DEGREE = args.degree
     for c in args.configs:
         r = {"c1": config1, "c2": config2, "c5": config5, "c2l": config2_large, "c4s": config4_share,
-             "c2q": config2_quad,
+             "c2q": config2_quad, "ref2d": ref2d,
              "c3h1": lambda st, w: config3_hex(st, w, 1), "c3h2": lambda st, w: config3_hex(st, w, 2),
              "c3h3": lambda st, w: config3_hex(st, w, 3), "c3h4": lambda st, w: config3_hex(st, w, 4),
              "c2f32": lambda st, w: config2(st, w, dtype="f32"),
