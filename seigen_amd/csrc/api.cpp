@@ -319,14 +319,14 @@ static int create_impl(const sg_config* cfg, sg_handle* h) {
     }
     if (const char* oc = std::getenv("SEIGEN_HIP_ORDER_CHUNK")) h->order_chunk = std::max(0, std::atoi(oc));
     h->no_whole = std::getenv("SEIGEN_HIP_NO_WHOLE") != nullptr;
-    // 2-D tile kernels: a persistent grid of three blocks per CU - what the plain stage kernels hold (121 - 166 VGPRs) - so
-    // that a wave sets up once and works through its share of the items: 2-D P4 at N = 256 (the reference's benchmark
-    // protocol) 84.5 -> 93.4 G DoF-updates/s against one item per wave, P3 +8 %, level elsewhere
-    // (profiles/r05/tile_grid_sweep.txt).  With a sponge the items differ in cost and a static share can collect the
-    // expensive ones: then 251 blocks per XCD label - with an odd (prime) stride of 4 * 251 items a wave's items do not
-    // keep falling on the same column of the mesh, i.e. on the sponge strips at both ends of every row (config 2:
-    // 0.228 ms per step with 768 blocks, 0.213 with 2008).
-    h->tile_grid = 3 * prop.multiProcessorCount / 8 * 8;
+    // 2-D tile kernels: a persistent grid of exactly the blocks the device holds of the stage's kernel (0 = the launcher
+    // asks the runtime per instantiation, kernels_tile2d.hip) - a wave sets up once and works through its share of the
+    // items: 2-D P4 at N = 256 (the reference's benchmark protocol) 84.5 -> 93.4 G DoF-updates/s against one item per
+    // wave, P3 +8 %, level elsewhere (profiles/r05/tile_grid_sweep.txt).  With a sponge the items differ in cost and a
+    // static share can collect the expensive ones: then 251 blocks per XCD label - with an odd (prime) stride of 4 * 251
+    // items a wave's items do not keep falling on the same column of the mesh, i.e. on the sponge strips at both ends of
+    // every row (config 2: 0.228 ms per step with 768 blocks, 0.213 with 2008).
+    h->tile_grid = 0;
     h->tile_grid_sponge = 2008;
     if (const char* tg = std::getenv("SEIGEN_HIP_TILE_GRID")) h->tile_grid = h->tile_grid_sponge = std::max(8, std::atoi(tg) / 8 * 8);
   }

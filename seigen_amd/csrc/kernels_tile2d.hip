@@ -496,26 +496,47 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
   }
 }
 
+// Blocks of four waves the device holds of one kernel instantiation (asked once per instantiation): the size of the
+// persistent grid when the caller names none (StageArgs::grid_blocks = 0, stages.cpp).  Exactly resident is a sharp optimum
+// on the meshes of the benchmark protocol - a few blocks more start a second, nearly empty round, a few less leave slots
+// unused with the same number of items per wave (profiles/r05/tile_grid_sweep.txt) - and the instantiations differ: the
+// fused F stages hold two waves per SIMD at degree 4, the other stages three.
+template <typename K>
+static int t2_resident_blocks(K kernel) {
+  int per_cu = 0, dev = 0, ncu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    ncu = 256;
+  return per_cu * ncu;
+}
+
 template <int P, int SYM, int GHOST, int TP = 0, typename R = double>
 static int launch_t2(int kind, const StageArgs& a, const T2Const& c, long nitems, hipStream_t s) {
-  long blocks = (nitems + 3) / 4;
-  const long cap = a.grid_blocks > 0 ? a.grid_blocks : 2048;
-  if (blocks > cap) blocks = cap;
-  blocks = (blocks + 7) / 8 * 8;  // every XCD label needs a block
-  const dim3 grid((unsigned)blocks), block(256);
+  const dim3 block(256);
+#define SG_T2_LAUNCH(K, M)                                                                          \
+  do {                                                                                              \
+    static const int resident = t2_resident_blocks(tile2d_stage<P, K, M, SYM, GHOST, TP, R>);       \
+    long blocks = (nitems + 3) / 4;                                                                 \
+    const long cap = a.grid_blocks > 0 ? a.grid_blocks : resident;                                  \
+    if (blocks > cap) blocks = cap;                                                                 \
+    blocks = (blocks + 7) / 8 * 8; /* every XCD label needs a block */                              \
+    const dim3 grid((unsigned)blocks);                                                              \
+    SG_LAUNCH((tile2d_stage<P, K, M, SYM, GHOST, TP, R>), grid, block, s, a, a, c);                 \
+  } while (0)
   if (kind == 0) {
     if (a.mode == 0)
-      SG_LAUNCH((tile2d_stage<P, 0, 0, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
+      SG_T2_LAUNCH(0, 0);
     else if (a.mode == 2)
-      SG_LAUNCH((tile2d_stage<P, 0, 2, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
+      SG_T2_LAUNCH(0, 2);
     else
-      SG_LAUNCH((tile2d_stage<P, 0, 1, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
+      SG_T2_LAUNCH(0, 1);
   } else {
     if (a.mode == 0)
-      SG_LAUNCH((tile2d_stage<P, 1, 0, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
+      SG_T2_LAUNCH(1, 0);
     else
-      SG_LAUNCH((tile2d_stage<P, 1, 1, SYM, GHOST, TP, R>), grid, block, s, a, a, c);
+      SG_T2_LAUNCH(1, 1);
   }
+#undef SG_T2_LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -343,6 +343,14 @@ static int enqueue_step(sg_handle* h) {
 static hipGraphExec_t capture_steps(sg_handle* h, int steps, bool with_src) {
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
+  {
+    // a dry pass through the launch code (nothing is queued): what a launcher asks the runtime once per kernel
+    // instantiation - the resident blocks of the 2-D tile kernels - is asked here, outside the capture
+    std::string name;
+    h->name_out = &name;
+    for (int st = 0; st < 6; ++st) (void)run_stage_impl(h, st, SG_REGION_ALL);
+    h->name_out = nullptr;
+  }
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
   int rc = SG_OK;
   h->capture_src = with_src;
