@@ -108,7 +108,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
     // only launches that run while an exchange is in flight leave block slots to RCCL
     a.grid_blocks = (region == SG_REGION_INTERIOR || region == SG_REGION_SECOND) ? h->grid_blocks : h->grid_full;
-    if (h->use_tile) a.grid_blocks = h->sponge_slot ? h->tile_grid_sponge : h->tile_grid;
+    if (h->use_tile) a.grid_blocks = (h->sponge_slot && kind == 0) ? h->tile_grid_sponge : h->tile_grid;   // the sponge is part of F only
     a.item_list = nullptr;
     a.nlist = 0;
     a.order_chunk = (h->use_mfma && !a.spread && kind == 0) ? h->order_chunk : 0;
