@@ -1,6 +1,8 @@
 // C-ABI of libseigen_hip.so (see include/seigen_hip.h): handle life cycle (device memory, operator tables, kernel
 // family choice), parameters, sponge, source and the table exports.  Field transfers: transfer.cpp; stage launches,
 // the fused six-launch LF4 step (seigen/elastic.py:283-313) and halo packs: stages.cpp.
+#include <limits>
+
 #include "handle.hpp"
 
 extern "C" {
@@ -53,6 +55,7 @@ void sg_destroy(sg_handle* h) {
   if (h->rho2_d) (void)hipFree(h->rho2_d);
   if (h->sponge_slot) (void)hipFree(h->sponge_slot);
   if (h->sponge_B) (void)hipFree(h->sponge_B);
+  if (h->sponge_sigma) (void)hipFree(h->sponge_sigma);
   if (h->src_nodes) (void)hipFree(h->src_nodes);
   if (h->src_values) (void)hipFree(h->src_values);
   if (h->src_slot_d) (void)hipFree(h->src_slot_d);
@@ -496,6 +499,11 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
     (void)hipFree(h->sponge_B);
     h->sponge_B = nullptr;
   }
+  if (h->sponge_sigma) {
+    (void)hipFree(h->sponge_sigma);
+    h->sponge_sigma = nullptr;
+  }
+  h->sponge_nslots = 0;
   if (!sigma_nodes) return SG_OK;
   if (sigma_degree < 1 || sigma_degree > 6) return fail(h, SG_ERR_ARG, "sigma_degree must be 1..6");
   const int d = h->cfg.dim, nd = h->re.nd;
@@ -504,12 +512,24 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   std::vector<double> A = sponge_tensor(d, h->cfg.degree, sigma_degree, h->re.kind);
   std::vector<int32_t> slot((size_t)h->ncells, -1);
   std::vector<double> B;
+  // 2-D tile kernels: a sigma that is one value on all nodes of a cell (the piecewise-constant sponges of the reference's
+  // problem scripts, explosive_source_lf4.py:42-45) makes B_e = Minv (sigma M) = sigma I: such a cell carries its sigma
+  // instead of a matrix (kernels.hpp StageArgs::sponge_sigma)
+  std::vector<double> sig;
+  if (h->use_tile) sig.assign((size_t)h->ncells, 0.0);
   int32_t nslots = 0;
   for (int64_t e = 0; e < h->ncells; ++e) {
     const double* sg_ = sigma_nodes + (size_t)e * nq;
-    bool nz = false;
-    for (int c = 0; c < nq; ++c) nz = nz || (sg_[c] != 0.0);
+    bool nz = false, same = true;
+    for (int c = 0; c < nq; ++c) {
+      nz = nz || (sg_[c] != 0.0);
+      same = same && (sg_[c] == sg_[0]);
+    }
     if (!nz) continue;
+    if (!sig.empty()) {
+      sig[(size_t)e] = same ? sg_[0] : std::numeric_limits<double>::quiet_NaN();
+      if (same) continue;
+    }
     slot[e] = nslots++;
     size_t base = B.size();
     B.resize(base + (size_t)nd * nd, 0.0);
@@ -524,6 +544,11 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   }
   HIPCHECK(h, hipMalloc((void**)&h->sponge_slot, slot.size() * sizeof(int32_t)));
   HIPCHECK(h, hipMemcpy(h->sponge_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->sponge_nslots = nslots;
+  if (!sig.empty()) {
+    HIPCHECK(h, hipMalloc((void**)&h->sponge_sigma, sig.size() * sizeof(double)));
+    HIPCHECK(h, hipMemcpy(h->sponge_sigma, sig.data(), sig.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (nslots > 0) {
     HIPCHECK(h, hipMalloc((void**)&h->sponge_B, B.size() * sizeof(double)));
     HIPCHECK(h, hipMemcpy(h->sponge_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));

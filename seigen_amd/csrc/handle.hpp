@@ -75,6 +75,8 @@ struct sg_handle {
   // sponge
   int32_t* sponge_slot = nullptr;
   double* sponge_B = nullptr;
+  double* sponge_sigma = nullptr;   // 2-D tile kernels only (kernels.hpp StageArgs::sponge_sigma)
+  int32_t sponge_nslots = 0;        // cells with a sponge matrix of their own
   // source
   int64_t src_nnz = 0;
   int64_t src_nfirst = 0;  // source nodes are stored with those in cells of SG_REGION_FIRST first

@@ -111,6 +111,8 @@ struct StageArgs {
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null
   const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
   const double* sponge_B;      // [slot][nd(a)][nd(b)]
+  const double* sponge_sigma;  // 2-D tile kernels: [cell] 0 = no sponge; a value = sigma is CONSTANT over the cell, the sponge term is
+                               // sigma u_i at the node itself and the cell has no slot; NaN = sigma varies: sponge_slot / sponge_B
   const double* lam;           // per-cell (per_cell=1) or null
   const double* mu;
   double lam0, mu0;

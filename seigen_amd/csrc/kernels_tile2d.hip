@@ -290,8 +290,14 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       const long ubase = ((long)item * ND) * 2 * 16;
       R* outb = out + ubase;            // wave-uniform
       const R* auxb = aux + ubase;
+      // sponge of this lane's cell: none (sig = 0), a sigma that is constant over the cell (sig: the term is sigma u at the
+      // node itself, no matrix) or a varying one (sig = NaN: the cell's matrix B_e in slot sslot) - kernels.hpp sponge_sigma
       int sslot = -1;
-      if (A.sponge_slot != nullptr && active) sslot = A.sponge_slot[e];
+      R sig = (R)0;
+      if (A.sponge_sigma != nullptr && active) {
+        sig = (R)A.sponge_sigma[e];
+        if (sig != sig) sslot = A.sponge_slot[e];
+      }
       R cs = (R)A.c_self, ca = (R)A.c_aux, cnw = (R)A.c_new;
       if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
         const R r0 = (R)A.rho2[2 * e], r1 = (R)A.rho2[2 * e + 1];
@@ -303,9 +309,18 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
       // row-quad of the item.  With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave
       // and the wave runs in program order, so these reads precede the stores (MT > 1: they are done before the
       // first row tile is stored).
-      const bool sponge_here = __any(sslot >= 0);
+      const bool sponge_here = __any(sig != (R)0);     // (NaN != 0: the lanes with a matrix count)
       R ssum[S4][2];
       auto sponge_sums = [&]() {
+        if (sslot < 0 && sig != (R)0) {     // constant sigma: sigma u_i at the lane's own rows
+          const R* ua = reinterpret_cast<const R*>(A.uabs) + ubase + w;
+#pragma unroll
+          for (int m = 0; m < S4; ++m) {
+            const int a = (4 * m + q < ND) ? 4 * m + q : 0;
+            ssum[m][0] = sig * ua[(a * 2 + 0) * 16];
+            ssum[m][1] = sig * ua[(a * 2 + 1) * 16];
+          }
+        }
         if (sslot >= 0) {
           const R* ua = reinterpret_cast<const R*>(A.uabs) + ubase + w;
           const double* B = A.sponge_B + ((long)sslot * ND + q) * ND;  // row a = 4 m + q: B + 4 m ND (double in both modes)
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(256) void tile2d_stage(const StageArgs A, const T2C
           }
       if (sponge_here) {
         if (MT == 1) sponge_sums();
-        if (sslot >= 0) {
+        if (sig != (R)0) {
 #pragma unroll
           for (int m = 0; m < S4T; ++m)
             if (4 * tile + m < S4) {

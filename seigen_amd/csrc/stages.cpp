@@ -62,6 +62,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.dbg = h->dbg ? h->dbg + 8 * (kind * 2 + (mode ? 1 : 0)) : nullptr;
   a.sponge_slot = (kind == 0) ? h->sponge_slot : nullptr;
   a.sponge_B = h->sponge_B;
+  a.sponge_sigma = (kind == 0) ? h->sponge_sigma : nullptr;
   a.lam = h->lam_d;
   a.mu = h->mu_d;
   a.lam0 = h->lam0;
@@ -108,7 +109,9 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     a.spread = (region == SG_REGION_BOUNDARY) ? 1 : 0;
     // only launches that run while an exchange is in flight leave block slots to RCCL
     a.grid_blocks = (region == SG_REGION_INTERIOR || region == SG_REGION_SECOND) ? h->grid_blocks : h->grid_full;
-    if (h->use_tile) a.grid_blocks = (h->sponge_slot && kind == 0) ? h->tile_grid_sponge : h->tile_grid;   // the sponge is part of F only
+    // (the sponge is part of F only, and only cells with a matrix of their own make items differ in cost: then one item per
+    // wave on the prime-strided grid)
+    if (h->use_tile) a.grid_blocks = (h->sponge_nslots > 0 && kind == 0) ? h->tile_grid_sponge : h->tile_grid;
     a.item_list = nullptr;
     a.nlist = 0;
     a.order_chunk = (h->use_mfma && !a.spread && kind == 0) ? h->order_chunk : 0;

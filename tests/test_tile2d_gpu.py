@@ -123,6 +123,52 @@ def test_tile_sponge_source_material_density_vs_generic(gpu, monkeypatch, degree
     assert rel_err(res["tile"][1], res["generic"][1]) < TOL
 
 
+@pytest.mark.parametrize("degree,n,diagonal", [(1, (21, 5), "left"), (2, (9, 6), "right"), (3, (18, 4), "left"), (4, (5, 7), "left"),
+                                               (2, (19, 4), "quadrilateral"), (4, (6, 5), "quadrilateral")])
+def test_tile_sponge_constant_on_a_cell_needs_no_matrix(gpu, monkeypatch, degree, n, diagonal):
+    """A sigma that is one value on all nodes of a cell (the reference's sponges: `x <= 20 ? 1000 : 0` interpolated into
+    DG4, explosive_source_lf4.py:42-45) makes the cell's sponge matrix sigma I: the tile kernels then take sigma u at the
+    node itself (StageArgs::sponge_sigma).  Cells of all three kinds in one block - none, constant, varying - and
+    neighbouring each other inside one 16-cell item: against the generic kernel (every sponge cell through its matrix)
+    and against the oracle."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    h = (0.9 / n[0], 1.1 / n[1])
+    dt = 0.05 * min(h) / degree ** 2
+    r = np.random.default_rng(11)
+    m = oracle_mesh(2, n, (0.9, 1.1), diagonal)
+    nq = m.node_coords(4).shape[1]
+    kind = r.integers(0, 3, size=m.ncells)                     # 0 none, 1 constant, 2 varying
+    sigma = np.zeros((m.ncells, nq))
+    sigma[kind == 1] = r.uniform(2.0, 30.0, size=((kind == 1).sum(), 1))
+    sigma[kind == 2] = r.uniform(0.0, 30.0, size=((kind == 2).sum(), nq))
+    u0 = r.uniform(-1, 1, (m.ncells,) + (HipBlock(2, degree, n, h, (0.0, 0.0), diagonal).field_shape(_lib.FIELD_U)[1:]))
+    s0 = r.uniform(-1, 1, u0.shape + (2,))
+    s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+    res = {}
+    for path in ("generic", "tile"):
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        blk = HipBlock(2, degree, n, h, (0.0, 0.0), diagonal)
+        blk.set_params(1.0, dt, 0.6, 0.3)
+        blk.set_absorption(sigma, 4)
+        blk.set_field(_lib.FIELD_U, u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.step(3)
+        res[path] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    orc = OracleLF4(m, degree)
+    orc.dt, orc.l, orc.mu, orc.density = dt, 0.6, 0.3, 1.0
+    orc.E.set_absorption(sigma, 4)
+    orc.u0, orc.s0 = u0.copy(), s0.copy()
+    for k in range(3):
+        orc.step((k + 1) * dt)
+    tol = 10 * (5 * TOL if (diagonal == "quadrilateral" and degree == 4) else TOL)
+    assert rel_err(res["tile"][0], res["generic"][0]) < tol
+    assert rel_err(res["tile"][1], res["generic"][1]) < tol
+    assert rel_err(res["tile"][0], orc.u1) < tol
+    assert rel_err(res["tile"][1], orc.s1) < tol
+
+
 @pytest.mark.parametrize("degree,n,grid", [
     (1, (20, 6), (2, 2)),
     (2, (33, 4), (2, 1)),
