@@ -56,6 +56,8 @@ void sg_destroy(sg_handle* h) {
   if (h->sponge_slot) (void)hipFree(h->sponge_slot);
   if (h->sponge_B) (void)hipFree(h->sponge_B);
   if (h->sponge_sigma) (void)hipFree(h->sponge_sigma);
+  if (h->sponge_cells) (void)hipFree(h->sponge_cells);
+  if (h->sponge_pre) (void)hipFree(h->sponge_pre);
   if (h->src_nodes) (void)hipFree(h->src_nodes);
   if (h->src_values) (void)hipFree(h->src_values);
   if (h->src_slot_d) (void)hipFree(h->src_slot_d);
@@ -504,6 +506,14 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
     h->sponge_sigma = nullptr;
   }
   h->sponge_nslots = 0;
+  if (h->sponge_cells) {
+    (void)hipFree(h->sponge_cells);
+    h->sponge_cells = nullptr;
+  }
+  if (h->sponge_pre) {
+    (void)hipFree(h->sponge_pre);
+    h->sponge_pre = nullptr;
+  }
   if (!sigma_nodes) return SG_OK;
   if (sigma_degree < 1 || sigma_degree > 6) return fail(h, SG_ERR_ARG, "sigma_degree must be 1..6");
   const int d = h->cfg.dim, nd = h->re.nd;
@@ -512,11 +522,11 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   std::vector<double> A = sponge_tensor(d, h->cfg.degree, sigma_degree, h->re.kind);
   std::vector<int32_t> slot((size_t)h->ncells, -1);
   std::vector<double> B;
-  // 2-D tile kernels: a sigma that is one value on all nodes of a cell (the piecewise-constant sponges of the reference's
+  // 2-D tile and 3-D MFMA kernels: a sigma that is one value on all nodes of a cell (the piecewise-constant sponges of the reference's
   // problem scripts, explosive_source_lf4.py:42-45) makes B_e = Minv (sigma M) = sigma I: such a cell carries its sigma
   // instead of a matrix (kernels.hpp StageArgs::sponge_sigma)
   std::vector<double> sig;
-  if (h->use_tile) sig.assign((size_t)h->ncells, 0.0);
+  if (h->use_tile || h->use_mfma) sig.assign((size_t)h->ncells, 0.0);
   int32_t nslots = 0;
   for (int64_t e = 0; e < h->ncells; ++e) {
     const double* sg_ = sigma_nodes + (size_t)e * nq;
@@ -545,6 +555,15 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   HIPCHECK(h, hipMalloc((void**)&h->sponge_slot, slot.size() * sizeof(int32_t)));
   HIPCHECK(h, hipMemcpy(h->sponge_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   h->sponge_nslots = nslots;
+  if (h->use_mfma && nslots > 0) {      // the 3-D MFMA kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
+                                         // kernels work their small matrices off themselves: a launch more per F stage costs them more
+    std::vector<int32_t> cells((size_t)nslots);
+    for (int64_t e = 0; e < h->ncells; ++e)
+      if (slot[(size_t)e] >= 0) cells[(size_t)slot[(size_t)e]] = (int32_t)e;
+    HIPCHECK(h, hipMalloc((void**)&h->sponge_cells, cells.size() * sizeof(int32_t)));
+    HIPCHECK(h, hipMemcpy(h->sponge_cells, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMalloc(&h->sponge_pre, (size_t)nslots * nd * d * (h->f32 ? sizeof(float) : sizeof(double))));
+  }
   if (!sig.empty()) {
     HIPCHECK(h, hipMalloc((void**)&h->sponge_sigma, sig.size() * sizeof(double)));
     HIPCHECK(h, hipMemcpy(h->sponge_sigma, sig.data(), sig.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -75,8 +75,10 @@ struct sg_handle {
   // sponge
   int32_t* sponge_slot = nullptr;
   double* sponge_B = nullptr;
-  double* sponge_sigma = nullptr;   // 2-D tile kernels only (kernels.hpp StageArgs::sponge_sigma)
+  double* sponge_sigma = nullptr;   // 2-D tile and 3-D MFMA kernels only (kernels.hpp StageArgs::sponge_sigma)
   int32_t sponge_nslots = 0;        // cells with a sponge matrix of their own
+  int32_t* sponge_cells = nullptr;  // [slot] -> cell: the pre-pass of the F stages (kernels.hpp launch_sponge_pre)
+  void* sponge_pre = nullptr;       // [slot][nd][dim] in the field type
   // source
   int64_t src_nnz = 0;
   int64_t src_nfirst = 0;  // source nodes are stored with those in cells of SG_REGION_FIRST first

@@ -587,6 +587,41 @@ __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64
   *p = *p + (T)(coef * sg_mul_rounded(scale, values[idx]));
 }
 
+// ---- sponge matrices of the cells whose sigma varies: sp[slot][a][i] = sum_b B_slot[a][b] u_abs[cell(slot)][b][i] ----------
+// One block per cell; u_abs in the layout of the kernel family (mesh_tables.hpp: gw cells interleaved).  Runs BEFORE the F
+// stage's launches (the stage may update u_abs in place); the stage kernels then read nd x dim values per such cell instead
+// of its nd x nd matrix - and no wave runs a matrix loop for the sake of one lane.
+template <typename T>
+__global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t* cells, T* sp, int nd, int dim, int ncls, int gw) {
+  extern __shared__ double s_u[];   // [nd][dim]
+  const int slot = blockIdx.x;
+  const long e = cells[slot], c = e / ncls, k = e - c * ncls;
+  const long base = (((c / gw) * ncls + k) * (long)nd) * dim * gw + c % gw;
+  for (int j = threadIdx.x; j < nd * dim; j += blockDim.x) s_u[j] = (double)uabs[base + (long)j * gw];
+  __syncthreads();
+  const double* Bs = B + (long)slot * nd * nd;
+  for (int j = threadIdx.x; j < nd * dim; j += blockDim.x) {
+    const int a = j / dim, i = j - a * dim;
+    double acc = 0.0;
+    for (int b = 0; b < nd; ++b) acc += Bs[a * nd + b] * s_u[b * dim + i];
+    sp[(long)slot * nd * dim + j] = (T)acc;
+  }
+}
+
+int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, void* sp, int32_t nslots, int nd, int dim, int ncls,
+                      int gw, int f32, void* stream) {
+  if (nslots <= 0) return 0;
+  const int threads = nd * dim <= 64 ? 64 : 128;
+  const size_t lds = (size_t)nd * dim * sizeof(double);
+  if (f32)
+    hipLaunchKernelGGL(sponge_pre_kernel<float>, dim3((unsigned)nslots), dim3(threads), lds, (hipStream_t)stream, (const float*)uabs, B,
+                       cells, (float*)sp, nd, dim, ncls, gw);
+  else
+    hipLaunchKernelGGL(sponge_pre_kernel<double>, dim3((unsigned)nslots), dim3(threads), lds, (hipStream_t)stream, (const double*)uabs,
+                       B, cells, (double*)sp, nd, dim, ncls, gw);
+  return (int)hipGetLastError();
+}
+
 __global__ void step_counter_kernel(int64_t* ctr, int64_t value, int add) { *ctr = add ? *ctr + value : value; }
 
 int launch_step_counter(int64_t* ctr, int64_t value, int add, void* stream) {

@@ -111,8 +111,9 @@ struct StageArgs {
   unsigned long long* dbg; // diagnostic builds (-DSG_STAMPS): per-phase cycle sums, else null
   const int32_t* sponge_slot;  // [cell] -> slot or -1 (null: no sponge)
   const double* sponge_B;      // [slot][nd(a)][nd(b)]
-  const double* sponge_sigma;  // 2-D tile kernels: [cell] 0 = no sponge; a value = sigma is CONSTANT over the cell, the sponge term is
+  const double* sponge_sigma;  // 2-D tile and 3-D MFMA kernels: [cell] 0 = no sponge; a value = sigma is CONSTANT over the cell, the sponge term is
                                // sigma u_i at the node itself and the cell has no slot; NaN = sigma varies: sponge_slot / sponge_B
+  const void* sponge_pre;      // 3-D MFMA kernels: [slot][nd][dim] = B_slot u_abs of the cell, computed before the stage (launch_sponge_pre)
   const double* lam;           // per-cell (per_cell=1) or null
   const double* mu;
   double lam0, mu0;
@@ -240,6 +241,10 @@ int launch_pack(const MeshDev* md_dev, const MeshDev& md_host, const void* field
 // (values are scaled by `scale` and rounded first: a separable source's weight of this step)
 int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* offs, const double* values, double coef,
                   double scale, const SrcStep& ss, int f32, void* stream);
+// sp[slot][a][i] = sum_b B[slot][a][b] u_abs[cell of slot][b][i] for the cells with a sponge matrix of their own (one block per
+// cell), queued before the F stage's launches (StageArgs::sponge_pre)
+int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, void* sp, int32_t nslots, int nd, int dim, int ncls,
+                      int gw, int f32, void* stream);
 // the device-side step counter of SrcStep: *ctr = value (add = 0) or *ctr += value (add = 1), one thread
 int launch_step_counter(int64_t* ctr, int64_t value, int add, void* stream);
 

@@ -1091,41 +1091,48 @@ __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stag
 
     SG_PRIO(SG_PRIO_EPI);
     STAMP(st3);
-    // ---- sponge (rare): -sum_b B_e[a][b] u_abs[b][i] on the lanes whose cell carries sigma.
-    // With the in-place combine u_abs may be `out`: every lane of a cell sits in this wave and the
-    // wave runs in program order, so all reads below precede the writes of the epilogue.
-    if (A.sponge_slot != nullptr) {
-      const int slot = L.active ? A.sponge_slot[e] : -1;
-      if (__any(slot >= 0)) {
-        if (slot >= 0) {
-          auto damp = [&](int a, R& r0, R& r1, R& r2) {
-            if (a < ND) {
-              const double* B = A.sponge_B + ((long)slot * ND + a) * ND;   // sponge matrices stay double
-              const R* ua = reinterpret_cast<const R*>(A.uabs);
-              R s0 = 0, s1 = 0, s2 = 0;
-              for (int b = 0; b < ND; ++b) {
-                const R bb = (R)B[b];
-                s0 += bb * ua[ubase + (b * 3 + 0) * 16];
-                s1 += bb * ua[ubase + (b * 3 + 1) * 16];
-                s2 += bb * ua[ubase + (b * 3 + 2) * 16];
+    // ---- sponge: -M^-1 int sigma phi_a phi_b u_abs[b][i] (elastic.py:207-208) on the lanes whose cell carries sigma.
+    // A sigma that is one value on all nodes of the cell - the piecewise-constant sponges of the reference's problem
+    // scripts - makes that -sigma u_abs at the node itself (StageArgs::sponge_sigma holds the value).  A varying one has a
+    // matrix B_e (sponge_sigma = NaN, sponge_slot): B_e u_abs of those cells is computed by a launch of its own before the
+    // stage (StageArgs::sponge_pre, kernels.hip sponge_pre_kernel) - a matrix loop here would hold the whole wave for the
+    // sake of one lane, and an item that straddles the edge of a sponge strip has such a lane.  Either way a lane reads
+    // one value per row and component: same loads, different base, stride and factor.  With the in-place combine u_abs
+    // may be `out`: every lane of a cell sits in this wave and the wave runs in program order, so the reads below precede
+    // the writes of the epilogue (and the pre-pass ran before the stage).
+    if (A.sponge_sigma != nullptr) {
+      R sig = (R)0;
+      int slot = -1;
+      if (L.active) {
+        sig = (R)A.sponge_sigma[e];
+        if (sig != sig) slot = A.sponge_slot[e];
+      }
+      if (__any(sig != (R)0)) {      // (NaN != 0: the lanes with a matrix count)
+        if (sig != (R)0) {
+          constexpr int NR = 4 * MTF + NSM;     // row-quads of this lane: node 4 r + q
+          const bool dense = slot >= 0;
+          const R* pb = dense ? reinterpret_cast<const R*>(A.sponge_pre) + ((long)slot * ND + q) * 3
+                              : reinterpret_cast<const R*>(A.uabs) + ub_q;
+          const int es = dense ? 1 : 16;
+          const R sc = dense ? (R)1 : sig;
+          R uo[NR][3];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int o = (4 * r + q < ND) ? 4 * r * 3 * es : 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) uo[r][i] = pb[o + i * es];
+          }
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (4 * r + q < ND) {
+                const R v = sc * uo[r][i];
+                if (r < 4 * MTF)
+                  acc[i][r >> 2][r & 3] -= v;
+                else
+                  accs[i][r - 4 * MTF] -= v;
               }
-              r0 -= s0;
-              r1 -= s1;
-              r2 -= s2;
-            }
-          };
-#pragma unroll
-          for (int t = 0; t < MTF; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              R r0 = acc[0][t][reg], r1 = acc[1][t][reg], r2 = acc[2][t][reg];
-              damp(16 * t + 4 * reg + q, r0, r1, r2);
-              acc[0][t][reg] = r0;
-              acc[1][t][reg] = r1;
-              acc[2][t][reg] = r2;
-            }
-#pragma unroll
-          for (int t = 0; t < NSM; ++t) damp(16 * MTF + 4 * t + q, accs[0][t], accs[1][t], accs[2][t]);
         }
       }
     }

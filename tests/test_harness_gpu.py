@@ -234,6 +234,7 @@ def _multiblock_case(dim, degree, n, grid, pipelined, extras=False, dtype="f64",
         r3 = np.random.default_rng(77)
         nq = 5 ** dim if diagonal == "quadrilateral" else {1: 5, 2: 15, 3: 35}[dim]
         sigma = np.where(r3.uniform(size=(single.ncells, nq)) > 0.6, 3.0, 0.0)
+        sigma[::4] = 3.0          # every fourth cell: one value on all nodes (applied without a matrix where a family can)
         src_nodes = np.unique(r3.integers(0, single.ncells * nd, size=min(40, single.ncells * nd)))
         sv = r3.uniform(-1, 1, size=(3, len(src_nodes), dim, dim))
         src_vals = 0.5 * (sv + np.swapaxes(sv, -1, -2))

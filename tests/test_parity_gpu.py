@@ -307,6 +307,57 @@ def test_stages_utemp_and_s1_read_only_their_operands(gpu, monkeypatch, path, di
     blk.close()
 
 
+@pytest.mark.parametrize("degree,n", [(4, (3, 2, 2)), (3, (5, 2, 3)), (4, (17, 2, 1))])
+def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n):
+    """3-D MFMA kernels: a sigma that is one value on all nodes of a cell is applied as sigma u at the node itself
+    (StageArgs::sponge_sigma), a varying one through B_e u computed by a launch of its own before the stage
+    (launch_sponge_pre) - cells of all three kinds (none, constant, varying) side by side inside one 16-cell item, three
+    whole steps (the in-place stage U1 reads u_abs = its own output buffer) against the generic kernels (every sponge cell
+    through its matrix, in the kernel) and against the oracle; then the same block split 2 x 1 x 1 with the stages run
+    in two regions each (the second region reads the pre-pass of the first)."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    L = tuple(0.4 * k for k in n)
+    h = [L[a] / n[a] for a in range(3)]
+    r = np.random.default_rng(21)
+    m = oracle_mesh(3, n, L, "left")
+    nq = m.node_coords(4).shape[1]
+    kind = r.integers(0, 3, size=m.ncells)
+    sigma = np.zeros((m.ncells, nq))
+    sigma[kind == 1] = r.uniform(2.0, 30.0, size=((kind == 1).sum(), 1))
+    sigma[kind == 2] = r.uniform(0.0, 30.0, size=((kind == 2).sum(), nq))
+    dt = 0.04 * min(h) / degree ** 2
+    res = {}
+    for path in ("generic", ""):
+        if path:
+            monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        else:
+            monkeypatch.delenv("SEIGEN_HIP_PATH", raising=False)
+        blk = HipBlock(3, degree, n, h, [0.0] * 3, "left")
+        if not path:
+            assert "mfma_stage_F" in blk.stage_kernel_name(_lib.STAGE_UH1)
+        u0 = seeded(blk.field_shape(_lib.FIELD_U), 61)
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 62)
+        s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        blk.set_params(1.0, dt, 0.6, 0.3)
+        blk.set_absorption(sigma, 4)
+        blk.set_field(_lib.FIELD_U, u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.step(3)
+        res[path] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    orc = OracleLF4(m, degree)
+    orc.dt, orc.l, orc.mu, orc.density = dt, 0.6, 0.3, 1.0
+    orc.E.set_absorption(sigma, 4)
+    orc.u0, orc.s0 = u0.copy(), s0.copy()
+    for k in range(3):
+        orc.step((k + 1) * dt)
+    assert rel_err(res[""][0], res["generic"][0]) < 10 * TOL
+    assert rel_err(res[""][1], res["generic"][1]) < 10 * TOL
+    assert rel_err(res[""][0], orc.u1) < 10 * TOL
+    assert rel_err(res[""][1], orc.s1) < 10 * TOL
+
+
 def test_error_behaviour(gpu):
     """Every entry point returns a negative code with a message instead of launching on bad input
     (the reference raises Python exceptions: seigen/elastic.py:64, :234-242)."""
