@@ -342,9 +342,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
       // ---- F: uh_i = line_x(T_i0) + line_y(T_i1) + line_z(T_i2) - sponge (elastic.py:204-209), one result component at
       //      a time (a rolled loop: the code of an item stays small).  T_i2 is held whole; T_i0 and T_i1 stream through
       //      plane by plane, the next plane requested while this one is worked on.
+      // sponge of this lane's cube: a sigma that is one value on all its nodes is applied as sigma u_abs at the node; a varying
+      // one through B_e u_abs, computed before the stage by a launch of its own (StageArgs::sponge_sigma / sponge_pre; a
+      // matrix loop here - 64 or 125 columns per value - would hold the wave for every cube at the edge of a sponge strip).
+      // One load per value either way: another base, stride and factor.
+      double sig = 0.0;
       int sslot = -1;
-      if (A.sponge_slot != nullptr && active) sslot = A.sponge_slot[e];
-      const bool any_sponge = A.sponge_slot != nullptr && __any(sslot >= 0);
+      if (A.sponge_sigma != nullptr && active) {
+        sig = A.sponge_sigma[e];
+        if (sig != sig) sslot = A.sponge_slot[e];
+      }
+      const bool any_sponge = A.sponge_sigma != nullptr && __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
+      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * 3
+                                       : A.uabs + (g * (long)ND) * 3 * 16 + w;
+      const int sp_es = sslot >= 0 ? 1 : 16;
+      const double sp_sc = sslot >= 0 ? 1.0 : sig;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
       if (MODE == 1 && A.rho2 != nullptr) {   // per-cell density (kernels.hpp)
         cs = A.rho2[2 * e];
@@ -384,20 +396,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
           X_plane(o, Va[s2], xt[s2]);
           Y_plane(o, Vb[s2], y0[s2], y1[s2]);
           if (any_sponge) {
-            // - sum_b B_e[a][b] u_abs[b][i] on the lanes whose cube carries sigma (rare: a layer of cells)
-            if (sslot >= 0) {
-              const double* B = A.sponge_B + (long)sslot * ND * ND;
-              const double* ua = A.uabs + (g * (long)ND) * 3 * 16 + w;
+            if (sig != 0.0) {
+              double sv[KSX][N1];
 #pragma unroll
               for (int i1 = 0; i1 < N1; ++i1)
 #pragma unroll
-                for (int ks = 0; ks < KSX; ++ks) {
-                  const int a = i0c[ks] + N1 * (i1 + N1 * i2);
-                  double sp = 0.0;
-#pragma unroll 1
-                  for (int b = 0; b < ND; ++b) sp += B[(long)a * ND + b] * ua[(b * 3 + i) * 16];
-                  o[ks][i1] -= sp;
-                }
+                for (int ks = 0; ks < KSX; ++ks) sv[ks][i1] = sp_pb[((i0c[ks] + N1 * (i1 + N1 * i2)) * 3 + i) * sp_es];
+#pragma unroll
+              for (int i1 = 0; i1 < N1; ++i1)
+#pragma unroll
+                for (int ks = 0; ks < KSX; ++ks) o[ks][i1] -= sp_sc * sv[ks][i1];
             }
           }
           if (MODE >= 1) {     // (MODE 2, stage UTEMP: out = c_aux aux + c_new rhs, stages.cpp)

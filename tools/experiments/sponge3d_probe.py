@@ -15,20 +15,21 @@ from seigen_amd.harness import baseline_configs as bc
 seigen_amd.elastic.log = lambda s: None
 
 
-def run(n, sponge, steps=20):
+def run(n, sponge, steps=20, hexa=0):
     h = 2.5
     L = n * h
-    if sponge:
+    if sponge or hexa:
         # config4_share builds and sets up; the sponge has to be in place before setup(): rebuild by hand
         from seigen_amd import BoxMesh, ElasticLF4, Vp, cfl_dt
-        mesh = BoxMesh(n, n, n, L, L, L)
-        el = ElasticLF4.create(mesh, "DG", 4, dimension=3, solver="explicit", output=False)
+        mesh = BoxMesh(n, n, n, L, L, L, hexahedral=bool(hexa))
+        el = ElasticLF4.create(mesh, "DQ" if hexa else "DG", hexa or 4, dimension=3, solver="explicit", output=False)
         el.density, el.mu, el.l = 1.0, 3600.0, 3599.3664
         el.dt = cfl_dt(h, Vp(el.mu, el.l, el.density), 0.05) / 8
-        el.absorption_function = Function(FunctionSpace(mesh, "DG", 4))
-        w = 8 * h
-        el.absorption = Expression("x[0] <= %r || x[0] >= %r || x[1] <= %r || x[1] >= %r || x[2] <= %r ? 1000 : 0"
-                                   % (w, L - w, w, L - w, w))
+        if sponge:
+            el.absorption_function = Function(FunctionSpace(mesh, "DQ" if hexa else "DG", 4))
+            w = 8 * h
+            el.absorption = Expression("x[0] <= %r || x[0] >= %r || x[1] <= %r || x[1] >= %r || x[2] <= %r ? 1000 : 0"
+                                       % (w, L - w, w, L - w, w))
         el.setup()
         el.block.set_source([], None)
         rng = np.random.default_rng(0)
@@ -48,11 +49,12 @@ def run(n, sponge, steps=20):
     c1 = blk.counters()
     st = [round((c1["kernel_ms"][i] - c0["kernel_ms"][i]) / steps, 3) for i in range(6)]
     dofs = blk.u_dofs + blk.s_dofs
-    print("n %d sponge %s: %.1f G DoF-updates/s, %.3f ms/step, stages %s" % (n, sponge, dofs / ms / 1e6, ms, st), flush=True)
+    print("%s n %d sponge %s: %.1f G DoF-updates/s, %.3f ms/step, stages %s" % ("hexahedra DQ_%d" % hexa if hexa else "tetrahedra P4", n, sponge, dofs / ms / 1e6, ms, st), flush=True)
     blk.close()
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    run(n, False)
-    run(n, True)
+    hexa = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 3 / 4: hexahedra of that degree
+    run(n, False, hexa=hexa)
+    run(n, True, hexa=hexa)
