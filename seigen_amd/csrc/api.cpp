@@ -526,7 +526,7 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   // problem scripts, explosive_source_lf4.py:42-45) makes B_e = Minv (sigma M) = sigma I: such a cell carries its sigma
   // instead of a matrix (kernels.hpp StageArgs::sponge_sigma)
   std::vector<double> sig;
-  if (h->use_tile || h->use_mfma || h->use_hexm) sig.assign((size_t)h->ncells, 0.0);
+  if (h->use_tile || h->use_mfma || h->use_hexm || h->use_lane) sig.assign((size_t)h->ncells, 0.0);
   int32_t nslots = 0;
   for (int64_t e = 0; e < h->ncells; ++e) {
     const double* sg_ = sigma_nodes + (size_t)e * nq;
@@ -555,7 +555,7 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   HIPCHECK(h, hipMalloc((void**)&h->sponge_slot, slot.size() * sizeof(int32_t)));
   HIPCHECK(h, hipMemcpy(h->sponge_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   h->sponge_nslots = nslots;
-  if ((h->use_mfma || h->use_hexm) && nslots > 0) {      // the 3-D matrix kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
+  if ((h->use_mfma || h->use_hexm || h->use_lane) && nslots > 0) {      // the 3-D matrix kernels and the lane kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
                                          // kernels work their small matrices off themselves: a launch more per F stage costs them more
     std::vector<int32_t> cells((size_t)nslots);
     for (int64_t e = 0; e < h->ncells; ++e)

@@ -171,10 +171,20 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
     if (KIND == 0) {
       // ---- F, one velocity component i at a time: only row i of the stress is needed, which
       //      halves (2-D) the live registers and doubles the resident waves
+      // sponge of this lane's cell: a sigma that is one value on all its nodes is applied as sigma u_abs at the node, a varying
+      // one through B_e u_abs computed before the stage by a launch of its own (StageArgs::sponge_sigma / sponge_pre): one
+      // load per value either way - another base, stride and factor - instead of an nd x nd matrix per lane
+      double sig = 0.0;
       int sslot = -1;
-      if (A.sponge_slot != nullptr && L.active) sslot = A.sponge_slot[e];
-      const bool any_sponge = __any(sslot >= 0);
+      if (A.sponge_sigma != nullptr && L.active) {
+        sig = A.sponge_sigma[e];
+        if (sig != sig) sslot = A.sponge_slot[e];
+      }
+      const bool any_sponge = __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
       const long ubase = ((g * NCLS + k) * (long)ND) * DIM * 64 + lane;
+      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * DIM : A.uabs + ubase;
+      const int sp_es = sslot >= 0 ? 1 : 64;
+      const double sp_sc = sslot >= 0 ? 1.0 : sig;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
       const bool self = A.c_self != 0.0 || A.rho2 != nullptr;     // uniform
       if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
         double ua[ND];
         if (any_sponge) {
 #pragma unroll
-          for (int b = 0; b < ND; ++b) ua[b] = A.uabs[ubase + (b * DIM + i) * 64];
+          for (int b = 0; b < ND; ++b) ua[b] = sig != 0.0 ? sp_sc * sp_pb[(b * DIM + i) * sp_es] : 0.0;
         }
         double po[ND], pa[ND];
         if (MODE == 1) {     // a.mode 2 (UTEMP: no self term) arrives here with c_self = 0 and `out` is not read
@@ -242,11 +252,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
           for (int f = 0; f < NFACES; ++f)
 #pragma unroll
             for (int bp = 0; bp < NF; ++bp) acc += Lop[(f * ND + a) * NF + bp] * fl[f][bp];
-          if (any_sponge && sslot >= 0) {
-            const double* B = A.sponge_B + ((long)sslot * ND + a) * ND;
-#pragma unroll
-            for (int b = 0; b < ND; ++b) acc -= B[b] * ua[b];
-          }
+          if (any_sponge) acc -= ua[a];
           if (MODE == 1) acc = cs * po[a] + ca * pa[a] + cn * acc;
           if (L.active) out[ubase + (a * DIM + i) * 64] = acc;
         }
@@ -442,10 +448,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
     };
 
     if (KIND == 0) {
+      // sponge of this lane's cell: a sigma that is one value on all its nodes is applied as sigma u_abs at the node, a varying
+      // one through B_e u_abs computed before the stage by a launch of its own (StageArgs::sponge_sigma / sponge_pre): one
+      // load per value either way - another base, stride and factor - instead of an nd x nd matrix per lane
+      double sig = 0.0;
       int sslot = -1;
-      if (A.sponge_slot != nullptr && L.active) sslot = A.sponge_slot[e];
-      const bool any_sponge = __any(sslot >= 0);
+      if (A.sponge_sigma != nullptr && L.active) {
+        sig = A.sponge_sigma[e];
+        if (sig != sig) sslot = A.sponge_slot[e];
+      }
+      const bool any_sponge = __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
       const long ubase = (g * (long)ND) * DIM * 64 + lane;
+      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * DIM : A.uabs + ubase;
+      const int sp_es = sslot >= 0 ? 1 : 64;
+      const double sp_sc = sslot >= 0 ? 1.0 : sig;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
       const bool self = A.c_self != 0.0 || A.rho2 != nullptr;     // uniform
       if (MODE == 1 && A.rho2 != nullptr) {
@@ -488,18 +504,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
             }
         }
         if (any_sponge) {
-          double ua[ND];
+          if (sig != 0.0) {
+            double ua[ND];
 #pragma unroll
-          for (int b = 0; b < ND; ++b) ua[b] = A.uabs[ubase + (b * DIM + i) * 64];
-          if (sslot >= 0) {
-            const double* B = A.sponge_B + (long)sslot * ND * ND;
+            for (int b = 0; b < ND; ++b) ua[b] = sp_pb[(b * DIM + i) * sp_es];
 #pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              double sacc = 0.0;
-#pragma unroll
-              for (int b = 0; b < ND; ++b) sacc += B[a * ND + b] * ua[b];
-              acc[a] -= sacc;
-            }
+            for (int a = 0; a < ND; ++a) acc[a] -= sp_sc * ua[a];
           }
         }
         if (MODE == 1) {

@@ -307,9 +307,14 @@ def test_stages_utemp_and_s1_read_only_their_operands(gpu, monkeypatch, path, di
     blk.close()
 
 
-@pytest.mark.parametrize("degree,n", [(4, (3, 2, 2)), (3, (5, 2, 3)), (4, (17, 2, 1))])
-def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n):
-    """3-D MFMA kernels: a sigma that is one value on all nodes of a cell is applied as sigma u at the node itself
+@pytest.mark.parametrize("degree,n,diagonal,family", [
+    (4, (3, 2, 2), "left", "mfma_stage_F"), (3, (5, 2, 3), "left", "mfma_stage_F"), (4, (17, 2, 1), "left", "mfma_stage_F"),
+    (2, (5, 3, 2), "left", "lane"), (1, (9, 2, 2), "left", "lane"),                                   # lane-per-cell kernels
+    (2, (5, 2, 3), "quadrilateral", "lane"), (1, (7, 3, 2), "quadrilateral", "lane"),               # hexahedra DQ_1 / DQ_2
+    (3, (5, 2, 2), "quadrilateral", "hexm_stage"), (4, (3, 2, 1), "quadrilateral", "hexm_stage"),   # hexahedra DQ_3 / DQ_4
+])
+def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n, diagonal, family):
+    """3-D kernel families: a sigma that is one value on all nodes of a cell is applied as sigma u at the node itself
     (StageArgs::sponge_sigma), a varying one through B_e u computed by a launch of its own before the stage
     (launch_sponge_pre) - cells of all three kinds (none, constant, varying) side by side inside one 16-cell item, three
     whole steps (the in-place stage U1 reads u_abs = its own output buffer) against the generic kernels (every sponge cell
@@ -320,7 +325,7 @@ def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n):
     L = tuple(0.4 * k for k in n)
     h = [L[a] / n[a] for a in range(3)]
     r = np.random.default_rng(21)
-    m = oracle_mesh(3, n, L, "left")
+    m = oracle_mesh(3, n, L, diagonal)
     nq = m.node_coords(4).shape[1]
     kind = r.integers(0, 3, size=m.ncells)
     sigma = np.zeros((m.ncells, nq))
@@ -331,11 +336,14 @@ def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n):
     for path in ("generic", ""):
         if path:
             monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+        elif family == "lane":
+            monkeypatch.setenv("SEIGEN_HIP_PATH", "lane")
         else:
             monkeypatch.delenv("SEIGEN_HIP_PATH", raising=False)
-        blk = HipBlock(3, degree, n, h, [0.0] * 3, "left")
+        blk = HipBlock(3, degree, n, h, [0.0] * 3, diagonal)
         if not path:
-            assert "mfma_stage_F" in blk.stage_kernel_name(_lib.STAGE_UH1)
+            name = blk.stage_kernel_name(_lib.STAGE_UH1)
+            assert (("lane_stage" in name or "hex_stage" in name) if family == "lane" else family in name), name
         u0 = seeded(blk.field_shape(_lib.FIELD_U), 61)
         s0 = seeded(blk.field_shape(_lib.FIELD_S), 62)
         s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
@@ -352,10 +360,11 @@ def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n):
     orc.u0, orc.s0 = u0.copy(), s0.copy()
     for k in range(3):
         orc.step((k + 1) * dt)
-    assert rel_err(res[""][0], res["generic"][0]) < 10 * TOL
-    assert rel_err(res[""][1], res["generic"][1]) < 10 * TOL
-    assert rel_err(res[""][0], orc.u1) < 10 * TOL
-    assert rel_err(res[""][1], orc.s1) < 10 * TOL
+    tol = 10 * tol_of(degree, diagonal) * (2 if diagonal == "quadrilateral" else 1)
+    assert rel_err(res[""][0], res["generic"][0]) < tol
+    assert rel_err(res[""][1], res["generic"][1]) < tol
+    assert rel_err(res[""][0], orc.u1) < tol
+    assert rel_err(res[""][1], orc.s1) < tol
 
 
 def test_error_behaviour(gpu):

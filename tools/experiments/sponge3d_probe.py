@@ -55,6 +55,6 @@ def run(n, sponge, steps=20, hexa=0):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    hexa = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 3 / 4: hexahedra of that degree
+    hexa = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 1 .. 4: hexahedra of that degree
     run(n, False, hexa=hexa)
     run(n, True, hexa=hexa)
