@@ -2,6 +2,8 @@
 // family choice), parameters, sponge, source and the table exports.  Field transfers: transfer.cpp; stage launches,
 // the fused six-launch LF4 step (seigen/elastic.py:283-313) and halo packs: stages.cpp.
 #include <limits>
+#include <string>
+#include <unordered_map>
 
 #include "handle.hpp"
 
@@ -57,6 +59,7 @@ void sg_destroy(sg_handle* h) {
   if (h->sponge_B) (void)hipFree(h->sponge_B);
   if (h->sponge_sigma) (void)hipFree(h->sponge_sigma);
   if (h->sponge_cells) (void)hipFree(h->sponge_cells);
+  if (h->sponge_mat) (void)hipFree(h->sponge_mat);
   if (h->sponge_pre) (void)hipFree(h->sponge_pre);
   if (h->src_nodes) (void)hipFree(h->src_nodes);
   if (h->src_values) (void)hipFree(h->src_values);
@@ -510,6 +513,10 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
     (void)hipFree(h->sponge_cells);
     h->sponge_cells = nullptr;
   }
+  if (h->sponge_mat) {
+    (void)hipFree(h->sponge_mat);
+    h->sponge_mat = nullptr;
+  }
   if (h->sponge_pre) {
     (void)hipFree(h->sponge_pre);
     h->sponge_pre = nullptr;
@@ -527,7 +534,14 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
   // instead of a matrix (kernels.hpp StageArgs::sponge_sigma)
   std::vector<double> sig;
   if (h->use_tile || h->use_mfma || h->use_hexm || h->use_lane) sig.assign((size_t)h->ncells, 0.0);
-  int32_t nslots = 0;
+  // Cells with the same nodal sigma share one matrix (A is the reference element's): the strips of the reference's scripts
+  // have a few dozen distinct edge cells, a sigma that depends on one coordinate n0 x classes - the matrix table stays in
+  // the caches.  Families that read B u_abs from the pre-pass number their matrix cells (slot -> cell, slot -> matrix); the
+  // others look the matrix up by the slot itself.
+  const bool pre_family = h->use_mfma || h->use_hexm || h->use_lane;
+  std::unordered_map<std::string, int32_t> mat_id;
+  std::vector<int32_t> mat_of;
+  int32_t nslots = 0, nmat = 0;
   for (int64_t e = 0; e < h->ncells; ++e) {
     const double* sg_ = sigma_nodes + (size_t)e * nq;
     bool nz = false, same = true;
@@ -540,28 +554,46 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
       sig[(size_t)e] = same ? sg_[0] : std::numeric_limits<double>::quiet_NaN();
       if (same) continue;
     }
-    slot[e] = nslots++;
-    size_t base = B.size();
-    B.resize(base + (size_t)nd * nd, 0.0);
-    for (int a = 0; a < nd; ++a)
-      for (int c = 0; c < nq; ++c) {
-        double s = sg_[c];
-        if (s == 0.0) continue;
-        const double* Arow = &A[((size_t)a * nq + c) * nd];
-        double* Brow = &B[base + (size_t)a * nd];
-        for (int b = 0; b < nd; ++b) Brow[b] += Arow[b] * s;
-      }
+    const std::string key(reinterpret_cast<const char*>(sg_), (size_t)nq * sizeof(double));
+    auto found = mat_id.find(key);
+    int32_t m;
+    if (found != mat_id.end()) {
+      m = found->second;
+    } else {
+      m = nmat++;
+      mat_id.emplace(key, m);
+      size_t base = B.size();
+      B.resize(base + (size_t)nd * nd, 0.0);
+      for (int a = 0; a < nd; ++a)
+        for (int c = 0; c < nq; ++c) {
+          double s = sg_[c];
+          if (s == 0.0) continue;
+          const double* Arow = &A[((size_t)a * nq + c) * nd];
+          double* Brow = &B[base + (size_t)a * nd];
+          for (int b = 0; b < nd; ++b) Brow[b] += Arow[b] * s;
+        }
+    }
+    if (pre_family) {
+      slot[e] = nslots++;
+      mat_of.push_back(m);
+    } else {
+      slot[e] = m;
+      nslots = nmat;
+    }
   }
   HIPCHECK(h, hipMalloc((void**)&h->sponge_slot, slot.size() * sizeof(int32_t)));
   HIPCHECK(h, hipMemcpy(h->sponge_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   h->sponge_nslots = nslots;
-  if ((h->use_mfma || h->use_hexm || h->use_lane) && nslots > 0) {      // the 3-D matrix kernels and the lane kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
-                                         // kernels work their small matrices off themselves: a launch more per F stage costs them more
+  if (pre_family && nslots > 0) {
+    // the 3-D matrix kernels and the lane kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
+    // kernels work their small matrices off themselves: a launch more per F stage costs them more
     std::vector<int32_t> cells((size_t)nslots);
     for (int64_t e = 0; e < h->ncells; ++e)
       if (slot[(size_t)e] >= 0) cells[(size_t)slot[(size_t)e]] = (int32_t)e;
     HIPCHECK(h, hipMalloc((void**)&h->sponge_cells, cells.size() * sizeof(int32_t)));
     HIPCHECK(h, hipMemcpy(h->sponge_cells, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMalloc((void**)&h->sponge_mat, mat_of.size() * sizeof(int32_t)));
+    HIPCHECK(h, hipMemcpy(h->sponge_mat, mat_of.data(), mat_of.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHECK(h, hipMalloc(&h->sponge_pre, (size_t)nslots * nd * d * (h->f32 ? sizeof(float) : sizeof(double))));
   }
   if (!sig.empty()) {

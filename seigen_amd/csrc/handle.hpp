@@ -78,6 +78,7 @@ struct sg_handle {
   double* sponge_sigma = nullptr;   // 2-D tile and 3-D MFMA kernels only (kernels.hpp StageArgs::sponge_sigma)
   int32_t sponge_nslots = 0;        // cells with a sponge matrix of their own
   int32_t* sponge_cells = nullptr;  // [slot] -> cell: the pre-pass of the F stages (kernels.hpp launch_sponge_pre)
+  int32_t* sponge_mat = nullptr;    // [slot] -> matrix in sponge_B (cells with the same nodal sigma share one)
   void* sponge_pre = nullptr;       // [slot][nd][dim] in the field type
   // source
   int64_t src_nnz = 0;

@@ -592,14 +592,15 @@ __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64
 // stage's launches (the stage may update u_abs in place); the stage kernels then read nd x dim values per such cell instead
 // of its nd x nd matrix - and no wave runs a matrix loop for the sake of one lane.
 template <typename T>
-__global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t* cells, T* sp, int nd, int dim, int ncls, int gw) {
+__global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t* cells, const int32_t* mats, T* sp, int nd, int dim,
+                                  int ncls, int gw) {
   extern __shared__ double s_u[];   // [nd][dim]
   const int slot = blockIdx.x;
   const long e = cells[slot], c = e / ncls, k = e - c * ncls;
   const long base = (((c / gw) * ncls + k) * (long)nd) * dim * gw + c % gw;
   for (int j = threadIdx.x; j < nd * dim; j += blockDim.x) s_u[j] = (double)uabs[base + (long)j * gw];
   __syncthreads();
-  const double* Bs = B + (long)slot * nd * nd;
+  const double* Bs = B + (long)mats[slot] * nd * nd;     // cells with the same nodal sigma share a matrix
   for (int j = threadIdx.x; j < nd * dim; j += blockDim.x) {
     const int a = j / dim, i = j - a * dim;
     double acc = 0.0;
@@ -608,17 +609,17 @@ __global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t*
   }
 }
 
-int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, void* sp, int32_t nslots, int nd, int dim, int ncls,
-                      int gw, int f32, void* stream) {
+int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, const int32_t* mats, void* sp, int32_t nslots, int nd,
+                      int dim, int ncls, int gw, int f32, void* stream) {
   if (nslots <= 0) return 0;
   const int threads = nd * dim <= 64 ? 64 : 128;
   const size_t lds = (size_t)nd * dim * sizeof(double);
   if (f32)
     hipLaunchKernelGGL(sponge_pre_kernel<float>, dim3((unsigned)nslots), dim3(threads), lds, (hipStream_t)stream, (const float*)uabs, B,
-                       cells, (float*)sp, nd, dim, ncls, gw);
+                       cells, mats, (float*)sp, nd, dim, ncls, gw);
   else
     hipLaunchKernelGGL(sponge_pre_kernel<double>, dim3((unsigned)nslots), dim3(threads), lds, (hipStream_t)stream, (const double*)uabs,
-                       B, cells, (double*)sp, nd, dim, ncls, gw);
+                       B, cells, mats, (double*)sp, nd, dim, ncls, gw);
   return (int)hipGetLastError();
 }
 

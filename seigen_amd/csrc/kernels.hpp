@@ -243,8 +243,8 @@ int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* of
                   double scale, const SrcStep& ss, int f32, void* stream);
 // sp[slot][a][i] = sum_b B[slot][a][b] u_abs[cell of slot][b][i] for the cells with a sponge matrix of their own (one block per
 // cell), queued before the F stage's launches (StageArgs::sponge_pre)
-int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, void* sp, int32_t nslots, int nd, int dim, int ncls,
-                      int gw, int f32, void* stream);
+int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, const int32_t* mats, void* sp, int32_t nslots, int nd,
+                      int dim, int ncls, int gw, int f32, void* stream);
 // the device-side step counter of SrcStep: *ctr = value (add = 0) or *ctr += value (add = 1), one thread
 int launch_step_counter(int64_t* ctr, int64_t value, int add, void* stream);
 

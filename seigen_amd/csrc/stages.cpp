@@ -67,7 +67,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   if (kind == 0 && h->sponge_pre && !h->name_out &&
       (region == SG_REGION_ALL || region == SG_REGION_FIRST || region == SG_REGION_INTERIOR)) {
     // the first launch of an F stage: B_e u_abs of the cells with a sponge matrix, before anything of the stage writes
-    if (launch_sponge_pre(a.uabs, h->sponge_B, h->sponge_cells, h->sponge_pre, h->sponge_nslots, h->re.nd, h->cfg.dim, h->ncls,
+    if (launch_sponge_pre(a.uabs, h->sponge_B, h->sponge_cells, h->sponge_mat, h->sponge_pre, h->sponge_nslots, h->re.nd, h->cfg.dim, h->ncls,
                           (int)h->md.gw, h->f32, h->stream) != 0)
       return fail(h, SG_ERR_DEVICE, "sponge pre-pass launch failed");
     // SECOND runs on its own stream after ev_stage - "everything before this stage's FIRST" - and reads the pre-pass too
