@@ -509,6 +509,8 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
     h->sponge_sigma = nullptr;
   }
   h->sponge_nslots = 0;
+  h->sponge_pre_key = -1;
+  h->sponge_pre_regions = 0;
   if (h->sponge_cells) {
     (void)hipFree(h->sponge_cells);
     h->sponge_cells = nullptr;

@@ -80,6 +80,7 @@ struct sg_handle {
   int32_t* sponge_cells = nullptr;  // [slot] -> cell: the pre-pass of the F stages (kernels.hpp launch_sponge_pre)
   int32_t* sponge_mat = nullptr;    // [slot] -> matrix in sponge_B (cells with the same nodal sigma share one)
   void* sponge_pre = nullptr;       // [slot][nd][dim] in the field type
+  int sponge_pre_key = -1, sponge_pre_regions = 0;   // the F stage (output field, mode) whose pre-pass ran last, and the regions launched since
   // source
   int64_t src_nnz = 0;
   int64_t src_nfirst = 0;  // source nodes are stored with those in cells of SG_REGION_FIRST first

@@ -64,9 +64,18 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
   a.sponge_B = h->sponge_B;
   a.sponge_sigma = (kind == 0) ? h->sponge_sigma : nullptr;
   a.sponge_pre = (kind == 0) ? h->sponge_pre : nullptr;
-  if (kind == 0 && h->sponge_pre && !h->name_out &&
-      (region == SG_REGION_ALL || region == SG_REGION_FIRST || region == SG_REGION_INTERIOR)) {
-    // the first launch of an F stage: B_e u_abs of the cells with a sponge matrix, before anything of the stage writes
+  // the first launch of an F stage - whichever region the caller starts with: the same stage again, or a region it has
+  // already seen, is the next instance of the stage
+  bool first_of_stage = false;
+  if (kind == 0 && h->sponge_pre && !h->name_out) {
+    const int key = out_f * 4 + mode;
+    first_of_stage = key != h->sponge_pre_key || (h->sponge_pre_regions & (1 << region)) != 0 || region == SG_REGION_ALL;
+    if (first_of_stage) h->sponge_pre_regions = 0;
+    h->sponge_pre_key = key;
+    h->sponge_pre_regions |= 1 << region;
+  }
+  if (first_of_stage) {
+    // B_e u_abs of the cells with a sponge matrix, before anything of the stage writes
     if (launch_sponge_pre(a.uabs, h->sponge_B, h->sponge_cells, h->sponge_mat, h->sponge_pre, h->sponge_nslots, h->re.nd, h->cfg.dim, h->ncls,
                           (int)h->md.gw, h->f32, h->stream) != 0)
       return fail(h, SG_ERR_DEVICE, "sponge pre-pass launch failed");
