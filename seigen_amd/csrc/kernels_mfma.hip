@@ -934,6 +934,23 @@ __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stag
       ca *= (R)A.rho2[2 * e + 1];
       cn *= (R)A.rho2[2 * e + 1];
     }
+    // Sponge of this lane's cell (the block further down): a sigma that is constant over the cell enters as -sigma u_abs at
+    // the node.  In the fused stages u_abs IS one of the combine's operands - `out` in stage U1, `aux` in stage UTEMP - so
+    // the term is a change of that operand's coefficient, no load and no arithmetic of its own.
+    R sig = (R)0;
+    bool sig_folded = false;
+    if (A.sponge_sigma != nullptr && L.active) {
+      sig = (R)A.sponge_sigma[e];
+      if (FUSED && sig == sig && sig != (R)0) {
+        if (SELF && A.uabs == A.out) {
+          cs -= cn * sig;
+          sig_folded = true;
+        } else if (A.uabs == A.aux) {
+          ca -= cn * sig;
+          sig_folded = true;
+        }
+      }
+    }
     // old values of the in-place combine: every one of the item requested before the first is used
     R po[M::MTFA][4][3], pa[M::MTFA][4][3], pos[M::NSMA][3], pas[M::NSMA][3];
     auto fetch_old = [&]() {
@@ -1101,14 +1118,11 @@ __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stag
     // may be `out`: every lane of a cell sits in this wave and the wave runs in program order, so the reads below precede
     // the writes of the epilogue (and the pre-pass ran before the stage).
     if (A.sponge_sigma != nullptr) {
-      R sig = (R)0;
       int slot = -1;
-      if (L.active) {
-        sig = (R)A.sponge_sigma[e];
-        if (sig != sig) slot = A.sponge_slot[e];
-      }
-      if (__any(sig != (R)0)) {      // (NaN != 0: the lanes with a matrix count)
-        if (sig != (R)0) {
+      if (sig != sig) slot = A.sponge_slot[e];
+      const bool sp_here = sig != (R)0 && !sig_folded;      // (NaN != 0: the lanes with a matrix count)
+      if (__any(sp_here)) {
+        if (sp_here) {
           constexpr int NR = 4 * MTF + NSM;     // row-quads of this lane: node 4 r + q
           const bool dense = slot >= 0;
           const R* pb = dense ? reinterpret_cast<const R*>(A.sponge_pre) + ((long)slot * ND + q) * 3
