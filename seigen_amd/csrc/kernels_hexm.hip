@@ -352,17 +352,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HXW<P>::WPE
         sig = A.sponge_sigma[e];
         if (sig != sig) sslot = A.sponge_slot[e];
       }
-      const bool any_sponge = A.sponge_sigma != nullptr && __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
-      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * 3
-                                       : A.uabs + (g * (long)ND) * 3 * 16 + w;
-      const int sp_es = sslot >= 0 ? 1 : 16;
-      const double sp_sc = sslot >= 0 ? 1.0 : sig;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
       if (MODE == 1 && A.rho2 != nullptr) {   // per-cell density (kernels.hpp)
         cs = A.rho2[2 * e];
         ca *= A.rho2[2 * e + 1];
         cn *= A.rho2[2 * e + 1];
       }
+      // in the fused stages u_abs IS one of the combine's operands (`out` in stage U1, `aux` in stage UTEMP): a constant
+      // sigma then changes that operand's coefficient - no load, no arithmetic of its own
+      if (MODE >= 1 && sslot < 0 && sig != 0.0) {
+        if (MODE == 1 && A.uabs == A.out) {
+          cs -= cn * sig;
+          sig = 0.0;
+        } else if (A.uabs == A.aux) {
+          ca -= cn * sig;
+          sig = 0.0;
+        }
+      }
+      const bool any_sponge = A.sponge_sigma != nullptr && __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
+      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * 3
+                                       : A.uabs + (g * (long)ND) * 3 * 16 + w;
+      const int sp_es = sslot >= 0 ? 1 : 16;
+      const double sp_sc = sslot >= 0 ? 1.0 : sig;
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         const int c0 = cix(i, 0), c1 = cix(i, 1), c2 = cix(i, 2);

@@ -180,11 +180,7 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
         sig = A.sponge_sigma[e];
         if (sig != sig) sslot = A.sponge_slot[e];
       }
-      const bool any_sponge = __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
       const long ubase = ((g * NCLS + k) * (long)ND) * DIM * 64 + lane;
-      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * DIM : A.uabs + ubase;
-      const int sp_es = sslot >= 0 ? 1 : 64;
-      const double sp_sc = sslot >= 0 ? 1.0 : sig;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
       const bool self = A.c_self != 0.0 || A.rho2 != nullptr;     // uniform
       if (MODE == 1 && A.rho2 != nullptr) {  // per-cell density (kernels.hpp)
@@ -192,6 +188,21 @@ __global__ __launch_bounds__(256) void lane_stage(StageArgs A) {
         ca *= A.rho2[2 * e + 1];
         cn *= A.rho2[2 * e + 1];
       }
+      // in the fused stages u_abs IS one of the combine's operands (`out` in stage U1, `aux` in stage UTEMP): a constant
+      // sigma then changes that operand's coefficient - no load, no arithmetic of its own
+      if (MODE == 1 && sslot < 0 && sig != 0.0) {
+        if (self && A.uabs == A.out) {
+          cs -= cn * sig;
+          sig = 0.0;
+        } else if (A.uabs == A.aux) {
+          ca -= cn * sig;
+          sig = 0.0;
+        }
+      }
+      const bool any_sponge = __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
+      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * DIM : A.uabs + ubase;
+      const int sp_es = sslot >= 0 ? 1 : 64;
+      const double sp_sc = sslot >= 0 ? 1.0 : sig;
 #pragma unroll
       for (int i = 0; i < DIM; ++i) {
         double q[ND][DIM];  // T_ij (j = 0..DIM-1) at every node, all requested at once
@@ -457,11 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
         sig = A.sponge_sigma[e];
         if (sig != sig) sslot = A.sponge_slot[e];
       }
-      const bool any_sponge = __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
       const long ubase = (g * (long)ND) * DIM * 64 + lane;
-      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * DIM : A.uabs + ubase;
-      const int sp_es = sslot >= 0 ? 1 : 64;
-      const double sp_sc = sslot >= 0 ? 1.0 : sig;
       double cs = A.c_self, ca = A.c_aux, cn = A.c_new;
       const bool self = A.c_self != 0.0 || A.rho2 != nullptr;     // uniform
       if (MODE == 1 && A.rho2 != nullptr) {
@@ -469,6 +476,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_HEX_WPE(
         ca *= A.rho2[2 * e + 1];
         cn *= A.rho2[2 * e + 1];
       }
+      // in the fused stages u_abs IS one of the combine's operands (`out` in stage U1, `aux` in stage UTEMP): a constant
+      // sigma then changes that operand's coefficient - no load, no arithmetic of its own
+      if (MODE == 1 && sslot < 0 && sig != 0.0) {
+        if (self && A.uabs == A.out) {
+          cs -= cn * sig;
+          sig = 0.0;
+        } else if (A.uabs == A.aux) {
+          ca -= cn * sig;
+          sig = 0.0;
+        }
+      }
+      const bool any_sponge = __any(sig != 0.0);     // (NaN != 0: the lanes with a matrix count)
+      const double* sp_pb = sslot >= 0 ? reinterpret_cast<const double*>(A.sponge_pre) + (long)sslot * ND * DIM : A.uabs + ubase;
+      const int sp_es = sslot >= 0 ? 1 : 64;
+      const double sp_sc = sslot >= 0 ? 1.0 : sig;
 #pragma unroll
       for (int i = 0; i < DIM; ++i) {
         double acc[ND];
