@@ -937,11 +937,13 @@ __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stag
     // Sponge of this lane's cell (the block further down): a sigma that is constant over the cell enters as -sigma u_abs at
     // the node.  In the fused stages u_abs IS one of the combine's operands - `out` in stage U1, `aux` in stage UTEMP - so
     // the term is a change of that operand's coefficient, no load and no arithmetic of its own.
+    // (the plain stage asks for its sigma where it uses it, further down: asked here it changes the register allocation of
+    // the whole item and costs the stage 3 % - without any sponge set)
     R sig = (R)0;
     bool sig_folded = false;
-    if (A.sponge_sigma != nullptr && L.active) {
+    if (FUSED && A.sponge_sigma != nullptr && L.active) {
       sig = (R)A.sponge_sigma[e];
-      if (FUSED && sig == sig && sig != (R)0) {
+      if (sig == sig && sig != (R)0) {
         if (SELF && A.uabs == A.out) {
           cs -= cn * sig;
           sig_folded = true;
@@ -1118,6 +1120,7 @@ __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stag
     // may be `out`: every lane of a cell sits in this wave and the wave runs in program order, so the reads below precede
     // the writes of the epilogue (and the pre-pass ran before the stage).
     if (A.sponge_sigma != nullptr) {
+      if (!FUSED && L.active) sig = (R)A.sponge_sigma[e];
       int slot = -1;
       if (sig != sig) slot = A.sponge_slot[e];
       const bool sp_here = sig != (R)0 && !sig_folded;      // (NaN != 0: the lanes with a matrix count)
