@@ -15,7 +15,7 @@ from seigen_amd.harness import baseline_configs as bc
 seigen_amd.elastic.log = lambda s: None
 
 
-def run(n, sponge, steps=20, hexa=0):
+def run(n, sponge, steps=20, hexa=0, ramp=False):
     h = 2.5
     L = n * h
     if sponge or hexa:
@@ -28,8 +28,12 @@ def run(n, sponge, steps=20, hexa=0):
         if sponge:
             el.absorption_function = Function(FunctionSpace(mesh, "DQ" if hexa else "DG", 4))
             w = 8 * h
-            el.absorption = Expression("x[0] <= %r || x[0] >= %r || x[1] <= %r || x[1] >= %r || x[2] <= %r ? 1000 : 0"
-                                       % (w, L - w, w, L - w, w))
+            if ramp:      # sigma varies inside every sponge cell: a linear ramp over the strips
+                el.absorption = Expression("fmax(fmax(fmax(%r - x[0], x[0] - %r), fmax(%r - x[1], x[1] - %r)), fmax(%r - x[2], 0.0)) * 50.0"
+                                           % (w, L - w, w, L - w, w))
+            else:
+                el.absorption = Expression("x[0] <= %r || x[0] >= %r || x[1] <= %r || x[1] >= %r || x[2] <= %r ? 1000 : 0"
+                                           % (w, L - w, w, L - w, w))
         el.setup()
         el.block.set_source([], None)
         rng = np.random.default_rng(0)
@@ -49,7 +53,7 @@ def run(n, sponge, steps=20, hexa=0):
     c1 = blk.counters()
     st = [round((c1["kernel_ms"][i] - c0["kernel_ms"][i]) / steps, 3) for i in range(6)]
     dofs = blk.u_dofs + blk.s_dofs
-    print("%s n %d sponge %s: %.1f G DoF-updates/s, %.3f ms/step, stages %s" % ("hexahedra DQ_%d" % hexa if hexa else "tetrahedra P4", n, sponge, dofs / ms / 1e6, ms, st), flush=True)
+    print("%s n %d sponge %s: %.1f G DoF-updates/s, %.3f ms/step, stages %s" % ("hexahedra DQ_%d" % hexa if hexa else "tetrahedra P4", n, ("ramp" if ramp else sponge), dofs / ms / 1e6, ms, st), flush=True)
     blk.close()
 
 
@@ -58,3 +62,5 @@ if __name__ == "__main__":
     hexa = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # 1 .. 4: hexahedra of that degree
     run(n, False, hexa=hexa)
     run(n, True, hexa=hexa)
+    if len(sys.argv) > 3:
+        run(n, True, hexa=hexa, ramp=True)
