@@ -347,10 +347,14 @@ def halo_block(elastic, m, comm, backend):
     ex, c0, c1, nst = elastic._exchanger, m["c0"], m["c1"], m["steps"]
     st = ex.stats()
     ms = [c1["kernel_ms"][i] - c0["kernel_ms"][i] for i in range(6)]
-    return {"transport": "host-staged/%s" % backend if ex.staged else backend,
+    # the native exchange moves device buffers over its own RCCL communicator whatever the process group is
+    return {"transport": "nccl" if getattr(ex, "native", False) else ("host-staged/%s" % backend if ex.staged else backend),
             # who drives the exchange: the library itself (csrc/comm.cpp: one C-ABI call per run of steps) or the
             # Python exchanger stage by stage (seigen_amd/parallel.py)
             "driver": "native" if getattr(ex, "native", False) else "python",
+            # which RCCL the native exchange is bound to (sg_comm_library / sg_comm_version): the copy already in the
+            # process, the system's, or the file SEIGEN_RCCL_LIB names
+            "rccl_library": getattr(ex, "library", None), "rccl_version": getattr(ex, "version", None),
             "pack_ms_per_step": comm.gather((c1["halo_pack_ms"] - c0["halo_pack_ms"]) / nst),
             "bytes_sent_per_step": comm.gather((c1["halo_bytes_packed"] - c0["halo_bytes_packed"]) / nst),
             # everything a stage waited for its traces (same definition as the round-1/2 records) ...

@@ -259,9 +259,14 @@ typedef struct sg_comm_stats {
 int sg_comm_get_unique_id(void* id, size_t nbytes);
 int sg_comm_init(sg_handle* h, const void* id, size_t nbytes, int rank, int nranks, const int32_t* peers);
 /* RCCL is bound at run time, on first use: the copy already in the process (torch brings its own) or the system's
- * librccl.so; SG_ERR_STATE where there is none (single blocks and the device-free entry points do not need it).
- * sg_comm_version: its version as RCCL encodes it (e.g. 22606). */
+ * librccl.so - or the one file the environment variable SEIGEN_RCCL_LIB names (a site's own build; the transport
+ * double of tests/fake_rccl) - and must report the major version of the rccl.h this library was compiled against;
+ * SG_ERR_STATE where there is none or the wrong one (single blocks and the device-free entry points do not need it).
+ * sg_comm_version: its version as RCCL encodes it (e.g. 22707).  sg_comm_library: the path of the shared object the
+ * bound entry points come from, NUL-terminated into buf[n] - which MPI / which RCCL moved the traces is part of a
+ * run's record (the reference prints its MPI through PyOP2's configuration, tests/tiling/utils.py:143-144 timers). */
 int sg_comm_version(int* version);
+int sg_comm_library(char* buf, size_t n);
 /* Everything sg_comm_init can refuse WITHOUT another rank (RCCL present, rank / nranks, peers[] against
  * sg_config::nbr_mask; two sides may share a peer only as the two ends of one axis).  Hosts call it on every rank and
  * agree on the result BEFORE the collective sg_comm_init: a rank that failed alone would leave the others waiting. */
@@ -271,7 +276,7 @@ int sg_comm_check(sg_handle* h, int rank, int nranks, const int32_t* peers);
  * (0 = every side receives its neighbour's trace; the role of a halo-exchange consistency check before a run).
  * Receives are posted in the order of the facing sides, so two faces between the same pair of ranks - a block that is
  * its own neighbour across an axis - are paired correctly, not mirrored. */
-int sg_comm_selftest(sg_handle* h, int64_t* mismatches);
+int sg_comm_selftest(sg_handle* h, int64_t* mismatches);   /* SG_ERR_STATE once traces have been exchanged: it overwrites the ghost buffers */
 int sg_comm_finalize(sg_handle* h);
 int sg_comm_get_stats(sg_handle* h, sg_comm_stats_t* out, int reset);
 /* one exchange of `field`'s traces on its own (tests), and the device addresses of a side's buffers */

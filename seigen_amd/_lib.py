@@ -75,6 +75,7 @@ SYMBOLS = {
     "sg_comm_get_unique_id": (C.c_int, [_P, C.c_size_t]),
     "sg_comm_init": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "sg_comm_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "sg_comm_library": (C.c_int, [C.c_char_p, C.c_size_t]),
     "sg_comm_check": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "sg_comm_selftest": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sg_comm_finalize": (C.c_int, [_P]),

@@ -17,6 +17,16 @@ def comm_unique_id():
     return bytes(buf.raw)
 
 
+def comm_library():
+    """(path, version) of the RCCL the native exchange is bound to (sg_comm_library / sg_comm_version); raises where
+    there is none."""
+    buf = C.create_string_buffer(1024)
+    check(_lib.load().sg_comm_library(buf, len(buf)))
+    v = C.c_int()
+    check(_lib.load().sg_comm_version(C.byref(v)))
+    return buf.value.decode(), int(v.value)
+
+
 class HipBlock(object):
     def __init__(self, dim, degree, n, h, origin, diagonal="left", nbr_mask=0, device=0, stream=None, dtype="f64",
                  cube0=None):

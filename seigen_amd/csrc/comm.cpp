@@ -17,7 +17,11 @@
 // RCCL is bound lazily, on the first sg_comm_* call that needs it: libseigen_hip.so loads - and every single-block and
 // device-free entry point works - on a machine without RCCL, and inside a process that has an RCCL already (torch
 // brings its own copy) the calls resolve to THAT copy instead of mixing two versions in one process.  The entry
-// points come from the copy already in the process (RTLD_DEFAULT) or, failing that, from librccl.so of the system.
+// points come from the copy already in the process (RTLD_DEFAULT) or, failing that, from librccl.so of the system -
+// or, when SEIGEN_RCCL_LIB names a file, from that file and nothing else (a site's own RCCL build; the transport
+// double of tests/fake_rccl).  Whatever was bound must report the major version of the <rccl/rccl.h> this file was
+// compiled against (enum values and argument layouts are only checked at compile time otherwise), and the file it came
+// from is recorded (sg_comm_library) so that a run can say which copy moved its traces.
 namespace {
 struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
@@ -30,6 +34,8 @@ struct RcclApi {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
   bool ok = false;
+  int version = 0;
+  std::string path;   // the shared object ncclCommInitRank lives in (dladdr)
   std::string err;
 };
 
@@ -37,7 +43,14 @@ const RcclApi& rccl() {
   static const RcclApi api = [] {
     RcclApi a;
     void* lib = RTLD_DEFAULT;
-    if (!dlsym(RTLD_DEFAULT, "ncclCommInitRank")) {
+    if (const char* named = std::getenv("SEIGEN_RCCL_LIB"); named && *named) {
+      lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) {
+        const char* why = dlerror();
+        a.err = std::string("SEIGEN_RCCL_LIB=") + named + " could not be loaded: " + (why ? why : "?");
+        return a;
+      }
+    } else if (!dlsym(RTLD_DEFAULT, "ncclCommInitRank")) {
       lib = nullptr;
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -65,7 +78,22 @@ const RcclApi& rccl() {
     bind(a.Send, "ncclSend");
     bind(a.Recv, "ncclRecv");
     bind(a.GetVersion, "ncclGetVersion");
-    a.ok = all;
+    if (!all) return a;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(a.CommInitRank), &info) && info.dli_fname) a.path = info.dli_fname;
+    if (a.GetVersion(&a.version) != ncclSuccess) {
+      a.err = "ncclGetVersion failed (" + a.path + ")";
+      return a;
+    }
+    // RCCL encodes 2.27.7 as 22707 (NCCL_VERSION, rccl.h; releases before 2.9 used major * 1000)
+    const int major = a.version >= 10000 ? a.version / 10000 : a.version / 1000;
+    if (major != NCCL_MAJOR) {
+      a.err = "the RCCL in this process (" + a.path + ", version " + std::to_string(a.version) + ") has major version " +
+              std::to_string(major) + ", this library was compiled against " + std::to_string(NCCL_MAJOR) + "." +
+              std::to_string(NCCL_MINOR);
+      return a;
+    }
+    a.ok = true;
     return a;
   }();
   return api;
@@ -81,6 +109,7 @@ struct sg_comm_state {
   void* recv[2][6];
   size_t count[6];    // values per side (dim per facet node for either kind)
   sg_comm_stats_t stats;
+  bool used = false;   // field traces have been exchanged: the ghost buffers hold data a stage may still read
   std::vector<hipEvent_t> wait_events;   // pairs (end of SECOND, end of the receives) still to be read
   std::vector<hipEvent_t> event_pool;
 };
@@ -135,17 +164,19 @@ static int exchange(sg_handle* h, int field, hipEvent_t* recv_done, bool pack = 
     rc = sg_halo_pack_sides(h, field, outs);
     if (rc != SG_OK) return rc;
   }
+  if (pack) c->used = true;
   const ncclDataType_t ty = h->f32 ? ncclFloat : ncclDouble;
-  static const bool dry = std::getenv("SEIGEN_COMM_DRY") != nullptr;   // measurements only: everything but the transport
-  if (dry) {
-    c->stats.exchanges += 1;
-    if (recv_done) {
-      rc = take_event(h, recv_done);
-      if (rc != SG_OK) return rc;
-      HIPCHECK(h, hipEventRecord(*recv_done, h->stream));
-    }
-    return SG_OK;
+#ifdef SG_COMM_DRY
+  // experiment builds only (make EXTRA=-DSG_COMM_DRY, tools/experiments/neighbour_overhead2.py): everything but the
+  // transport - the results of a block with neighbours are WRONG; never part of the shipped library
+  c->stats.exchanges += 1;
+  if (recv_done) {
+    rc = take_event(h, recv_done);
+    if (rc != SG_OK) return rc;
+    HIPCHECK(h, hipEventRecord(*recv_done, h->stream));
   }
+  return SG_OK;
+#endif
   const RcclApi& nc = rccl();
   NCCLCHECK(h, nc.GroupStart());
   // sends in the order of my sides ...
@@ -254,7 +285,20 @@ int sg_comm_version(int* version) {
     g_create_err = rccl().err;
     return SG_ERR_STATE;
   }
-  return rccl().GetVersion(version) == ncclSuccess ? SG_OK : SG_ERR_DEVICE;
+  *version = rccl().version;
+  return SG_OK;
+}
+
+// which RCCL moves the traces: the file the bound entry points come from (torch's bundled copy, the system's librccl.so,
+// the file SEIGEN_RCCL_LIB names) - PyOP2 prints its MPI the same way in the reference's logs
+int sg_comm_library(char* buf, size_t n) {
+  if (!buf || n == 0) return SG_ERR_ARG;
+  if (!rccl().ok) {
+    g_create_err = rccl().err;
+    return SG_ERR_STATE;
+  }
+  std::snprintf(buf, n, "%s", rccl().path.c_str());
+  return SG_OK;
 }
 
 // everything sg_comm_init can refuse WITHOUT talking to another rank: the host calls it on every rank and agrees on
@@ -366,7 +410,13 @@ int sg_comm_selftest(sg_handle* h, int64_t* mismatches) {
   if (int rc = join_second(h)) return rc;
   const size_t es = h->f32 ? sizeof(float) : sizeof(double);
   *mismatches = 0;
-  if (std::getenv("SEIGEN_COMM_DRY") != nullptr) return SG_OK;   // measurements without the transport: nothing to test
+  // the test writes patterns into the send AND ghost buffers and leaves them zeroed: once traces have been exchanged a
+  // stage may still read them, and zero traces would be a silently wrong run
+  if (c->used)
+    return fail(h, SG_ERR_STATE, "sg_comm_selftest overwrites the ghost buffers: call it right after sg_comm_init, before any exchange or step");
+#ifdef SG_COMM_DRY
+  return SG_OK;   // experiment builds without the transport: nothing to test
+#endif
   const sg_comm_stats_t keep = c->stats;      // not part of the run's statistics
   std::vector<double> hd;
   std::vector<float> hf;

@@ -254,7 +254,11 @@ class ElasticLF4(object):
                 import torch
                 dev = torch.device("cuda", _device_for_rank())
                 import torch.distributed as dist
-                native = dist.get_backend() == "nccl" and os.environ.get("SEIGEN_HALO_NATIVE", "1") != "0" \
+                # SEIGEN_HALO_NATIVE: "1" (default) = inside the library when the process group is RCCL's; "0" = never;
+                # "force" = also under a process group without device transport (gloo, MPI): the library makes its
+                # own RCCL communicator, the group only carries the unique id and the ranks' agreement
+                want = os.environ.get("SEIGEN_HALO_NATIVE", "1")
+                native = (want == "force" or (dist.get_backend() == "nccl" and want != "0")) \
                     and os.environ.get("SEIGEN_HALO_SCHEDULE", "pipelined") != "plain"
                 if native:      # the exchange inside the library: one C-ABI call per run of steps (csrc/comm.cpp)
                     # every rank must end up on the same path: agree on whether the communicator came up everywhere

@@ -129,6 +129,8 @@ class NativeExchanger(object):
             raise
         self._sent0 = 0
         self.timing = False
+        from .backend import comm_library
+        self.library, self.version = comm_library()      # which RCCL moves the traces: part of a run's record
 
     @property
     def bytes_sent(self):

@@ -30,9 +30,22 @@ def main():
     grid = tuple(int(x) for x in sys.argv[5].split(","))
     source = {"source": True, "asym": "asym"}.get(sys.argv[6], False) if len(sys.argv) > 6 else False
     part = Partition(n, rank, world, grid)
+    if os.environ.get("SEIGEN_TEST_BAD_PEERS_RANK") == str(rank):
+        # tests/test_native_exchange_gpu.py: THIS rank hands the library's argument check a peer on a side that has no
+        # neighbour - sg_comm_check refuses it locally, and the ranks must agree to fall back together
+        from seigen_amd.backend import HipBlock
+        good_check = HipBlock.comm_check
+
+        def bad_check(self, r, nr, peers):
+            peers = list(peers)
+            peers[[i for i, p in enumerate(peers) if p is None][0]] = (r + 1) % nr
+            return good_check(self, r, nr, peers)
+        HipBlock.comm_check = bad_check
     el, u, s = run_case(n, degree, nsteps, part, source)
+    ex = el._exchanger
     np.savez(os.path.join(out, "rank%d.npz" % rank), u=u, s=s, start=np.array(part.start), n=np.array(part.n),
-             bytes_sent=el._exchanger.bytes_sent, staged=int(el._exchanger.staged), device=dev)
+             bytes_sent=ex.bytes_sent, staged=int(ex.staged), device=dev, native=int(getattr(ex, "native", False)),
+             library=str(getattr(ex, "library", "")))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -5,7 +5,7 @@ source wavelet, which cells are sampled); each side builds its own mesh, operato
 
   c3  3-D eigenmode, 64^3 cubes x 6 tets, P4, FP64 (tests/eigenmode/eigenmode_3d.py:7-40), 3 LF4 steps
   c2  2-D explosive source, 512 x 512 squares, P2, DG4 sponge + box source (explosive_source_lf4.py:17-45), 20 steps
-  c5  Marmousi 382 x 120 squares, P3, per-cell lambda / mu from seigen/marmousi.py's lookup and a per-cell Gardner
+  c5  Marmousi 383 x 121 squares, P3, per-cell lambda / mu from seigen/marmousi.py's lookup and a per-cell Gardner
       density in the physical update, box source, 20 steps
 c2 and c5 start from a smooth non-zero state (so that the sponge and every cell's material act from the first
 step) and use the reference's Ricker wavelet centred ten steps into the run (so that the source is at full

@@ -159,7 +159,7 @@ def test_config2_full_size_vs_oracle(gpu, quadrilateral):
 
 
 def test_config5_full_size_vs_oracle(gpu):
-    """Marmousi 382 x 120 squares, P3, per-cell lambda / mu and Gardner density (physical update), box-Ricker
+    """Marmousi 383 x 121 squares, P3, per-cell lambda / mu and Gardner density (physical update), box-Ricker
     source (BASELINE config 5) on the 2-D MFMA tile kernels, 20 steps from a smooth state."""
     _quiet()
     from seigen_amd import ElasticLF4, Function, RectangleMesh
