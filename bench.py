@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="f64: the reference's precision (headline); f32: the separately reported FP32 second mode "
-                         "(SURVEY 8d, 32 B per DoF-update)")
+                         "(SURVEY 8d; 30 B per DoF-update on this step's 90 words per node)")
     ap.add_argument("--workload", choices=("c3", "c4"), default=None,
                     help="c3: weak scaling of config 3 (default); c4: BASELINE config 4 (256^3 in total, 4 or 8 GPUs; "
                          "one GPU: one rank's 128^3 share).  8 ranks without this flag: c3 plus a \"config4\" object")
@@ -637,10 +637,15 @@ def main():
                 if self.done:       # the extra finished while the timer was firing
                     return
                 self.expired = True
-                note = json.loads(json.dumps(out, default=str))     # a snapshot the main thread cannot change under us
-            target = note if self.holder is None else note.setdefault(self.holder, {})
-            target[self.key] = {"error": "timed out after the headline measurement; headline unaffected"}
+            # from here on the process ends in this thread, whatever happens: __exit__ sleeps once `expired` is set,
+            # so nothing between that and os._exit may be able to raise past the finally
             try:
+                try:                # a snapshot the main thread cannot change under us ...
+                    note = json.loads(json.dumps(out, default=str))
+                except Exception:   # noqa: BLE001 ... or, if it is changing it right now, the top level as it stands
+                    note = dict(out)
+                target = note if self.holder is None else note.setdefault(self.holder, {})
+                target[self.key] = {"error": "timed out after the headline measurement; headline unaffected"}
                 if world > 1:
                     faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 finish(note)

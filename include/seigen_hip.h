@@ -33,6 +33,14 @@
 extern "C" {
 #endif
 
+/* ABI version: bumped whenever the MEANING of an existing entry point, argument or field changes (new entry points
+ * alone do not bump it).  A host that drives stages itself must check it: it is the only sign of such a change.
+ *   1  rounds 1-4: SG_FIELD_UH holds utemp after stage UTEMP; stage S1 reads sh1 (SG_FIELD_SH) and utemp
+ *   2  round 5: stage UTEMP leaves w = dt u1 + dt^3/24 utemp in SG_FIELD_UH, stage S1 = s0 + Minv g(w) reads
+ *      SG_FIELD_UH and SG_FIELD_S only (enum sg_stage below); (u1, s1) unchanged to round-off */
+#define SG_ABI_VERSION 2
+int sg_abi_version(void);   /* the SG_ABI_VERSION the loaded library was built with (device-free) */
+
 #define SG_OK 0
 #define SG_ERR_ARG (-1)      /* bad argument */
 #define SG_ERR_DEVICE (-2)   /* HIP runtime error / no device */

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_ENV = "SEIGEN_HIP_LIB"
 
 SG_OK = 0
+ABI_VERSION = 2      # SG_ABI_VERSION of include/seigen_hip.h this binding was written against
 FIELD_U, FIELD_UH, FIELD_S, FIELD_SH = 0, 1, 2, 3
 STAGE_UH1, STAGE_STEMP, STAGE_U1, STAGE_SH1, STAGE_UTEMP, STAGE_S1 = range(6)
 REGION_ALL, REGION_INTERIOR, REGION_BOUNDARY, REGION_FIRST, REGION_SECOND = 0, 1, 2, 3, 4
@@ -44,6 +45,7 @@ class SgCounters(C.Structure):
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
 SYMBOLS = {
+    "sg_abi_version": (C.c_int, []),
     "sg_create": (C.c_int, [C.POINTER(SgConfig), C.POINTER(_P)]),
     "sg_destroy": (None, [_P]),
     "sg_last_error": (C.c_char_p, [_P]),
@@ -123,6 +125,10 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    have = lib.sg_abi_version()
+    if have != ABI_VERSION:
+        raise SeigenHipError("%s was built with SG_ABI_VERSION %d, this binding expects %d (include/seigen_hip.h): rebuild the "
+                             "library" % (path, have, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -140,6 +140,8 @@ void region_boxes(int d, const int32_t n[3], const int32_t has_nbr[6], int regio
 
 extern "C" {
 
+int sg_abi_version(void) { return SG_ABI_VERSION; }
+
 int sg_block_node_coords(const sg_config* cfg, int degree, double* out, size_t nbytes) {
   if (!cfg || !out || degree < 1 || degree > 8 || cfg->dim < 1 || cfg->dim > 3) return SG_ERR_ARG;
   NodeGeom G;

@@ -617,3 +617,16 @@ def test_partition_peers_satisfy_the_native_exchange_preconditions():
             for s, q in named:
                 assert parts[q].neighbour(s ^ 1) == r, (world, grid, r, s, q)
                 assert all((s >> 1) == (t >> 1) for t, q2 in named if q2 == q), "one rank behind two axes"
+
+
+def test_experiment_patches_are_indexed_and_apply():
+    """tools/experiments/*.patch are the code of closed experiments; each is pinned in PATCHES.txt to the newest commit
+    whose tree takes it (HEAD for those that must keep applying) and check_patches.sh verifies the index.  Needs the
+    history (skipped in an export without .git)."""
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git history here")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "experiments", "check_patches.sh")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok ") >= 9

@@ -318,8 +318,10 @@ def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n, diagon
     (StageArgs::sponge_sigma), a varying one through B_e u computed by a launch of its own before the stage
     (launch_sponge_pre) - cells of all three kinds (none, constant, varying) side by side inside one 16-cell item, three
     whole steps (the in-place stage U1 reads u_abs = its own output buffer) against the generic kernels (every sponge cell
-    through its matrix, in the kernel) and against the oracle; then the same block split 2 x 1 x 1 with the stages run
-    in two regions each (the second region reads the pre-pass of the first)."""
+    through its matrix, in the kernel) and against the oracle.  (The same mix of cells on SPLIT stages - the SECOND region
+    reads the pre-pass the FIRST region launched, stages.cpp sponge_pre_key / sponge_pre_regions - is checked bitwise
+    against the single block by test_harness_gpu.py::_multiblock_case(extras=True) for every family, tetrahedra and
+    hexahedra, and over the native exchange by test_native_exchange_gpu.py's "source" cases.)"""
     from seigen_amd import _lib
     from seigen_amd.backend import HipBlock
     L = tuple(0.4 * k for k in n)

@@ -5,7 +5,9 @@
   ghost/split      FIRST + pack + SECOND from Python (no transport)
   native/split     csrc/comm.cpp, rank is its own z-/z+ neighbour over RCCL, FIRST + SECOND
   (native/ordered: the ordered schedule of tools/experiments/ordered_schedule.patch, when that patch is applied)
-(SEIGEN_COMM_DRY=1 in the environment: the native modes without the RCCL calls.)"""
+(the native modes without the RCCL calls: a library built with `SRC=comm tools/build_variant.sh dry -DSG_COMM_DRY -x hip`
+ and named in SEIGEN_HIP_LIB - wrong results by design, which is why it is a compile-time define of experiment builds and
+ no longer an environment switch of the shipped library.)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
