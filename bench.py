@@ -368,30 +368,41 @@ def halo_block(elastic, m, comm, backend):
             "grid_blocks": os.environ.get("SEIGEN_HIP_GRID_BLOCKS", "default (15/16 of the block slots while exchanging)")}
 
 
-def secondary_config(key, with_cpu=True, threads=None):
+C4_SHARE_CUBES = int(os.environ.get("SEIGEN_BENCH_C4_SHARE_CUBES", "128"))        # one rank's share of config 4's 256^3 cubes on 8 GPUs (tests: SEIGEN_BENCH_C4_SHARE_CUBES)
+_C4_KEEP = {}
+
+
+def secondary_config(key, with_cpu=True, threads=None, keep_c4=False):
     """One entry of the bench line's "configs" object: a BASELINE configuration other than the headline (or the
     reference's own benchmark protocol) through the solver class on this GPU - W untimed + K timed steps between
     synchronisations, per-kernel device times in a second pass - and, for c1 / c2 / c5, the oracle's C port on the host
     cores beside it (C1 in full, C2 20 steps, C5 50 steps)."""
     from seigen_amd.harness import baseline_configs as bc
-    if key == "ref_strong_2d_N256_P4_T2":
-        rec = bc.reference_strong_2d(256, 4, 2.0)
+    if key.startswith("ref_strong_2d_N256_P") and key.endswith("_T2"):
+        # P4: the strong-scaling protocol (README.md:7-13); P1..P3: its spatial-degree comparison on the same mesh (:22-31)
+        deg = int(key[len("ref_strong_2d_N256_P"):-len("_T2")])
+        rec = bc.reference_strong_2d(256, deg, 2.0)
         t = rec["timestepping_s"] or rec["run_wall_s"]
         value = rec["dofs"] * rec["steps"] / t / 1e6
         bpu = bytes_per_dof_update(2)
         frac = value * 1e6 * bpu / 1e9 / HBM_PEAK_GBS
-        rec.update({"workload": "the reference's strong-scaling protocol on one device (tests/eigenmode/README.md:7-13): 2D eigenmode "
-                                "N=256, P4, T=2.0, explicit; one warm-up run as pybench's warmups = 1, whole run(T) through the solver class",
+        rec.update({"workload": "the reference's %s on one device (tests/eigenmode/README.md:%s): 2D eigenmode "
+                                "N=256, P%d, T=2.0, explicit; one warm-up run as pybench's warmups = 1, whole run(T) through the solver class"
+                                % (("strong-scaling protocol", "7-13", deg) if deg == 4 else ("spatial-degree comparison", "22-31", deg)),
                     "value": value, "unit": "M DoF-updates/s", "ms_per_step": t / rec["steps"] * 1e3,
                     "roofline": {"bound": "hbm", "frac": frac, "frac_physical": frac * bytes_per_dof_update(2, sym=True) / bpu,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_dof_update": bpu,
                                  "note": "whole run: algorithmic bytes per DoF-update (bench.py stage_accounting) x value / peak; "
                                          "physical = with the stress stored symmetric"}})
         return rec
-    steps, warm = {"c1": (20000, 1000), "c2": (2000, 50), "c5": (5000, 100), "c4_share": (20, 3)}[key]
-    build = {"c1": bc.config1, "c2": bc.config2, "c5": bc.config5, "c4_share": bc.config4_share}[key]
+    steps, warm = {"c1": (20000, 1000), "c2": (2000, 50), "c5": (5000, 100), "c4_share": (20, 3), "c4_share_sponge": (20, 3)}[key]
     t0 = time.perf_counter()
-    el, label = build(2 * steps + warm)
+    if key.startswith("c4_share"):
+        # both entries on ONE block (85 GB, allocated once), from a smooth non-zero state: on the all-zero block rounds 1-5
+        # measured the package clocks 5-8 % higher
+        el, label = bc.config4_share(2 * steps + warm, n=C4_SHARE_CUBES, sponge=key.endswith("_sponge"), el=_C4_KEEP.pop("el", None))
+    else:
+        el, label = {"c1": bc.config1, "c2": bc.config2, "c5": bc.config5}[key](2 * steps + warm)
     blk = el.block
     setup_s = time.perf_counter() - t0
     el._advance(warm)
@@ -432,7 +443,10 @@ def secondary_config(key, with_cpu=True, threads=None):
                         "kernels": {kk: {"avg_us": v["avg_ms"] * 1e3, "launches": v["launches"], "algorithmic_GBps": v["gbs"],
                                          "physical_GBps": v["gbs_phys"]} for kk, v in kern.items()},
                         "stage_avg_us_event_timed": [stage_ms[i] / max(nst, 1) * 1e3 for i in range(6)]}}
-    blk.close()
+    if key == "c4_share" and keep_c4:
+        _C4_KEEP["el"] = el          # the sponge variant follows: same block
+    else:
+        blk.close()
     del el, blk
     if with_cpu and key in ("c1", "c2", "c5"):
         from oracle import baselines
@@ -464,7 +478,7 @@ def main():
     ap.add_argument("--configs", default=None,
                     help="one GPU, default headline: the other single-GPU configurations of BASELINE.json and the reference's "
                          "own benchmark protocol, measured after the headline and reported as \"configs\": a comma-separated list "
-                         "of c1, c2, c5, c4_share, ref_strong_2d_N256_P4_T2 (default: all of them with the default headline, "
+                         "of c1, c2, c5, c4_share, c4_share_sponge, ref_strong_2d_N256_P<1..4>_T2 (default: all of them with the default headline, "
                          "else none; \"none\": skip)")
     ap.add_argument("--config-timeout", type=float, default=75.0, help="deadline of each entry of --configs, seconds")
     ap.add_argument("--timeout", type=float, default=900.0,
@@ -675,7 +689,8 @@ def main():
     # (--configs given explicitly: whatever the headline's size is - tests use a small one)
     default_headline = n == 64 and P == 4 and args.dtype == "f64"
     if args.configs is None:
-        args.configs = "c1,c2,c5,c4_share,ref_strong_2d_N256_P4_T2" if default_headline else "none"
+        args.configs = ("c1,c2,c5,c4_share,c4_share_sponge,ref_strong_2d_N256_P4_T2,ref_strong_2d_N256_P1_T2,"
+                        "ref_strong_2d_N256_P2_T2,ref_strong_2d_N256_P3_T2") if default_headline else "none"
     want_configs = world == 1 and args.workload is None and args.configs != "none"
     if want_sweep or want_c4 or want_configs:
         faulthandler.cancel_dump_traceback_later()
@@ -687,10 +702,12 @@ def main():
     if want_configs:
         out["configs"] = {}
         threads = (out.get("cpu_baseline") or {}).get("cores")
-        for key in [c.strip() for c in args.configs.split(",") if c.strip()]:
+        keys = [c.strip() for c in args.configs.split(",") if c.strip()]
+        for key in keys:
             try:
                 with ExtraDeadline(key, args.config_timeout, "configs"):
-                    out["configs"][key] = secondary_config(key, with_cpu=not args.no_cpu_baseline, threads=threads)
+                    out["configs"][key] = secondary_config(key, with_cpu=not args.no_cpu_baseline, threads=threads,
+                                                           keep_c4="c4_share_sponge" in keys[keys.index(key) + 1:keys.index(key) + 2])
             except Exception as e:      # noqa: BLE001 - anything here must not cost the headline
                 out["configs"][key] = {"error": repr(e)}
 

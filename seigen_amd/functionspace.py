@@ -96,23 +96,60 @@ class FunctionSpace(object):
         return out
 
 
-    def node_coords_chunks(self, max_nodes=1 << 22):
-        """Yields (cell0, X[cells, nd, dim]) over slabs of the block's last axis, at most about
-        `max_nodes` nodes at a time (a 128^3-cube P4 block has 440 M nodes = 10.6 GB of coordinates)."""
+    def _chunk_specs(self, max_nodes):
+        """(first cell, config of the slab, cells in it) over slabs of the block's last axis"""
         mesh, part = self.mesh, self.mesh.partition
         d = self.dim
         ncls = mesh.cells_per_block
         per_layer = int(np.prod(part.n[:d - 1])) * ncls if d > 1 else ncls
         layers = max(1, int(max_nodes // max(1, per_layer * self.nd)))
-        lib = _lib.load()
         for k0 in range(0, part.n[d - 1], layers):
             nl = min(layers, part.n[d - 1] - k0)
             cfg = block_config(mesh, min(self.degree, 4))
             cfg.n[d - 1] = nl
             cfg.cube0[d - 1] = part.start[d - 1] + k0
-            X = np.empty((per_layer * nl, self.nd, d))
-            _lib.check(lib.sg_block_node_coords(C.byref(cfg), self.degree, X.ctypes.data, X.nbytes))
-            yield k0 * per_layer, X
+            yield k0 * per_layer, cfg, per_layer * nl
+
+    def _chunk_coords(self, cfg, ncells):
+        X = np.empty((ncells, self.nd, self.dim))
+        _lib.check(_lib.load().sg_block_node_coords(C.byref(cfg), self.degree, X.ctypes.data, X.nbytes))
+        return X
+
+    def node_coords_chunks(self, max_nodes=1 << 22):
+        """Yields (cell0, X[cells, nd, dim]) over slabs of the block's last axis, at most about
+        `max_nodes` nodes at a time (a 128^3-cube P4 block has 440 M nodes = 10.6 GB of coordinates)."""
+        for cell0, cfg, ncells in self._chunk_specs(max_nodes):
+            yield cell0, self._chunk_coords(cfg, ncells)
+
+    def map_chunks(self, fn, max_nodes=1 << 21):
+        """Yields (cell0, fn(X)) slab by slab IN ORDER, the slabs' coordinates and fn evaluated by a pool of host threads
+        (the coordinate builder and numpy's loops release the GIL): the set-up of a 128^3-cube block - 440 M nodes - is
+        host-bound otherwise (interpolating a sponge Expression: 53 s on one thread).  SEIGEN_HOST_THREADS bounds the
+        pool (default: the cores of the process, at most 16); at most pool + 2 slabs are alive at a time."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        nthreads = int(os.environ.get("SEIGEN_HOST_THREADS", "0")) or min(ncpu, 16)
+        specs = list(self._chunk_specs(max_nodes))
+        if nthreads <= 1 or len(specs) <= 1:
+            for cell0, cfg, ncells in specs:
+                yield cell0, fn(self._chunk_coords(cfg, ncells))
+            return
+
+        def work(spec):
+            return fn(self._chunk_coords(spec[1], spec[2]))
+
+        with ThreadPoolExecutor(max_workers=nthreads) as pool:
+            window, nxt = [], 0
+            while nxt < len(specs) or window:
+                while nxt < len(specs) and len(window) < nthreads + 2:
+                    window.append((specs[nxt][0], pool.submit(work, specs[nxt])))
+                    nxt += 1
+                cell0, fut = window.pop(0)
+                yield cell0, fut.result()
 
 
 class VectorFunctionSpace(FunctionSpace):
@@ -213,14 +250,17 @@ class Function(object):
             # neither the coordinates nor the evaluation temporaries of the whole block ever exist
             if self._binding is None and self._host is None:
                 self._host = np.empty(self._shape())
-            for cell0, X in space.node_coords_chunks():
+            def values(X):
                 v = expression.evaluate(X) if is_expr else np.asarray(expression(X), dtype=np.float64)
-                v = np.ascontiguousarray(v, dtype=np.float64).reshape((X.shape[0], space.nd) + space.value_shape)
+                return np.ascontiguousarray(v, dtype=np.float64).reshape((X.shape[0], space.nd) + space.value_shape)
+
+            # evaluated by a pool of host threads, handed over in order by this one (one host thread drives a handle)
+            for cell0, v in space.map_chunks(values):
                 if self._binding is not None:
                     block, field = self._binding
                     block.set_field_range(field, cell0, v)
                 else:
-                    self._host[cell0:cell0 + X.shape[0]] = v
+                    self._host[cell0:cell0 + v.shape[0]] = v
             return self
         if is_expr:
             vals = expression.evaluate(space.node_coords())

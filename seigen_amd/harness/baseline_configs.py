@@ -6,7 +6,10 @@ the reference's scripts set up theirs - shared by `bench.py` (the driver-timed `
   c1   tests/eigenmode 2-D, 40 x 40 squares, P1                         (tests/eigenmode/eigenmode_2d.py:7-36)
   c2   2-D explosive source, 512 x 512 squares, P2, DG4 sponge + source  (tests/explosive_source/explosive_source_lf4.py:7-56)
   c5   Marmousi 383 x 121 squares, P3, per-cell lambda / mu              (seigen/marmousi.py:4-24)
-  c4s  one rank's 128^3-cube share of config 4 (3-D explosive source 256^3 on 8 GPUs), P4, no neighbours
+  c4s  one rank's 128^3-cube share of config 4 (3-D explosive source 256^3 on 8 GPUs), P4, no neighbours; from a smooth
+       NON-ZERO state (on an all-zero block the package clocks 5-8 % higher: a flattering figure), and - `sponge=True` - with
+       the sponge of the reference's 2-D problem carried over to 3-D: sigma = 1000 in strips 8 cells wide on five faces,
+       none on the free surface (tests/explosive_source/explosive_source_lf4.py:42-45)
   ref  the reference's own benchmark protocol: 2-D eigenmode N = 256, P = 4, T = 2.0, explicit
        (tests/eigenmode/README.md:7-13, eigenmode_bench.py:19-41) - `reference_strong_2d`, a whole `run(T)`
 """
@@ -63,13 +66,45 @@ def config5(nsteps):
     return ready(el, nsteps), "c5: Marmousi %dx%d squares, P3, per-cell lambda/mu" % (NX - 1, NY - 1)
 
 
-def config4_share(nsteps, n=128, degree=4):
+def layer_periodic_state(el, s_scale=3600.0):
+    """A smooth non-zero state for large 3-D blocks at the cost of ONE layer of cubes: u_i = sin(k_i . x), s_ij = s_ji =
+    s_scale cos(k_(i+j)%3 . x + i - j) with whole wavelengths across the block in x and y and exactly one wavelength per cube
+    layer in z - the nodal values of every z layer are those of the first, which is evaluated once and uploaded n_z times
+    (a 128^3-cube P4 block has 440 M nodes: evaluating 12 fields there takes the host half a minute)."""
+    import numpy as np
+    from seigen_amd import _lib
+    mesh, blk = el.mesh, el.block
+    n, h = mesh.partition.n, mesh.h
+    per_layer = n[0] * n[1] * mesh.cells_per_block
+    _, X = next(iter(el.U.node_coords_chunks(per_layer * el.U.nd)))       # the first layer of cubes
+    assert X.shape[0] == per_layer
+    two_pi = 2.0 * np.pi
+    k = np.array([[3 * two_pi / (n[0] * h[0]), 2 * two_pi / (n[1] * h[1]), two_pi / h[2]],
+                  [2 * two_pi / (n[0] * h[0]), -5 * two_pi / (n[1] * h[1]), two_pi / h[2]],
+                  [-4 * two_pi / (n[0] * h[0]), 3 * two_pi / (n[1] * h[1]), -two_pi / h[2]]])
+    u = np.stack([np.sin(X @ k[i]) for i in range(3)], axis=-1)
+    s = np.zeros(X.shape[:-1] + (3, 3))
+    for i in range(3):
+        for j in range(i, 3):
+            s[..., i, j] = s[..., j, i] = s_scale * np.cos(X @ k[(i + j) % 3] + i - j)
+    for layer in range(n[2]):
+        blk.set_field_range(_lib.FIELD_U, layer * per_layer, u)
+        blk.set_field_range(_lib.FIELD_S, layer * per_layer, s)
+
+
+def config4_share(nsteps, n=128, degree=4, sponge=False, state="smooth", el=None):
+    """`el`: a solver this function returned before (same n, degree) - re-used with the other sponge setting instead of
+    allocating the block's 85 GB again (its fields are overwritten by the smooth state)."""
+    assert el is None or state == "smooth"
     h = 2.5
-    mesh = BoxMesh(n, n, n, n * h, n * h, n * h)
-    el = ElasticLF4.create(mesh, "DG", degree, dimension=3, solver="explicit", output=False)
-    el.density, el.mu, el.l = 1.0, 3600.0, 3599.3664            # explosive_source_lf4.py:21-23
-    el.dt = cfl_dt(h, Vp(el.mu, el.l, el.density), 0.05) / 2 ** (degree - 1)   # 2^(P-1) as in eigenmode_3d.py's dt rule
-    c = 0.5 * n * h
+    L = n * h
+    if el is None:
+        mesh = BoxMesh(n, n, n, L, L, L)
+        el = ElasticLF4.create(mesh, "DG", degree, dimension=3, solver="explicit", output=False)
+        el.density, el.mu, el.l = 1.0, 3600.0, 3599.3664            # explosive_source_lf4.py:21-23
+        el.dt = cfl_dt(h, Vp(el.mu, el.l, el.density), 0.05) / 2 ** (degree - 1)   # 2^(P-1) as in eigenmode_3d.py's dt rule
+    mesh = el.mesh
+    c = 0.5 * L
     box = " && ".join("x[%d] >= %r && x[%d] <= %r" % (a, c - 2 * h, a, c + 2 * h) for a in range(3))
     # the wavelet of explosive_source_lf4.py:37-38, centred inside the steps that are run
     code = "%s ? (-1.0 + 2*a*pow(t - t0, 2))*exp(-a*pow(t - t0, 2)) : 0.0" % box
@@ -77,9 +112,21 @@ def config4_share(nsteps, n=128, degree=4):
     el.source_expression = Expression(((code, z, z), (z, code, z), (z, z, code)), a=A_RICKER, t0=0.5 * nsteps * el.dt, t=0)
     el.source_expression.support_box = ((c - 2 * h,) * 3, (c + 2 * h,) * 3)
     el.source_function = Function(el.S)          # zero; the per-step table is what the kernels see
+    if sponge:
+        from seigen_amd import FunctionSpace
+        w = 8 * h       # explosive_source_lf4.py:45: strips 20 units = 8 cells of 2.5 wide; x[1] there is the depth axis, z here
+        el.absorption_function = Function(FunctionSpace(mesh, "DG", 4))
+        el.absorption = Expression("x[0] <= %r || x[0] >= %r || x[1] <= %r || x[1] >= %r || x[2] <= %r ? 1000 : 0"
+                                   % (w, L - w, w, L - w, w))
+    else:
+        el.absorption_function = None
     el.setup()
     el.upload_source([el.dt * (k + 1) for k in range(nsteps)])
-    return el, "c4s: one rank's share of config 4: %d^3 cubes x 6 tets, P%d, box-Ricker source" % (n, degree)
+    if state == "smooth":
+        layer_periodic_state(el)        # (state = "zero": the fields of a fresh block, as rounds 1-5 measured it)
+    return el, "c4s: one rank's share of config 4: %d^3 cubes x 6 tets, P%d, box-Ricker source, %s initial state%s" % (
+        n, degree, "smooth non-zero" if state == "smooth" else "zero",
+        ", sigma = 1000 in strips 8 cells wide on five faces (explosive_source_lf4.py:42-45)" if sponge else "")
 
 
 def config3_hex(nsteps, P, N=None):

@@ -207,3 +207,27 @@ def test_bench_line_carries_the_other_configs(gpu):
         # five kernels: F plain (UH1), F fused (U1), F fused without the self term (UTEMP), G plain (STEMP, SH1), G fused (S1)
         assert rf["dominant_kernel"].startswith("sg::tile2d_stage<") and len(rf["kernels"]) == 5
         assert "cpu_baseline" not in c
+
+
+def test_bench_line_config4_share_variants_and_degree_comparison(gpu):
+    """The entries VERDICT r05 item 3 asked for, at a test's size: config 4's share from a smooth NON-ZERO state, the same
+    block (re-used, not re-allocated) with the reference-style sponge strips on five faces, and one row of the reference's
+    spatial-degree comparison (2-D N = 256, README.md:22-31)."""
+    env = dict(os.environ, SEIGEN_BENCH_C4_SHARE_CUBES="32")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "8", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--configs", "c4_share,c4_share_sponge,ref_strong_2d_N256_P1_T2"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert sorted(out["configs"]) == ["c4_share", "c4_share_sponge", "ref_strong_2d_N256_P1_T2"]
+    plain, sponge, p1 = (out["configs"][k] for k in ("c4_share", "c4_share_sponge", "ref_strong_2d_N256_P1_T2"))
+    for c in (plain, sponge):
+        assert "error" not in c, c
+        assert c["cells"] == 6 * 32 ** 3 and c["value"] > 0 and "smooth non-zero" in c["workload"]
+        assert 0 < c["roofline"]["frac_physical"] < c["roofline"]["frac"] < 1
+        assert c["roofline"]["dominant_kernel"].startswith("sg::mfma_stage_")
+    assert "sigma = 1000" in sponge["workload"] and "sigma" not in plain["workload"]
+    assert sponge["ms_per_step"] > plain["ms_per_step"]          # the sponge costs something: it was really applied
+    assert "error" not in p1, p1
+    assert p1["degree"] == 1 and p1["steps"] == 1024 and p1["cells"] == 2 * 256 * 256 and "22-31" in p1["workload"]
+    assert p1["u_error"] < 1e-2 and 0 < p1["roofline"]["frac_physical"] < p1["roofline"]["frac"] < 1
