@@ -80,7 +80,25 @@ struct sg_handle {
   int32_t* sponge_cells = nullptr;  // [slot] -> cell: the pre-pass of the F stages (kernels.hpp launch_sponge_pre)
   int32_t* sponge_mat = nullptr;    // [slot] -> matrix in sponge_B (cells with the same nodal sigma share one)
   void* sponge_pre = nullptr;       // [slot][nd][dim] in the field type
+  // cells whose sigma is affine in the reference coordinates take dim + 1 numbers instead of a matrix (kernels.hpp
+  // launch_sponge_pre_affine); the cells that keep a matrix are then a LIST of slots
+  int sponge_pre_lines = 0;             // sponge_pre in line layout, slot = item * gw + w (3-D MFMA family), else a record per slot
+  int32_t sponge_nmat_slots = 0;        // slots with a matrix (all of them where no cell is affine: sponge_mat_slots stays null)
+  int32_t* sponge_mat_slots = nullptr;
+  int32_t sponge_aff_nitems = 0, sponge_aff_W = 0;
+  int32_t* sponge_aff_items = nullptr;  // [item] -> (cube group) * ncls + class
+  int32_t* sponge_aff_slots = nullptr;  // [item][gw] -> slot or -1
+  double* sponge_aff_coef = nullptr;    // [slot][dim + 1]
+  double* sponge_aff_X = nullptr;       // [dim][nd][W]
+  int32_t* sponge_aff_col = nullptr;    // [nd][W], null where the rows are dense
+  double* sponge_aff_frag = nullptr;    // 3-D MFMA family in double: the X_k as row tiles (mfma_frags_dense)
   int sponge_pre_key = -1, sponge_pre_regions = 0;   // the F stage (output field, mode) whose pre-pass ran last, and the regions launched since
+  // The pre-pass is B_e u_abs of a FIELD STATE: stages UH1 and U1 both absorb u0 (elastic.py:206-208 in form_uh1 and form_uh2),
+  // so the second of them finds the first one's result - two pre-passes per step instead of three.  fver counts the writes to
+  // each field (stage outputs, uploads); sponge_pre_ver / _field name the state the buffer holds (~0: none).
+  uint64_t fver[4] = {0, 0, 0, 0};
+  uint64_t sponge_pre_ver = ~0ull;
+  int sponge_pre_field = -1;
   // source
   int64_t src_nnz = 0;
   int64_t src_nfirst = 0;  // source nodes are stored with those in cells of SG_REGION_FIRST first

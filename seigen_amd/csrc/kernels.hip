@@ -592,10 +592,10 @@ __global__ void source_kernel(T* field, int ncomp, int gw, long nnz, const int64
 // stage's launches (the stage may update u_abs in place); the stage kernels then read nd x dim values per such cell instead
 // of its nd x nd matrix - and no wave runs a matrix loop for the sake of one lane.
 template <typename T>
-__global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t* cells, const int32_t* mats, T* sp, int nd, int dim,
-                                  int ncls, int gw) {
+__global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t* cells, const int32_t* mats, const int32_t* slots, T* sp,
+                                  int nd, int dim, int ncls, int gw, int lines) {
   extern __shared__ double s_u[];   // [nd][dim]
-  const int slot = blockIdx.x;
+  const int slot = slots ? slots[blockIdx.x] : (int)blockIdx.x;   // (slots: the cells with a matrix among cells with an affine sigma)
   const long e = cells[slot], c = e / ncls, k = e - c * ncls;
   const long base = (((c / gw) * ncls + k) * (long)nd) * dim * gw + c % gw;
   for (int j = threadIdx.x; j < nd * dim; j += blockDim.x) s_u[j] = (double)uabs[base + (long)j * gw];
@@ -605,21 +605,153 @@ __global__ void sponge_pre_kernel(const T* uabs, const double* B, const int32_t*
     const int a = j / dim, i = j - a * dim;
     double acc = 0.0;
     for (int b = 0; b < nd; ++b) acc += Bs[a * nd + b] * s_u[b * dim + i];
-    sp[(long)slot * nd * dim + j] = (T)acc;
+    // a record per slot, or (lines: slot = item * gw + w) the layout of the fields: [item][node][comp][gw cells]
+    if (lines)
+      sp[((long)(slot / gw) * nd * dim + j) * gw + slot % gw] = (T)acc;
+    else
+      sp[(long)slot * nd * dim + j] = (T)acc;
   }
 }
 
-int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, const int32_t* mats, void* sp, int32_t nslots, int nd,
-                      int dim, int ncls, int gw, int f32, void* stream) {
+int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, const int32_t* mats, const int32_t* slots, void* sp,
+                      int32_t nslots, int nd, int dim, int ncls, int gw, int lines, int f32, void* stream) {
   if (nslots <= 0) return 0;
   const int threads = nd * dim <= 64 ? 64 : 128;
   const size_t lds = (size_t)nd * dim * sizeof(double);
   if (f32)
     hipLaunchKernelGGL(sponge_pre_kernel<float>, dim3((unsigned)nslots), dim3(threads), lds, (hipStream_t)stream, (const float*)uabs, B,
-                       cells, mats, (float*)sp, nd, dim, ncls, gw);
+                       cells, mats, slots, (float*)sp, nd, dim, ncls, gw, lines);
   else
     hipLaunchKernelGGL(sponge_pre_kernel<double>, dim3((unsigned)nslots), dim3(threads), lds, (hipStream_t)stream, (const double*)uabs,
-                       B, cells, mats, (double*)sp, nd, dim, ncls, gw);
+                       B, cells, mats, slots, (double*)sp, nd, dim, ncls, gw, lines);
+  return (int)hipGetLastError();
+}
+
+// ---- cells whose sigma is AFFINE in the reference coordinates (smooth ramps: every cell of a linear profile) ----------------
+// sigma = s_0 + sum_k s_k xi_k makes the cell's sponge matrix B_e = M^-1 int sigma phi_a phi_b = s_0 I + sum_k s_k X_k with the
+// ELEMENT-CONSTANT matrices X_k = Mhat^-1 int xi_k phi_a phi_b: dim + 1 numbers per cell instead of an nd x nd matrix (9.8 KB
+// at 3-D P4 against 2.5 KB of field data - what made a ramp cost 1.4 ms per F stage on config 3's mesh).  One block works
+// on one ITEM at a time - the gw cells of one class whose values share their lines (mesh_tables.hpp) - so u_abs is read in
+// whole lines; the X_k sit in LDS for the life of the block (rows in ELL form: simplices dense, tensor-product cells the
+// 3 P + 1 entries of a row that are not zero).  Same output as sponge_pre_kernel: sp[slot][a][i], read by the F stage.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void sponge_pre_affine_kernel(const T* __restrict__ uabs, const double* __restrict__ X,
+                                                                const int32_t* __restrict__ col, int W, const int32_t* __restrict__ items,
+                                                                const int32_t* __restrict__ item_slots, const double* __restrict__ coef,
+                                                                T* __restrict__ sp, int nitems, int nd, int gw) {
+  extern __shared__ double s_all[];
+  double* sX = s_all;                                   // [DIM][nd][W]
+  double* sU = sX + DIM * nd * W;                       // [nd * DIM][gw]   (then the results as [gw][nd * DIM])
+  double* sC = sU + nd * DIM * gw;                      // [gw][DIM + 1]
+  int32_t* sCol = reinterpret_cast<int32_t*>(sC + gw * (DIM + 1));   // [nd][W] (null col: dense, b = j)
+  int32_t* sSlot = sCol + (col ? nd * W : 0);           // [gw]
+  for (int j = threadIdx.x; j < DIM * nd * W; j += 256) sX[j] = X[j];
+  if (col)
+    for (int j = threadIdx.x; j < nd * W; j += 256) sCol[j] = col[j];
+  const int rows = nd * DIM, ndW = nd * W;
+  for (int n = blockIdx.x; n < nitems; n += gridDim.x) {
+    __syncthreads();      // the previous item's results have left (first round: orders the table writes before their reads, with the next)
+    const T* src = uabs + (long)items[n] * rows * gw;   // item = (cube group) * ncls + class: its lines are contiguous
+    for (int j = threadIdx.x; j < rows * gw; j += 256) sU[j] = (double)src[j];
+    for (int j = threadIdx.x; j < gw; j += 256) {
+      const int sl = item_slots[(long)n * gw + j];
+      sSlot[j] = sl;
+#pragma unroll
+      for (int k = 0; k <= DIM; ++k) sC[j * (DIM + 1) + k] = sl >= 0 ? coef[(long)sl * (DIM + 1) + k] : 0.0;
+    }
+    __syncthreads();
+    // thread -> (cell w, node a); the results stay in registers until every thread has read its operands
+    constexpr int MAXR = 8;     // rounds of (w, a) pairs per thread: gw * nd <= MAXR * 256 (checked by the launcher)
+    double res[MAXR][DIM];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int idx = (int)threadIdx.x + r * 256;
+      double acc[DIM];
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) acc[i] = 0.0;
+      if (idx < gw * nd) {
+        const int w = idx % gw, a = idx / gw;
+        if (sSlot[w] >= 0) {
+          double c[DIM + 1];
+#pragma unroll
+          for (int k = 0; k <= DIM; ++k) c[k] = sC[w * (DIM + 1) + k];
+          const double* xr = sX + a * W;
+          const int32_t* cr = col ? sCol + a * W : nullptr;
+          const double* uw = sU + w;
+          for (int j = 0; j < W; ++j) {
+            const int b = cr ? cr[j] : j;
+            double m = c[1] * xr[j];
+            if (DIM > 1) m += c[2] * xr[ndW + j];
+            if (DIM > 2) m += c[3] * xr[2 * ndW + j];
+            const double* ub = uw + b * DIM * gw;
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) acc[i] += m * ub[i * gw];
+          }
+#pragma unroll
+          for (int i = 0; i < DIM; ++i) acc[i] += c[0] * uw[(a * DIM + i) * gw];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) res[r][i] = acc[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int idx = (int)threadIdx.x + r * 256;
+      if (idx < gw * nd) {
+        const int w = idx % gw, a = idx / gw;
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) sU[w * rows + a * DIM + i] = res[r][i];      // [w][a][i]: a cell's record is contiguous
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < rows * gw; j += 256) {
+      const int w = j / rows, rr = j - w * rows;
+      const int sl = sSlot[w];
+      if (sl >= 0) sp[(long)sl * rows + rr] = (T)sU[j];
+    }
+  }
+}
+
+size_t sponge_pre_affine_lds(int W, int has_col, int nd, int dim, int gw) {
+  return ((size_t)dim * nd * W + (size_t)nd * dim * gw + (size_t)gw * (dim + 1)) * sizeof(double) +
+         ((has_col ? (size_t)nd * W : 0) + (size_t)gw) * sizeof(int32_t);
+}
+
+int launch_sponge_pre_affine(const void* uabs, const double* X, const int32_t* col, int W, const int32_t* items, const int32_t* item_slots,
+                             const double* coef, void* sp, int32_t nitems, int nd, int dim, int gw, int f32, void* stream) {
+  if (nitems <= 0) return 0;
+  const int threads = 256;
+  if (gw * nd > 8 * threads) return (int)hipErrorInvalidValue;      // MAXR of the kernel
+  const size_t lds = sponge_pre_affine_lds(W, col != nullptr, nd, dim, gw);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+  }
+  const int per_cu = (int)(((size_t)160 << 10) / (lds + 512)) < 1 ? 1 : (int)(((size_t)160 << 10) / (lds + 512));
+  long grid = (long)ncu * (per_cu > 4 ? 4 : per_cu);
+  if (grid > nitems) grid = nitems;
+#define SG_AFF_LAUNCH(TT, DD)                                                                                                     \
+  do {                                                                                                                          \
+    auto kern = sponge_pre_affine_kernel<TT, DD>;                                                                               \
+    if (lds > ((size_t)64 << 10) &&                                                                                             \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
+      return (int)hipGetLastError();                                                                                            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, (hipStream_t)stream, (const TT*)uabs, X, col, W, items, \
+                       item_slots, coef, (TT*)sp, nitems, nd, gw);                                                              \
+  } while (0)
+  if (f32) {
+    if (dim == 1) SG_AFF_LAUNCH(float, 1);
+    else if (dim == 2) SG_AFF_LAUNCH(float, 2);
+    else SG_AFF_LAUNCH(float, 3);
+  } else {
+    if (dim == 1) SG_AFF_LAUNCH(double, 1);
+    else if (dim == 2) SG_AFF_LAUNCH(double, 2);
+    else SG_AFF_LAUNCH(double, 3);
+  }
+#undef SG_AFF_LAUNCH
   return (int)hipGetLastError();
 }
 

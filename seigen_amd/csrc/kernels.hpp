@@ -243,8 +243,19 @@ int launch_source(void* field, int ncomp, int gw, int64_t nnz, const int64_t* of
                   double scale, const SrcStep& ss, int f32, void* stream);
 // sp[slot][a][i] = sum_b B[slot][a][b] u_abs[cell of slot][b][i] for the cells with a sponge matrix of their own (one block per
 // cell), queued before the F stage's launches (StageArgs::sponge_pre)
-int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, const int32_t* mats, void* sp, int32_t nslots, int nd,
-                      int dim, int ncls, int gw, int f32, void* stream);
+// (slots: the list of slots to work on, or null = slots 0 .. nslots-1)
+// (lines: sp in the layout of the fields, slot = item * gw + w - the 3-D MFMA family)
+int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, const int32_t* mats, const int32_t* slots, void* sp,
+                      int32_t nslots, int nd, int dim, int ncls, int gw, int lines, int f32, void* stream);
+// the same sp[slot][a][i] for the cells whose sigma is affine in the reference coordinates: B_e = s_0 I + sum_k s_k X_k with the
+// element-constant X[k][a][j] (row a in ELL form: column col[a][j], or j itself where col is null), coef[slot][dim + 1] = s;
+// items[n] = (cube group) * ncls + class of the n-th item that holds such a cell, item_slots[n][gw] its cells' slots (-1: none)
+int launch_sponge_pre_affine(const void* uabs, const double* X, const int32_t* col, int W, const int32_t* items, const int32_t* item_slots,
+                             const double* coef, void* sp, int32_t nitems, int nd, int dim, int gw, int f32, void* stream);
+size_t sponge_pre_affine_lds(int W, int has_col, int nd, int dim, int gw);
+// ... on the matrix pipe for the 3-D MFMA family in double (kernels_mfma.hip): fragX = mfma_frags_dense of the three X_k
+int launch_sponge_affine_mfma(int P, const void* uabs, const double* fragX, const int32_t* items, const int32_t* item_slots,
+                              const double* coef, void* sp, int32_t nitems, void* stream);
 // the device-side step counter of SrcStep: *ctr = value (add = 0) or *ctr += value (add = 1), one thread
 int launch_step_counter(int64_t* ctr, int64_t value, int add, void* stream);
 

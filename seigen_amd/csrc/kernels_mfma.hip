@@ -1128,9 +1128,10 @@ __global__ __launch_bounds__(256, (mfma_resident_blocks<R, P>())) void mfma_stag
         if (sp_here) {
           constexpr int NR = 4 * MTF + NSM;     // row-quads of this lane: node 4 r + q
           const bool dense = slot >= 0;
-          const R* pb = dense ? reinterpret_cast<const R*>(A.sponge_pre) + ((long)slot * ND + q) * 3
+          // (the pre-pass results are lines like the fields': slot = their item * 16 + the cell's column)
+          const R* pb = dense ? reinterpret_cast<const R*>(A.sponge_pre) + ((long)(slot >> 4) * ND * 3 + q * 3) * 16 + (slot & 15)
                               : reinterpret_cast<const R*>(A.uabs) + ub_q;
-          const int es = dense ? 1 : 16;
+          constexpr int es = 16;
           const R sc = dense ? (R)1 : sig;
           R uo[NR][3];
 #pragma unroll
@@ -1267,6 +1268,106 @@ static int launch_ps(int kind, const StageArgs& a, hipStream_t s) {
 template <typename R, int P>
 static int launch_p(int kind, const StageArgs& a, hipStream_t s) {
   return a.sym ? launch_ps<R, P, 1>(kind, a, s) : launch_ps<R, P, 0>(kind, a, s);
+}
+
+// --------------------------------------------------------------------------------------------
+//  Sponge of the cells whose sigma is affine in the reference coordinates (kernels.hpp launch_sponge_pre_affine has the
+//  family-independent form): sp[slot][a][i] = s_0 u_i[a] + sum_k s_k (X_k u_i)[a] with the element-constant X_k as row
+//  tiles in LDS and the cells' own values as B operands straight from their lines - the first product of a G stage with
+//  other matrices; the per-cell coefficients s_k scale the accumulator COLUMNS (a lane's cell) as the results come out,
+//  and s_0 u needs no load: accumulator row 4 m + q of a lane is the node of its B operand at k-step m.
+// --------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(512) void sponge_affine_mfma(const double* __restrict__ uabs, const double* __restrict__ fragX,
+                                                          const int32_t* __restrict__ items, const int32_t* __restrict__ item_slots,
+                                                          const double* __restrict__ coef, double* __restrict__ sp, int nitems) {
+  using M = MG<P, double>;
+  typedef RT<double>::v4 d4;
+  constexpr int ND = M::ND, KS = M::KS, MTF = M::MTF, NSM = M::NSM, MTT = M::MTT, S4 = M::S4;
+  static_assert(KS == S4, "k-step m and row-quad m name the same nodes");
+  __shared__ double sX[3 * MTT * KS * 64];
+  copy_to_lds<3 * MTT * KS * 64, double, 512>(sX, fragX);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, w = lane & 15;
+  // A unit of work is ONE velocity component of one item: 9 B rows, 9 + 9 accumulator values - about 60 registers, so six
+  // waves per SIMD hide the unit's two dependent load latencies (slots -> coefficients, rows) behind each other's matrix
+  // work.  (A wave per whole item - 27 rows, 81 accumulators, two waves per SIMD - took 0.50 ms per launch for 48 000 items
+  // whose matrix work is 0.07 ms; the same wave with the next item's operands requested ahead spilled and took 0.9 ms.)
+  const long nunits = (long)nitems * 3;
+  for (long un = (long)blockIdx.x * 8 + wave; un < nunits; un += (long)gridDim.x * 8) {
+    const long n = un / 3;
+    const int i = (int)(un - n * 3);
+    const int sl = item_slots[n * 16 + w];
+    double sc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (sl >= 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] = coef[(long)sl * 4 + k];
+    }
+    const double* own = uabs + ((long)items[n] * ND * 3 + i) * 16 + w;
+    double ub[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ub[ks] = own[((4 * ks + q < ND) ? 4 * ks + q : 0) * 3 * 16];      // padded rows meet zero operator columns
+    int lo = lane;      // opaque: keeps the item-invariant tile reads inside the loop (they would not fit the registers)
+    asm volatile("" : "+v"(lo));
+    double r[S4];
+#pragma unroll
+    for (int m = 0; m < S4; ++m) r[m] = sc[0] * ub[m];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      d4 acc[M::MTFA];
+      double accs[M::NSMA];
+#pragma unroll
+      for (int t = 0; t < MTF; ++t) acc[t] = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) accs[t] = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < MTT; ++t) {
+          const double a = sX[((k * MTT + t) * KS + ks) * 64 + lo];
+          if (t < MTF)
+            acc[t < MTF ? t : 0] = RT<double>::big(a, ub[ks], acc[t < MTF ? t : 0]);
+          else
+            accs[t < MTF ? 0 : t - MTF] = RT<double>::small(a, ub[ks], accs[t < MTF ? 0 : t - MTF]);
+        }
+      const double sk = sc[1 + k];
+#pragma unroll
+      for (int t = 0; t < MTF; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) r[4 * t + reg] += sk * acc[t][reg];
+#pragma unroll
+      for (int t = 0; t < NSM; ++t) r[4 * MTF + t] += sk * accs[t];
+    }
+    // line layout (slot = item' * 16 + w): whole 128-byte lines; the columns of cells without an affine sigma belong to
+    // nobody or to the matrix pre-pass (another kernel, same stream): masked
+    if (sl >= 0) {
+      double* rec = sp + ((long)(sl >> 4) * ND * 3 + i) * 16 + w;
+#pragma unroll
+      for (int m = 0; m < S4; ++m) {
+        const int a = 4 * m + q;
+        if (a < ND) rec[a * 3 * 16] = r[m];
+      }
+    }
+  }
+}
+
+int launch_sponge_affine_mfma(int P, const void* uabs, const double* fragX, const int32_t* items, const int32_t* item_slots,
+                              const double* coef, void* sp, int32_t nitems, void* stream) {
+  if (nitems <= 0) return 0;
+  long blocks = ((long)nitems * 3 + 7) / 8;
+  if (blocks > 768) blocks = 768;      // three resident blocks of eight waves per CU (42 KB of tiles each at degree 4)
+  const dim3 grid((unsigned)blocks), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  switch (P) {
+    case 1: hipLaunchKernelGGL(sponge_affine_mfma<1>, grid, block, 0, s, (const double*)uabs, fragX, items, item_slots, coef, (double*)sp, nitems); break;
+    case 2: hipLaunchKernelGGL(sponge_affine_mfma<2>, grid, block, 0, s, (const double*)uabs, fragX, items, item_slots, coef, (double*)sp, nitems); break;
+    case 3: hipLaunchKernelGGL(sponge_affine_mfma<3>, grid, block, 0, s, (const double*)uabs, fragX, items, item_slots, coef, (double*)sp, nitems); break;
+    case 4: hipLaunchKernelGGL(sponge_affine_mfma<4>, grid, block, 0, s, (const double*)uabs, fragX, items, item_slots, coef, (double*)sp, nitems); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
 }
 
 int mfma_blocks_per_cu(int P, int f32) {

@@ -82,6 +82,22 @@ std::vector<double> mfma_frags_G(const RefElem& re) {
   return out;
 }
 
+// row tiles of dense element-constant nd x nd matrices M_0 .. M_{count-1} (row-major), in the order of mfma_frags_G
+std::vector<double> mfma_frags_dense(const RefElem& re, const double* M, int count) {
+  MfmaGeom g = mfma_geom(re);
+  std::vector<double> out((size_t)count * g.mtt * g.ks * 64, 0.0);
+  for (int r = 0; r < count; ++r)
+    for (int t = 0; t < g.mtt; ++t)
+      for (int k0 = 0; k0 < g.ks; ++k0) {
+        size_t frag = ((size_t)r * g.mtt + t) * g.ks + k0;
+        for (int l = 0; l < 64; ++l) {
+          const int a = tile_row(g, t, l), b = 4 * k0 + (l >> 4);
+          out[frag * 64 + l] = (a < re.nd && b < re.nd) ? M[((size_t)r * re.nd + a) * re.nd + b] : 0.0;
+        }
+      }
+  return out;
+}
+
 std::vector<double> mfma_frags_L(const RefElem& re) {
   MfmaGeom g = mfma_geom(re);
   std::vector<double> out((size_t)re.nfaces * g.mtt * g.ksf * 64, 0.0);

@@ -47,6 +47,9 @@ std::vector<double> mfma_frags_F(const RefElem& re);
 // G volume: the row tiles of E_0, E_1, E_2 one after the other:
 //   frag ((r*mtt + t)*ks + k0): A[row][col] = E_r[row0(t) + row][4 k0 + col]
 std::vector<double> mfma_frags_G(const RefElem& re);
+// `count` dense element-constant matrices M[r][nd][nd] as row tiles: frag ((r*mtt + t)*ks + k0): A[row][col] = M_r[row0(t) + row][4 k0 + col]
+// (the X_k of cells with an affine sponge, kernels_mfma.hip sponge_affine_mfma)
+std::vector<double> mfma_frags_dense(const RefElem& re, const double* M, int count);
 // facet lifts (shared by F and G): frag ((f*mtt + t)*ksf + k0): A[row][col] = 1/2 L_f[row0(t) + row][4 k0 + col]
 // (the 1/2 of the central flux average: both kernels lift +-1/2 of a neighbour trace)
 std::vector<double> mfma_frags_L(const RefElem& re);

@@ -74,14 +74,26 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
     h->sponge_pre_key = key;
     h->sponge_pre_regions |= 1 << region;
   }
+  if (first_of_stage && h->sponge_pre_field == uabs_f && h->sponge_pre_ver == h->fver[uabs_f]) first_of_stage = false;   // the buffer holds it
   if (first_of_stage) {
+    h->sponge_pre_field = uabs_f;
+    h->sponge_pre_ver = h->fver[uabs_f];
     // B_e u_abs of the cells with a sponge matrix, before anything of the stage writes
-    if (launch_sponge_pre(a.uabs, h->sponge_B, h->sponge_cells, h->sponge_mat, h->sponge_pre, h->sponge_nslots, h->re.nd, h->cfg.dim, h->ncls,
-                          (int)h->md.gw, h->f32, h->stream) != 0)
+    if (launch_sponge_pre(a.uabs, h->sponge_B, h->sponge_cells, h->sponge_mat, h->sponge_mat_slots, h->sponge_pre, h->sponge_nmat_slots,
+                          h->re.nd, h->cfg.dim, h->ncls, (int)h->md.gw, h->sponge_pre_lines, h->f32, h->stream) != 0)
       return fail(h, SG_ERR_DEVICE, "sponge pre-pass launch failed");
+    // ... and of the cells whose sigma is affine in the reference coordinates: dim + 1 numbers per cell, element-constant matrices
+    const int arc = h->sponge_aff_frag
+                        ? launch_sponge_affine_mfma(h->cfg.degree, a.uabs, h->sponge_aff_frag, h->sponge_aff_items, h->sponge_aff_slots,
+                                                    h->sponge_aff_coef, h->sponge_pre, h->sponge_aff_nitems, h->stream)
+                        : launch_sponge_pre_affine(a.uabs, h->sponge_aff_X, h->sponge_aff_col, h->sponge_aff_W, h->sponge_aff_items,
+                                                   h->sponge_aff_slots, h->sponge_aff_coef, h->sponge_pre, h->sponge_aff_nitems, h->re.nd,
+                                                   h->cfg.dim, (int)h->md.gw, h->f32, h->stream);
+    if (arc != 0) return fail(h, SG_ERR_DEVICE, "affine-sigma sponge pre-pass launch failed");
     // SECOND runs on its own stream after ev_stage - "everything before this stage's FIRST" - and reads the pre-pass too
     if (region == SG_REGION_FIRST && h->overlap && h->first_recorded_stage >= 0) HIPCHECK(h, hipEventRecord(h->ev_stage, h->stream));
   }
+  if (!h->name_out) h->fver[out_f] += 1;     // (after the pre-pass decision: an in-place stage absorbs the state it overwrites)
   a.lam = h->lam_d;
   a.mu = h->mu_d;
   a.lam0 = h->lam0;
@@ -376,7 +388,9 @@ static hipGraphExec_t capture_steps(sg_handle* h, int steps, bool with_src) {
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
   int rc = SG_OK;
   h->capture_src = with_src;
+  h->sponge_pre_ver = ~0ull;      // a replay starts from whatever the buffer holds: the captured step computes its own
   for (int k = 0; k < steps && rc == SG_OK; ++k) rc = enqueue_step(h);
+  h->sponge_pre_ver = ~0ull;      // nothing was launched: the buffer holds what it held
   h->capture_src = false;
   hipError_t e = hipStreamEndCapture(h->stream, &g);
   if (rc == SG_OK && e == hipSuccess && g) {
@@ -423,6 +437,10 @@ int sg_step(sg_handle* h, int64_t nsteps) {
     for (int st = 0; st < 6; ++st) h->counters.launches[st] += nsteps;
     h->counters.steps += nsteps;
     h->src_step += nsteps;
+    if (nsteps > 0) {
+      for (int f = 0; f < 4; ++f) h->fver[f] += 1;
+      h->sponge_pre_ver = ~0ull;
+    }
   }
   for (; k < nsteps; ++k) {
     for (int st = 0; st < 6; ++st) {

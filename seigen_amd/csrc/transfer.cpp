@@ -87,6 +87,7 @@ static int transfer(sg_handle* h, int field, int64_t cell0, int64_t ncells, doub
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   if (int rc = join_second(h)) return rc;
   HIPCHECK(h, sync_all(h));
+  if (to_device) h->fver[field] += 1;      // what was derived from the field's old state (the sponge pre-pass) is stale
   const size_t per_cell = h->field_len[field] / (size_t)h->ncells;
   // downloads only: uploads from pageable memory already run at 47 GB/s inside the runtime (measured,
   // tools/transfer_rate.py: 35 GB/s through this pipeline)

@@ -329,10 +329,16 @@ def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n, diagon
     r = np.random.default_rng(21)
     m = oracle_mesh(3, n, L, diagonal)
     nq = m.node_coords(4).shape[1]
-    kind = r.integers(0, 3, size=m.ncells)
+    kind = r.integers(0, 4, size=m.ncells)
     sigma = np.zeros((m.ncells, nq))
     sigma[kind == 1] = r.uniform(2.0, 30.0, size=((kind == 1).sum(), 1))
     sigma[kind == 2] = r.uniform(0.0, 30.0, size=((kind == 2).sum(), nq))
+    # kind 3 (round 6): a sigma that is AFFINE in x, varying in all three coordinates, a different one per cell - such cells
+    # take four coefficients and the element-constant matrices X_k instead of a matrix of their own (sponge_pre_affine_kernel)
+    Xq = m.node_coords(4)
+    n3 = int((kind == 3).sum())
+    grad = r.uniform(-20.0, 20.0, size=(n3, 1, 3))
+    sigma[kind == 3] = r.uniform(5.0, 30.0, size=(n3, 1)) + (grad * (Xq[kind == 3] - Xq[kind == 3][:, :1])).sum(axis=-1)
     dt = 0.04 * min(h) / degree ** 2
     res = {}
     for path in ("generic", ""):
@@ -367,6 +373,55 @@ def test_3d_sponge_constant_and_matrix_cells(gpu, monkeypatch, degree, n, diagon
     assert rel_err(res[""][1], res["generic"][1]) < tol
     assert rel_err(res[""][0], orc.u1) < tol
     assert rel_err(res[""][1], orc.s1) < tol
+
+
+@pytest.mark.parametrize("degree,n,diagonal,path", [
+    (4, (17, 3, 2), "left", ""), (3, (6, 3, 4), "left", ""), (2, (5, 3, 4), "left", "lane"), (1, (9, 2, 3), "left", "lane"),
+    (3, (5, 3, 2), "quadrilateral", ""), (4, (3, 2, 2), "quadrilateral", ""), (2, (5, 3, 2), "quadrilateral", "lane"),
+])
+@pytest.mark.parametrize("sigma_degree", [4, 1])
+def test_3d_affine_sigma_ramp(gpu, monkeypatch, degree, n, diagonal, path, sigma_degree):
+    """A sponge that is a linear ramp in all three coordinates (sigma in DG4 as the reference's scripts declare it,
+    elastic.py:136-141, and in DG1): every cell's sigma is affine in its reference coordinates, so the 3-D families apply
+    B_e = s_0 I + sum_k s_k X_k from four coefficients per cell (kernels.hip sponge_pre_affine_kernel) instead of reading an
+    nd x nd matrix per cell.  Three whole steps against the SAME library with the affine path switched off (every cell through
+    its matrix, SEIGEN_HIP_SPONGE_AFFINE=0) and against the oracle's absorption_matrix form."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    L = tuple(0.4 * k for k in n)
+    h = [L[a] / n[a] for a in range(3)]
+    m = oracle_mesh(3, n, L, diagonal)
+    Xq = m.node_coords(sigma_degree)
+    sigma = 4.0 + 11.0 * Xq[..., 0] + 7.0 * Xq[..., 1] + 23.0 * Xq[..., 2]
+    dt = 0.04 * min(h) / degree ** 2
+    if path:
+        monkeypatch.setenv("SEIGEN_HIP_PATH", path)
+    res = {}
+    for affine in ("1", "0"):
+        monkeypatch.setenv("SEIGEN_HIP_SPONGE_AFFINE", affine)
+        blk = HipBlock(3, degree, n, h, [0.0] * 3, diagonal)
+        u0 = seeded(blk.field_shape(_lib.FIELD_U), 71)
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 72)
+        s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        blk.set_params(1.0, dt, 0.6, 0.3)
+        blk.set_absorption(sigma, sigma_degree)
+        blk.set_field(_lib.FIELD_U, u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.step(3)
+        res[affine] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    orc = OracleLF4(m, degree)
+    orc.dt, orc.l, orc.mu, orc.density = dt, 0.6, 0.3, 1.0
+    orc.E.set_absorption(sigma, sigma_degree)
+    orc.u0, orc.s0 = u0.copy(), s0.copy()
+    for k in range(3):
+        orc.step((k + 1) * dt)
+    tol = 10 * tol_of(degree, diagonal) * (2 if diagonal == "quadrilateral" else 1)
+    assert np.abs(res["1"][0] - u0).max() > 1e-6
+    for a, b in ((res["1"][0], res["0"][0]), (res["1"][1], res["0"][1]), (res["1"][0], orc.u1), (res["1"][1], orc.s1)):
+        assert rel_err(a, b) < tol
+    # the sponge really acted, and differently from a cell-constant one of the same mean
+    assert rel_err(res["1"][0], u0) > 1e-4
 
 
 def test_error_behaviour(gpu):
