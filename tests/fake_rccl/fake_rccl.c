@@ -24,6 +24,13 @@
  * FAKE_RCCL_LOG=<prefix>: ncclCommDestroy writes "<prefix>.rank<r>" with the counts of what this rank moved.
  *
  * Several ranks may live in one process (one communicator per thread): group state is thread-local.
+ *
+ * FAKE_RCCL_ASYNC=1 (GPU mode, ONE rank per process): the transfers are enqueued on `stream` like RCCL's and the call
+ * returns at once - device-to-host copy + a host function that publishes the message; a host function that waits for
+ * the peer's message + host-to-device copy + a host function that frees the slot - so the library's own stream
+ * dependencies (the SECOND launch on its second stream beside the exchange, the next stage behind the receives) are
+ * exercised as under RCCL instead of being serialised by a blocking call.  The segment is pinned for that
+ * (FAKE_RCCL_SLOT_BYTES <= 1 MiB there).  A rank per THREAD would deadlock on the runtime's one callback thread.
  */
 #define _GNU_SOURCE
 #include <rccl/rccl.h> /* types and the prototypes the definitions below must match */
@@ -63,6 +70,8 @@ typedef struct {
 
 struct ncclComm {         /* rccl.h leaves the struct incomplete: this is the double's */
   int rank, nranks;
+  int async, pinned;
+  uint64_t send_enq[FK_MAXRANKS], recv_enq[FK_MAXRANKS];   /* async mode: messages ENQUEUED per peer (the slots they will use) */
   size_t slot_bytes, chan_stride, map_bytes;
   unsigned char* base;
   int corrupt_recv;
@@ -86,8 +95,16 @@ static __thread int tl_nops = 0, tl_cap = 0;
 /* ---- the HIP runtime, bound at run time (the host mode needs none) ---------------------------------------- */
 typedef int (*fk_memcpy_fn)(void*, const void*, size_t, int);
 typedef int (*fk_streamsync_fn)(void*);
+typedef int (*fk_memcpy_async_fn)(void*, const void*, size_t, int, void*);
+typedef int (*fk_hostfunc_fn)(void*, void (*)(void*), void*);
+typedef int (*fk_hostreg_fn)(void*, size_t, unsigned);
+typedef int (*fk_hostunreg_fn)(void*);
 static fk_memcpy_fn fk_hipMemcpy = NULL;
 static fk_streamsync_fn fk_hipStreamSynchronize = NULL;
+static fk_memcpy_async_fn fk_hipMemcpyAsync = NULL;
+static fk_hostfunc_fn fk_hipLaunchHostFunc = NULL;
+static fk_hostreg_fn fk_hipHostRegister = NULL;
+static fk_hostunreg_fn fk_hipHostUnregister = NULL;
 static int fk_host_mode = -1;
 
 static int fk_bind_hip(void) {
@@ -105,6 +122,10 @@ static int fk_bind_hip(void) {
   }
   fk_hipMemcpy = (fk_memcpy_fn)dlsym(lib, "hipMemcpy");
   fk_hipStreamSynchronize = (fk_streamsync_fn)dlsym(lib, "hipStreamSynchronize");
+  fk_hipMemcpyAsync = (fk_memcpy_async_fn)dlsym(lib, "hipMemcpyAsync");
+  fk_hipLaunchHostFunc = (fk_hostfunc_fn)dlsym(lib, "hipLaunchHostFunc");
+  fk_hipHostRegister = (fk_hostreg_fn)dlsym(lib, "hipHostRegister");
+  fk_hipHostUnregister = (fk_hostunreg_fn)dlsym(lib, "hipHostUnregister");
   return (fk_hipMemcpy && fk_hipStreamSynchronize) ? 0 : -1;
 }
 
@@ -235,12 +256,25 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   if (res == ncclSuccess && atomic_load(&h->poisoned)) res = ncclSystemError;
   /* the name is not needed any more once everybody has mapped the segment (or nobody will): the mappings keep it alive */
   if (rank == 0 || res != ncclSuccess) shm_unlink(c->name);
+  const char* as = getenv("FAKE_RCCL_ASYNC");
+  if (res == ncclSuccess && as && *as && strcmp(as, "0") != 0 && !fk_host_mode) {
+    if (!fk_hipMemcpyAsync || !fk_hipLaunchHostFunc || !fk_hipHostRegister || !fk_hipHostUnregister || c->slot_bytes > ((size_t)1 << 20)) {
+      fprintf(stderr, "fake_rccl: FAKE_RCCL_ASYNC needs hipLaunchHostFunc / hipHostRegister and FAKE_RCCL_SLOT_BYTES <= 1 MiB\n");
+      res = ncclInvalidUsage;
+    } else if (fk_hipHostRegister(c->base, c->map_bytes, 0) != 0) {
+      fprintf(stderr, "fake_rccl: hipHostRegister of the segment failed\n");
+      res = ncclSystemError;
+    } else {
+      c->async = c->pinned = 1;
+    }
+  }
   const char* fi = getenv("FAKE_RCCL_FAIL_INIT");
   if (res == ncclSuccess && fi && *fi && atoi(fi) == rank) {
     fprintf(stderr, "fake_rccl[rank %d]: injected ncclCommInitRank failure\n", rank);
     res = ncclSystemError;     /* the other ranks have returned success: a failure of one rank alone */
   }
   if (res != ncclSuccess) {
+    if (c->pinned) fk_hipHostUnregister(c->base);
     munmap(c->base, c->map_bytes);
     free(c);
     return res;
@@ -258,13 +292,14 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
     FILE* f = fopen(path, "a");
     if (f) {
       fprintf(f, "{\"rank\": %d, \"nranks\": %d, \"sends\": %llu, \"recvs\": %llu, \"bytes_sent\": %llu, \"bytes_recv\": %llu, "
-                 "\"groups\": %llu, \"host_mode\": %d}\n",
+                 "\"groups\": %llu, \"host_mode\": %d, \"async\": %d}\n",
               c->rank, c->nranks, (unsigned long long)c->sends, (unsigned long long)c->recvs,
-              (unsigned long long)c->bytes_sent, (unsigned long long)c->bytes_recv, (unsigned long long)c->groups, fk_host_mode);
+              (unsigned long long)c->bytes_sent, (unsigned long long)c->bytes_recv, (unsigned long long)c->groups, fk_host_mode, c->async);
       fclose(f);
     }
   }
   atomic_fetch_add(&fk_hdr(c)->left, 1);
+  if (c->pinned) fk_hipHostUnregister(c->base);
   munmap(c->base, c->map_bytes);
   free(c);
   return ncclSuccess;
@@ -326,8 +361,111 @@ static ncclResult_t fk_do_recv(fk_op* op) {
   return ncclSuccess;
 }
 
+/* ---- async mode: the transfers as stream-ordered work ---------------------------------------------------------------- */
+typedef struct {
+  ncclComm_t comm;
+  fk_chan* ch;
+  uint64_t seq;
+  size_t bytes;
+  int peer;
+} fk_cb;
+
+static void fk_cb_publish(void* p) {   /* runs behind the device-to-host copy of the message */
+  fk_cb* a = (fk_cb*)p;
+  a->ch->bytes[a->seq % FK_NSLOT] = a->bytes;
+  atomic_store_explicit(&a->ch->head, a->seq + 1, memory_order_release);
+  free(a);
+}
+
+static void fk_cb_wait(void* p) {      /* holds the stream until the peer's message is there */
+  fk_cb* a = (fk_cb*)p;
+  ncclComm_t c = a->comm;
+  const double t0 = fk_now(), limit = fk_timeout();
+  int spins = 0;
+  while (atomic_load_explicit(&a->ch->head, memory_order_acquire) <= a->seq) {
+    if (atomic_load(&fk_hdr(c)->poisoned)) break;
+    if (fk_now() - t0 > limit) {
+      fk_poison(c, "ncclRecv (async): nothing arrived from the source", ncclSystemError);
+      break;
+    }
+    fk_pause(++spins);
+  }
+  if (!atomic_load(&fk_hdr(c)->poisoned) && a->ch->bytes[a->seq % FK_NSLOT] != a->bytes)
+    fk_poison(c, "ncclRecv (async): byte count differs from the matching send", ncclInvalidArgument);
+  if (c->corrupt_recv && a->bytes) {
+    unsigned char* slot = fk_slot(c, a->ch, a->seq);
+    slot[0] = (unsigned char)~slot[0];
+  }
+  free(a);
+}
+
+static void fk_cb_consume(void* p) {   /* runs behind the host-to-device copy: the slot is free again */
+  fk_cb* a = (fk_cb*)p;
+  atomic_store_explicit(&a->ch->tail, a->seq + 1, memory_order_release);
+  free(a);
+}
+
+static fk_cb* fk_cb_new(ncclComm_t c, fk_chan* ch, uint64_t seq, size_t bytes, int peer) {
+  fk_cb* a = (fk_cb*)malloc(sizeof(fk_cb));
+  if (a) {
+    a->comm = c;
+    a->ch = ch;
+    a->seq = seq;
+    a->bytes = bytes;
+    a->peer = peer;
+  }
+  return a;
+}
+
+static ncclResult_t fk_enqueue_send(fk_op* op) {
+  ncclComm_t c = op->comm;
+  fk_chan* ch = fk_channel(c, c->rank, op->peer);
+  const uint64_t seq = c->send_enq[op->peer]++;
+  const double t0 = fk_now(), limit = fk_timeout();
+  int spins = 0;
+  while (seq - atomic_load_explicit(&ch->tail, memory_order_acquire) >= FK_NSLOT) {   /* back-pressure: the host may run far ahead */
+    if (atomic_load(&fk_hdr(c)->poisoned)) return ncclSystemError;
+    if (fk_now() - t0 > limit) return fk_poison(c, "ncclSend (async): the destination does not receive", ncclSystemError);
+    fk_pause(++spins);
+  }
+  fk_cb* a = fk_cb_new(c, ch, seq, op->bytes, op->peer);
+  if (!a) return ncclSystemError;
+  if ((op->bytes && fk_hipMemcpyAsync(fk_slot(c, ch, seq), op->buf, op->bytes, 2, (void*)op->stream) != 0) ||
+      fk_hipLaunchHostFunc((void*)op->stream, fk_cb_publish, a) != 0)
+    return fk_poison(c, "ncclSend (async): enqueue failed", ncclUnhandledCudaError);
+  c->sends += 1;
+  c->bytes_sent += op->bytes;
+  return ncclSuccess;
+}
+
+static ncclResult_t fk_enqueue_recv(fk_op* op) {
+  ncclComm_t c = op->comm;
+  fk_chan* ch = fk_channel(c, op->peer, c->rank);
+  const uint64_t seq = c->recv_enq[op->peer]++;
+  fk_cb* a = fk_cb_new(c, ch, seq, op->bytes, op->peer);
+  fk_cb* b = fk_cb_new(c, ch, seq, op->bytes, op->peer);
+  if (!a || !b) return ncclSystemError;
+  if (fk_hipLaunchHostFunc((void*)op->stream, fk_cb_wait, a) != 0 ||
+      (op->bytes && fk_hipMemcpyAsync(op->buf, fk_slot(c, ch, seq), op->bytes, 1, (void*)op->stream) != 0) ||
+      fk_hipLaunchHostFunc((void*)op->stream, fk_cb_consume, b) != 0)
+    return fk_poison(c, "ncclRecv (async): enqueue failed", ncclUnhandledCudaError);
+  c->recvs += 1;
+  c->bytes_recv += op->bytes;
+  return ncclSuccess;
+}
+
 static ncclResult_t fk_flush(void) {
   ncclResult_t res = ncclSuccess;
+  if (tl_nops > 0 && tl_ops[0].comm && tl_ops[0].comm->async) {
+    /* every send of the group before any receive, all of it stream-ordered: nothing here waits for the device */
+    for (int i = 0; i < tl_nops && res == ncclSuccess; ++i)
+      if (tl_ops[i].is_send) res = fk_enqueue_send(&tl_ops[i]);
+    for (int i = 0; i < tl_nops && res == ncclSuccess; ++i)
+      if (!tl_ops[i].is_send) res = fk_enqueue_recv(&tl_ops[i]);
+    tl_ops[0].comm->groups += 1;
+    tl_nops = 0;
+    return res;
+  }
   /* stream order, part 1: everything queued before the group has finished before a byte is read or overwritten */
   if (!fk_host_mode)
     for (int i = 0; i < tl_nops && res == ncclSuccess; ++i) {

@@ -9,7 +9,10 @@ library's nine RCCL entry points to tests/fake_rccl (shared memory + host stagin
 checked on its own in tests/test_fake_rccl.py).  What runs for the first time between DIFFERENT ranks: ncclCommInitRank
 across processes, peers on all three axes, the facing-side order of the receives, the statistics - and the result must
 equal the single-block run BITWISE (the reference's exchange: seigen/elastic.py:404-436, ParLoopHaloEnd in
-tests/tiling/utils.py:143-144).  The second half runs the host-side agreement of seigen_amd/parallel.py::NativeExchanger
+tests/tiling/utils.py:143-144).  The double has two modes: blocking (every call completes its transfers before it
+returns: any number of ranks per process) and ASYNC (the transfers are work on the library's stream - copies and host
+functions - and the calls return at once, as RCCL's do: the two-stream schedule of a split stage then runs concurrently
+with the exchange instead of being serialised by the transport).  The second half runs the host-side agreement of seigen_amd/parallel.py::NativeExchanger
 through the solver class (gloo process group, SEIGEN_HALO_NATIVE=force): a failure injected into ONE rank - argument
 check, communicator, self-test - must put EVERY rank on the host-driven exchanger, within a timeout, with the same
 bitwise result."""
@@ -41,13 +44,13 @@ def _env(fake, tmp_path, **extra):
     return env
 
 
-def _spawn_workers(fake, tmp_path, world, layout, grid, n, degree, steps, dtype, scenario):
+def _spawn_workers(fake, tmp_path, world, layout, grid, n, degree, steps, dtype, scenario, **extra_env):
     procs, first = [], 0
     for k in layout:
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "native_exchange_worker.py"), str(tmp_path), str(world), str(first),
              str(k), ",".join(map(str, grid)), ",".join(map(str, n)), str(degree), str(steps), dtype, scenario],
-            cwd=ROOT, env=_env(fake, tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+            cwd=ROOT, env=_env(fake, tmp_path, **extra_env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         first += k
     assert first == world
     errs = []
@@ -86,18 +89,25 @@ def _block_cells(n, start, bn):
     return np.array(idx)
 
 
-@pytest.mark.parametrize("world,layout,grid,n,degree,dtype,scenario", [
-    (2, [1, 1], (1, 1, 2), (16, 4, 4), 4, "f64", "plain"),         # slab, the headline element
-    (2, [1, 1], (2, 1, 1), (32, 2, 2), 4, "f64", "source"),        # x split: shells of whole layout groups
-    (4, [1, 1, 1, 1], (2, 2, 1), (32, 4, 2), 4, "f64", "source"),  # 2 x 2 x 1, P4, source + sponge across the blocks
-    (4, [1, 1, 1, 1], (1, 2, 2), (16, 4, 4), 2, "f64", "source"),  # P2
-    (4, [2, 2], (1, 1, 4), (16, 2, 8), 3, "f32", "plain"),         # inner blocks with two neighbours on one axis, FP32
-    (8, [2, 2, 2, 2], (2, 2, 2), (32, 4, 4), 4, "f64", "source"),  # config 4's grid: 2 x 2 x 2, peers on three axes
-    (8, [2, 2, 2, 2], (2, 2, 2), (8, 4, 4), 2, "f64", "source"),   # P2, generic-kernel sized blocks
+@pytest.mark.parametrize("world,layout,grid,n,degree,dtype,scenario,mode", [
+    (2, [1, 1], (1, 1, 2), (16, 4, 4), 4, "f64", "plain", "blocking"),         # slab, the headline element
+    (2, [1, 1], (2, 1, 1), (32, 2, 2), 4, "f64", "source", "blocking"),        # x split: shells of whole layout groups
+    (4, [1, 1, 1, 1], (2, 2, 1), (32, 4, 2), 4, "f64", "source", "blocking"),  # 2 x 2 x 1, P4, source + sponge across the blocks
+    (4, [1, 1, 1, 1], (1, 2, 2), (16, 4, 4), 2, "f64", "source", "blocking"),  # P2
+    (4, [2, 2], (1, 1, 4), (16, 2, 8), 3, "f32", "plain", "blocking"),         # inner blocks with two neighbours on one axis, FP32
+    (8, [2, 2, 2, 2], (2, 2, 2), (32, 4, 4), 4, "f64", "source", "blocking"),  # config 4's grid: 2 x 2 x 2, peers on three axes
+    (8, [2, 2, 2, 2], (2, 2, 2), (8, 4, 4), 2, "f64", "source", "blocking"),   # P2, generic-kernel sized blocks
+    # the double's ASYNC mode (one rank per process): the transfers are stream-ordered work and the calls return at once, as
+    # RCCL's do - the SECOND launches on the second stream and the next stage's FIRST really run beside / behind them
+    (2, [1, 1], (1, 1, 2), (16, 4, 4), 4, "f64", "source", "async"),
+    (4, [1, 1, 1, 1], (2, 2, 1), (32, 4, 2), 4, "f64", "source", "async"),
+    (4, [1, 1, 1, 1], (1, 2, 2), (32, 8, 8), 3, "f64", "plain", "async"),       # larger blocks: launches long enough to overlap
+    (4, [1, 1, 1, 1], (1, 1, 4), (16, 2, 8), 2, "f32", "source", "async"),
 ])
-def test_native_exchange_between_ranks_bitwise(gpu, fake, tmp_path, world, layout, grid, n, degree, dtype, scenario):
+def test_native_exchange_between_ranks_bitwise(gpu, fake, tmp_path, world, layout, grid, n, degree, dtype, scenario, mode):
     steps = 3
-    _spawn_workers(fake, tmp_path, world, layout, grid, n, degree, steps, dtype, scenario)
+    extra = {"FAKE_RCCL_ASYNC": "1", "FAKE_RCCL_SLOT_BYTES": "1048576"} if mode == "async" else {}
+    _spawn_workers(fake, tmp_path, world, layout, grid, n, degree, steps, dtype, scenario, **extra)
     single = _single_block(n, degree, steps, dtype, scenario)
     assert np.isfinite(single["u"]).all() and np.abs(single["u"]).max() > 0
     for rank in range(world):
@@ -110,6 +120,7 @@ def test_native_exchange_between_ranks_bitwise(gpu, fake, tmp_path, world, layou
         log = json.loads(open(str(tmp_path / "fake") + ".rank%d" % rank).read().splitlines()[-1])
         nex = int(d["exchanges"]) + 2
         assert log["host_mode"] == 0 and log["sends"] == log["recvs"] == nex * int(d["nsides"]) and log["groups"] == nex
+        assert log["async"] == (1 if mode == "async" else 0)
         assert log["bytes_sent"] >= int(d["bytes_sent"]) > 0
 
 

@@ -8,10 +8,11 @@ TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --configs none"
+# BENCH_EXTRA: more bench.py arguments (e.g. "--degree 1": the same passes for another degree on config 3's mesh)
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --configs none ${BENCH_EXTRA:-}"
 # pass 1: kernel durations over a long timed region (100 steps; the 3 warm-up steps are 3 % of the launches), with the
 # bench's own line - hipEvent averages of the same launches - kept next to it for the cross-check
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 100 --warmup 3 --no-cpu-baseline --configs none > $OUT/trace_bench.json 2> $OUT/trace.log
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 100 --warmup 3 --no-cpu-baseline --configs none ${BENCH_EXTRA:-} > $OUT/trace_bench.json 2> $OUT/trace.log
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o run -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o run -- $BENCH > $OUT/write.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
