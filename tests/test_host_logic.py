@@ -629,4 +629,4 @@ def test_experiment_patches_are_indexed_and_apply():
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "experiments", "check_patches.sh")], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ok ") >= 10
+    assert r.stdout.count("ok ") >= 11
