@@ -180,3 +180,40 @@ def test_ranks_agree_on_the_exchanger(gpu, fake, tmp_path, fault, native):
         assert np.array_equal(d["u"], us[idx]) and np.array_equal(d["s"], ss[idx]), "rank %d differs from the single block" % rank
         if native:
             assert os.path.basename(str(d["library"])) == "libfake_rccl.so"
+
+
+@pytest.mark.parametrize("args,cells,scaling", [
+    (["--gpus", "4", "--steps", "3", "--warmup", "1", "--cubes", "16"], 4 * 6 * 16 ** 3, "weak"),
+    (["--gpus", "4", "--workload", "c4", "--c4-cubes", "32", "--steps", "3", "--warmup", "1"], 6 * 32 ** 3, "strong"),
+])
+def test_bench_reports_the_native_exchange(gpu, fake, tmp_path, args, cells, scaling):
+    """bench.py as the driver launches it for N > 1, with the exchange INSIDE the library (the default of every RCCL run)
+    carried by the transport double in its async mode: the line's halo block - driver, transport, which RCCL, payload per
+    step against the closed form, waits, the grid sweep of the weak-scaling workload - has only ever been filled by the
+    host-driven exchanger before (tests/test_dist_gpu.py); the first 8-GPU job goes through exactly this code."""
+    extra = {"SEIGEN_DIST_BACKEND": "gloo", "SEIGEN_HIP_DEVICE": "0", "SEIGEN_HALO_NATIVE": "force", "FAKE_RCCL_ASYNC": "1",
+             "FAKE_RCCL_SLOT_BYTES": "1048576", "FAKE_RCCL_TIMEOUT_S": "60"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(fake, tmp_path, **extra), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["scaling"] == scaling and out["value"] > 0 and out["config"]["cells"] == cells
+    h = out["halo"]
+    assert h["driver"] == "native" and h["transport"] == "nccl"
+    assert os.path.basename(h["rccl_library"]) == "libfake_rccl.so" and h["rccl_version"] // 10000 == 2
+    steps = out["steps"]
+    assert h["exchanges_per_step"] == (6 * steps + 1) / steps          # + the exchange of the first stage's input per sg_step call
+    for key in ("pack_ms_per_step", "bytes_sent_per_step", "exposed_wait_ms_per_step", "kernel_ms_per_step"):
+        assert len(h[key]) == 4 and all(v >= 0 for v in h[key]), (key, h[key])
+    assert all(v > 0 for v in h["bytes_sent_per_step"]) and all(v == 0 for v in h["host_blocked_ms_per_step"])
+    if scaling == "weak":
+        # 1 x 2 x 2 grid of 16^3 blocks, P4: two sides of 16 * 16 * 2 facets * 15 nodes * 3 components each
+        face = 16 * 16 * 2 * 15 * 3 * 8
+        assert out["config"]["block_grid"] == [1, 2, 2]
+        assert all(v == 2 * face * (6 * steps + 1) / steps for v in h["bytes_sent_per_step"]), h["bytes_sent_per_step"]
+        sw = h["grid_blocks_sweep_ms_per_step"]
+        assert sorted(sw) == ["448", "480", "496", "512"] and all(v > 0 for v in sw.values())
+    assert len(out["rank_ms_per_step"]["per_rank"]) == 4
