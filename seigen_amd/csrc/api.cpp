@@ -773,6 +773,8 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
       }
     if (sponge_pre_affine_lds(W, !dense, nd, d, gw) > ((size_t)150 << 10))
       return fail(h, SG_ERR_STATE, "sg_set_absorption: the affine-sigma tables of this element do not fit the LDS (set SEIGEN_HIP_SPONGE_AFFINE=0)");
+    if (prepare_sponge_pre_affine(d, h->f32, sponge_pre_affine_lds(W, !dense, nd, d, gw)) != 0)
+      return fail(h, SG_ERR_DEVICE, "sg_set_absorption: the affine-sigma pre-pass cannot have its LDS");
     auto up = [&](void** dst, const void* src, size_t bytes) {
       if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return false;
       return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;

@@ -638,7 +638,7 @@ template <typename T, int DIM>
 __global__ __launch_bounds__(256) void sponge_pre_affine_kernel(const T* __restrict__ uabs, const double* __restrict__ X,
                                                                 const int32_t* __restrict__ col, int W, const int32_t* __restrict__ items,
                                                                 const int32_t* __restrict__ item_slots, const double* __restrict__ coef,
-                                                                T* __restrict__ sp, int nitems, int nd, int gw) {
+                                                                T* __restrict__ sp, int nitems, int nd, int gw, int lines) {
   extern __shared__ double s_all[];
   double* sX = s_all;                                   // [DIM][nd][W]
   double* sU = sX + DIM * nd * W;                       // [nd * DIM][gw]   (then the results as [gw][nd * DIM])
@@ -708,9 +708,24 @@ __global__ __launch_bounds__(256) void sponge_pre_affine_kernel(const T* __restr
     for (int j = threadIdx.x; j < rows * gw; j += 256) {
       const int w = j / rows, rr = j - w * rows;
       const int sl = sSlot[w];
-      if (sl >= 0) sp[(long)sl * rows + rr] = (T)sU[j];
+      // a record per slot, or (lines: slot = item' * gw + column, the 3-D MFMA family) the layout of the fields
+      if (sl >= 0) sp[lines ? ((long)(sl / gw) * rows + rr) * gw + sl % gw : (long)sl * rows + rr] = (T)sU[j];
     }
   }
+}
+
+// the instantiations that may need more than 64 KB of dynamic LDS (hexahedra DQ_4) are told so ONCE, at set-up time
+// (sg_set_absorption) - not at the first launch, which may sit inside a stream capture
+int prepare_sponge_pre_affine(int dim, int f32, size_t lds) {
+  if (lds <= ((size_t)64 << 10)) return 0;
+  const void* k = nullptr;
+  if (f32)
+    k = dim == 1 ? (const void*)sponge_pre_affine_kernel<float, 1> : dim == 2 ? (const void*)sponge_pre_affine_kernel<float, 2>
+                                                                              : (const void*)sponge_pre_affine_kernel<float, 3>;
+  else
+    k = dim == 1 ? (const void*)sponge_pre_affine_kernel<double, 1> : dim == 2 ? (const void*)sponge_pre_affine_kernel<double, 2>
+                                                                               : (const void*)sponge_pre_affine_kernel<double, 3>;
+  return (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 size_t sponge_pre_affine_lds(int W, int has_col, int nd, int dim, int gw) {
@@ -719,7 +734,7 @@ size_t sponge_pre_affine_lds(int W, int has_col, int nd, int dim, int gw) {
 }
 
 int launch_sponge_pre_affine(const void* uabs, const double* X, const int32_t* col, int W, const int32_t* items, const int32_t* item_slots,
-                             const double* coef, void* sp, int32_t nitems, int nd, int dim, int gw, int f32, void* stream) {
+                             const double* coef, void* sp, int32_t nitems, int nd, int dim, int gw, int lines, int f32, void* stream) {
   if (nitems <= 0) return 0;
   const int threads = 256;
   if (gw * nd > 8 * threads) return (int)hipErrorInvalidValue;      // MAXR of the kernel
@@ -735,12 +750,9 @@ int launch_sponge_pre_affine(const void* uabs, const double* X, const int32_t* c
   if (grid > nitems) grid = nitems;
 #define SG_AFF_LAUNCH(TT, DD)                                                                                                     \
   do {                                                                                                                          \
-    auto kern = sponge_pre_affine_kernel<TT, DD>;                                                                               \
-    if (lds > ((size_t)64 << 10) &&                                                                                             \
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
-      return (int)hipGetLastError();                                                                                            \
+    auto kern = sponge_pre_affine_kernel<TT, DD>;   /* (more than 64 KB of LDS: prepare_sponge_pre_affine, at set-up) */      \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, (hipStream_t)stream, (const TT*)uabs, X, col, W, items, \
-                       item_slots, coef, (TT*)sp, nitems, nd, gw);                                                              \
+                       item_slots, coef, (TT*)sp, nitems, nd, gw, lines);                                                       \
   } while (0)
   if (f32) {
     if (dim == 1) SG_AFF_LAUNCH(float, 1);

@@ -251,8 +251,9 @@ int launch_sponge_pre(const void* uabs, const double* B, const int32_t* cells, c
 // element-constant X[k][a][j] (row a in ELL form: column col[a][j], or j itself where col is null), coef[slot][dim + 1] = s;
 // items[n] = (cube group) * ncls + class of the n-th item that holds such a cell, item_slots[n][gw] its cells' slots (-1: none)
 int launch_sponge_pre_affine(const void* uabs, const double* X, const int32_t* col, int W, const int32_t* items, const int32_t* item_slots,
-                             const double* coef, void* sp, int32_t nitems, int nd, int dim, int gw, int f32, void* stream);
+                             const double* coef, void* sp, int32_t nitems, int nd, int dim, int gw, int lines, int f32, void* stream);
 size_t sponge_pre_affine_lds(int W, int has_col, int nd, int dim, int gw);
+int prepare_sponge_pre_affine(int dim, int f32, size_t lds);   // once, outside any stream capture: allow that much dynamic LDS
 // ... on the matrix pipe for the 3-D MFMA family in double (kernels_mfma.hip): fragX = mfma_frags_dense of the three X_k
 int launch_sponge_affine_mfma(int P, const void* uabs, const double* fragX, const int32_t* items, const int32_t* item_slots,
                               const double* coef, void* sp, int32_t nitems, void* stream);

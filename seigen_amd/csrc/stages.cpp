@@ -88,7 +88,7 @@ static int run_op(sg_handle* h, int kind, int in_f, int out_f, int aux_f, int mo
                                                     h->sponge_aff_coef, h->sponge_pre, h->sponge_aff_nitems, h->stream)
                         : launch_sponge_pre_affine(a.uabs, h->sponge_aff_X, h->sponge_aff_col, h->sponge_aff_W, h->sponge_aff_items,
                                                    h->sponge_aff_slots, h->sponge_aff_coef, h->sponge_pre, h->sponge_aff_nitems, h->re.nd,
-                                                   h->cfg.dim, (int)h->md.gw, h->f32, h->stream);
+                                                   h->cfg.dim, (int)h->md.gw, h->sponge_pre_lines, h->f32, h->stream);
     if (arc != 0) return fail(h, SG_ERR_DEVICE, "affine-sigma sponge pre-pass launch failed");
     // SECOND runs on its own stream after ev_stage - "everything before this stage's FIRST" - and reads the pre-pass too
     if (region == SG_REGION_FIRST && h->overlap && h->first_recorded_stage >= 0) HIPCHECK(h, hipEventRecord(h->ev_stage, h->stream));

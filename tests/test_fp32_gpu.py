@@ -198,3 +198,33 @@ def test_fp32_2d_eigenmode_error_close_to_fp64(gpu):
             u1, s1 = em.eigenmode2d(T=5.0)
             errs[dtype] = em.eigenmode_error(u1, s1)
         assert abs(errs["f32"][0] - errs["f64"][0]) < 2e-5 and abs(errs["f32"][1] - errs["f64"][1]) < 2e-5, (quad, errs)
+
+
+@pytest.mark.parametrize("degree,n,diagonal", [(4, (17, 3, 2), "left"), (2, (18, 3, 2), "left"), (3, (6, 3, 4), "left")])
+def test_affine_sigma_ramp_fp32(gpu, monkeypatch, degree, n, diagonal):
+    """The FP32 second mode with a sponge that is a linear ramp in all three coordinates: its affine cells go through
+    sponge_pre_affine_kernel<float> (the matrix-pipe form is double only); against the same library with every cell
+    through its matrix, both in float: the difference is float round-off."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    L = tuple(0.4 * k for k in n)
+    h = [L[a] / n[a] for a in range(3)]
+    Xq = oracle_mesh(3, n, L, diagonal).node_coords(4)
+    sigma = 4.0 + 11.0 * Xq[..., 0] + 7.0 * Xq[..., 1] + 23.0 * Xq[..., 2]
+    dt = 0.04 * min(h) / degree ** 2
+    res = {}
+    for affine in ("1", "0"):
+        monkeypatch.setenv("SEIGEN_HIP_SPONGE_AFFINE", affine)
+        blk = HipBlock(3, degree, n, h, [0.0] * 3, diagonal, dtype="f32")
+        u0 = seeded(blk.field_shape(_lib.FIELD_U), 81)
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 82)
+        s0 = 0.5 * (s0 + np.swapaxes(s0, -1, -2))
+        blk.set_params(1.0, dt, 0.6, 0.3)
+        blk.set_absorption(sigma, 4)
+        blk.set_field(_lib.FIELD_U, u0)
+        blk.set_field(_lib.FIELD_S, s0)
+        blk.step(3)
+        res[affine] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    assert np.isfinite(res["1"][0]).all() and rel_err(res["1"][0], u0) > 1e-4
+    assert rel_err(res["1"][0], res["0"][0]) < 2e-5 and rel_err(res["1"][1], res["0"][1]) < 2e-5
