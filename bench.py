@@ -42,6 +42,11 @@ import time
 
 import numpy as np
 
+# The host driver of this pool only supports dmabuf IPC: without this RCCL (and torch's sharing of device tensors between
+# processes) fails with `hipIpcGetMemHandle: invalid argument`.  It has to be in the environment before the HIP runtime
+# starts - i.e. before torch or libseigen_hip are loaded - so it is set here, at import, if the launcher did not.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
