@@ -61,6 +61,11 @@ def main():
             b.set_source(nodes, sv)
             b.set_absorption(sigma, 4)
         nat.comm_init(comm_unique_id(), 0, 1, [None, None, None, None, 0, 0])
+        # which RCCL the library bound (torch's bundled copy or the system's): a major version 2 copy with a name
+        from seigen_amd.backend import comm_library
+        lib_path, lib_version = comm_library()
+        assert lib_path and lib_version // 10000 == 2, (lib_path, lib_version)
+        print("native exchange bound to %s (version %d)" % (lib_path, lib_version))
         # the pattern self-test of the exchange (what NativeExchanger runs before it trusts the communicator)
         assert nat.comm_selftest() == 0
         assert nat.comm_stats()["exchanges"] == 0 and nat.comm_stats()["bytes_sent"] == 0
