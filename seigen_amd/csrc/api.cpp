@@ -6,6 +6,7 @@
 #include <unordered_map>
 
 #include "handle.hpp"
+#include "sponge_tables.hpp"
 
 static void free_affine_sponge(sg_handle* h);
 
@@ -506,304 +507,96 @@ static void free_affine_sponge(sg_handle* h) {
   h->sponge_aff_W = 0;
 }
 
-// sigma of one cell, given at the DG_q nodes: is it s_0 + sum_k s_k xi_k in the reference coordinates (an affine function
-// of x on an affine cell: every cell of a linear ramp)?  The fit comes from the vertex nodes, the verdict from all of them.
-static bool affine_fit(const double* sg_, const std::vector<int>& latQ, int nq, int d, int q, const int* vtx, double* s) {
-  s[0] = sg_[vtx[0]];
-  double big = std::fabs(s[0]);
-  for (int k = 0; k < d; ++k) {
-    s[1 + k] = sg_[vtx[1 + k]] - s[0];
-    big = std::max(big, std::fabs(sg_[vtx[1 + k]]));
-  }
-  const double tol = 64 * std::numeric_limits<double>::epsilon() * big;
-  for (int c = 0; c < nq; ++c) {
-    double v = s[0];
-    for (int k = 0; k < d; ++k) v += s[1 + k] * ((double)latQ[(size_t)c * d + k] / q);
-    if (!(std::fabs(v - sg_[c]) <= tol)) return false;
-  }
-  return true;
-}
-
+// What each cell gets - nothing, a scalar, dim + 1 numbers, a matrix - is decided by plan_sponge (sponge_tables.cpp: plain
+// C++, under the CPU sanitizers); this function frees the old tables and uploads the new ones.
 int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree) {
   if (h) h->epoch += 1;
   if (!h) return SG_ERR_ARG;
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   HIPCHECK(h, sync_all(h));
-  if (h->sponge_slot) {
-    (void)hipFree(h->sponge_slot);
-    h->sponge_slot = nullptr;
-  }
-  if (h->sponge_B) {
-    (void)hipFree(h->sponge_B);
-    h->sponge_B = nullptr;
-  }
-  if (h->sponge_sigma) {
-    (void)hipFree(h->sponge_sigma);
-    h->sponge_sigma = nullptr;
-  }
+  for (void** p : {(void**)&h->sponge_slot, (void**)&h->sponge_B, (void**)&h->sponge_sigma, (void**)&h->sponge_cells,
+                   (void**)&h->sponge_mat, (void**)&h->sponge_pre})
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
   h->sponge_nslots = 0;
   h->sponge_pre_key = -1;
   h->sponge_pre_regions = 0;
   h->sponge_pre_ver = ~0ull;
   h->sponge_pre_field = -1;
-  if (h->sponge_cells) {
-    (void)hipFree(h->sponge_cells);
-    h->sponge_cells = nullptr;
-  }
-  if (h->sponge_mat) {
-    (void)hipFree(h->sponge_mat);
-    h->sponge_mat = nullptr;
-  }
-  if (h->sponge_pre) {
-    (void)hipFree(h->sponge_pre);
-    h->sponge_pre = nullptr;
-  }
+  h->sponge_pre_lines = 0;
   free_affine_sponge(h);
   if (!sigma_nodes) return SG_OK;
   if (sigma_degree < 1 || sigma_degree > 6) return fail(h, SG_ERR_ARG, "sigma_degree must be 1..6");
   const int d = h->cfg.dim, nd = h->re.nd;
-  const int nq = num_nodes(d, sigma_degree, h->re.kind);
-  // B_e[a][b] = sum_c A[a][c][b] sigma_{e,c}  for cells with a non-zero sigma
-  std::vector<double> A = sponge_tensor(d, h->cfg.degree, sigma_degree, h->re.kind);
-  std::vector<int32_t> slot((size_t)h->ncells, -1);
-  std::vector<double> B;
-  // 2-D tile and 3-D matrix kernels (tetrahedra, hexahedra DQ_3 / DQ_4): a sigma that is one value on all nodes of a cell (the piecewise-constant sponges of the reference's
-  // problem scripts, explosive_source_lf4.py:42-45) makes B_e = Minv (sigma M) = sigma I: such a cell carries its sigma
-  // instead of a matrix (kernels.hpp StageArgs::sponge_sigma)
-  std::vector<double> sig;
-  if (h->use_tile || h->use_mfma || h->use_hexm || h->use_lane) sig.assign((size_t)h->ncells, 0.0);
-  // Cells with the same nodal sigma share one matrix (A is the reference element's): the strips of the reference's scripts
-  // have a few dozen distinct edge cells, a sigma that depends on one coordinate n0 x classes - the matrix table stays in
-  // the caches.  Families that read B u_abs from the pre-pass number their matrix cells (slot -> cell, slot -> matrix); the
-  // others look the matrix up by the slot itself.
-  const bool pre_family = h->use_mfma || h->use_hexm || h->use_lane;
-  std::unordered_map<std::string, int32_t> mat_id;
-  std::vector<int32_t> mat_of;
-  int32_t nslots = 0, nmat = 0;
-  // Families with a pre-pass: a cell whose sigma is AFFINE in the reference coordinates (every cell inside a linear ramp)
-  // takes its dim + 1 coefficients instead of a matrix (kernels.hip sponge_pre_affine_kernel); SEIGEN_HIP_SPONGE_AFFINE=0
-  // sends those cells through their matrices as before (tests: the two must agree)
+  SpongeRequest rq;
+  rq.dim = d;
+  rq.degree = h->cfg.degree;
+  rq.kind = h->re.kind;
+  rq.sigma_degree = sigma_degree;
+  rq.ncells = h->ncells;
+  rq.ncls = h->ncls;
+  rq.gw = (int)h->md.gw;
+  // 2-D tile and 3-D matrix kernels, lane kernels: a sigma that is one value on all nodes of a cell (the piecewise-constant
+  // sponges of the reference's problem scripts, explosive_source_lf4.py:42-45) is applied as sigma u at the node
+  rq.want_scalar = h->use_tile || h->use_mfma || h->use_hexm || h->use_lane;
+  // the 3-D matrix kernels and the lane kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
+  // kernels work their small matrices off themselves: a launch more per F stage costs them more
+  rq.pre_family = h->use_mfma || h->use_hexm || h->use_lane;
+  // Affine cells take dim + 1 numbers (kernels.hip sponge_pre_affine_kernel, kernels_mfma.hip sponge_affine_mfma);
+  // SEIGEN_HIP_SPONGE_AFFINE=0 sends them through their matrices (tests: the two must agree).  The lane kernels' cells -
+  // hexahedra DQ_1 / DQ_2, gw = 64 - have matrices of at most 27 x 27 shared through the caches: there the matrix pre-pass
+  // is the faster one (64.5 against 61.9 G at 96^3 DQ_2, profiles/r06/affine_sponge.txt); '1' forces the affine path
   const char* aff_env = std::getenv("SEIGEN_HIP_SPONGE_AFFINE");
-  // (the lane kernels' cells - hexahedra DQ_1 / DQ_2, gw = 64 - have matrices of at most 27 x 27 shared through the caches:
-  // there the matrix pre-pass is the faster one, 51.5 against 45.1 G at 96^3 DQ_2, profiles/r06/affine_sponge.txt; '1' forces)
-  const bool try_affine = pre_family && sigma_degree >= 1 && !(aff_env && aff_env[0] == '0') &&
-                          (!h->use_lane || (aff_env && aff_env[0] == '1'));
-  std::vector<int> latQ;
-  int vtx[4] = {0, 0, 0, 0};
-  if (try_affine) {
-    lattice_points(d, sigma_degree, latQ, h->re.kind);
-    for (int c = 0; c < nq; ++c) {
-      int sum = 0, which = -1;
-      for (int k = 0; k < d; ++k) {
-        sum += latQ[(size_t)c * d + k];
-        if (latQ[(size_t)c * d + k] == sigma_degree) which = k;
-      }
-      if (sum == 0) vtx[0] = c;
-      if (sum == sigma_degree && which >= 0) vtx[1 + which] = c;
-    }
+  rq.try_affine = rq.pre_family && !(aff_env && aff_env[0] == '0') && (!h->use_lane || (aff_env && aff_env[0] == '1'));
+  // 3-D MFMA family: the pre-pass results live in LINE layout like the fields (a record per cell cost the affine pre-pass
+  // scattered 24-byte stores and the F stage scattered loads)
+  rq.line_layout = h->use_mfma;
+  SpongePlan pl;
+  try {
+    pl = plan_sponge(rq, sigma_nodes);
+  } catch (const std::exception& e) {
+    return fail(h, SG_ERR_ARG, std::string("sg_set_absorption: ") + e.what());
   }
-  std::vector<double> aff_coef;        // [slot][d + 1] (zeros for the slots with a matrix)
-  std::vector<int32_t> mat_slots;      // the slots that have a matrix
-  int32_t naffine = 0;
-  for (int64_t e = 0; e < h->ncells; ++e) {
-    const double* sg_ = sigma_nodes + (size_t)e * nq;
-    bool nz = false, same = true;
-    for (int c = 0; c < nq; ++c) {
-      nz = nz || (sg_[c] != 0.0);
-      same = same && (sg_[c] == sg_[0]);
-    }
-    if (!nz) continue;
-    if (!sig.empty()) {
-      sig[(size_t)e] = same ? sg_[0] : std::numeric_limits<double>::quiet_NaN();
-      if (same) continue;
-    }
-    if (try_affine) {
-      double sfit[4] = {0, 0, 0, 0};
-      const bool aff = affine_fit(sg_, latQ, nq, d, sigma_degree, vtx, sfit);
-      aff_coef.resize((size_t)(nslots + 1) * (d + 1), 0.0);
-      if (aff) {
-        for (int k = 0; k <= d; ++k) aff_coef[(size_t)nslots * (d + 1) + k] = sfit[k];
-        slot[e] = nslots++;
-        mat_of.push_back(-1);
-        naffine += 1;
-        continue;
-      }
-    }
-    if (pre_family) mat_slots.push_back(nslots);
-    const std::string key(reinterpret_cast<const char*>(sg_), (size_t)nq * sizeof(double));
-    auto found = mat_id.find(key);
-    int32_t m;
-    if (found != mat_id.end()) {
-      m = found->second;
-    } else {
-      m = nmat++;
-      mat_id.emplace(key, m);
-      size_t base = B.size();
-      B.resize(base + (size_t)nd * nd, 0.0);
-      for (int a = 0; a < nd; ++a)
-        for (int c = 0; c < nq; ++c) {
-          double s = sg_[c];
-          if (s == 0.0) continue;
-          const double* Arow = &A[((size_t)a * nq + c) * nd];
-          double* Brow = &B[base + (size_t)a * nd];
-          for (int b = 0; b < nd; ++b) Brow[b] += Arow[b] * s;
-        }
-    }
-    if (pre_family) {
-      slot[e] = nslots++;
-      mat_of.push_back(m);
-    } else {
-      slot[e] = m;
-      nslots = nmat;
-    }
-  }
-  // 3-D MFMA family: the pre-pass results live in LINE layout like the fields - sp[(item n)][node][comp][16 cells], n counting
-  // the items that hold a cell with a slot - so the pre-pass stores and the F stage's loads move whole 128-byte lines (a
-  // record per cell cost the affine pre-pass half its time in scattered 24-byte stores).  A cell's slot is then n * 16 + w.
-  const bool line_pre = h->use_mfma && nslots > 0;
-  if (line_pre) {
-    const int gw = (int)h->md.gw, ncls = h->ncls;
-    const int64_t ngroups = (h->ncells / ncls + gw - 1) / gw;
-    std::vector<int32_t> renum((size_t)nslots, -1);
-    int32_t nit = 0;
-    for (int64_t g = 0; g < ngroups; ++g)
-      for (int k = 0; k < ncls; ++k) {
-        bool any = false;
-        for (int w = 0; w < gw; ++w) {
-          const int64_t e = (g * gw + w) * ncls + k;
-          if (e < h->ncells && slot[(size_t)e] >= 0) {
-            renum[(size_t)slot[(size_t)e]] = nit * gw + w;
-            any = true;
-          }
-        }
-        if (any) nit += 1;
-      }
-    const int32_t nnew = nit * gw;
-    std::vector<int32_t> mat2((size_t)nnew, -1);
-    std::vector<double> coef2(aff_coef.empty() ? 0 : (size_t)nnew * (d + 1), 0.0);
-    aff_coef.resize(aff_coef.empty() ? 0 : (size_t)nslots * (d + 1), 0.0);
-    for (int32_t o = 0; o < nslots; ++o) {
-      mat2[(size_t)renum[(size_t)o]] = mat_of[(size_t)o];
-      if (!coef2.empty())
-        for (int k = 0; k <= d; ++k) coef2[(size_t)renum[(size_t)o] * (d + 1) + k] = aff_coef[(size_t)o * (d + 1) + k];
-    }
-    for (int32_t& ms : mat_slots) ms = renum[(size_t)ms];
-    for (int64_t e = 0; e < h->ncells; ++e)
-      if (slot[(size_t)e] >= 0) slot[(size_t)e] = renum[(size_t)slot[(size_t)e]];
-    mat_of.swap(mat2);
-    aff_coef.swap(coef2);
-    nslots = nnew;
-  }
-  h->sponge_pre_lines = line_pre ? 1 : 0;
-  HIPCHECK(h, hipMalloc((void**)&h->sponge_slot, slot.size() * sizeof(int32_t)));
-  HIPCHECK(h, hipMemcpy(h->sponge_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  h->sponge_nslots = nslots;
-  if (pre_family && nslots > 0) {
-    // the 3-D matrix kernels and the lane kernels read B u_abs from a pre-pass (kernels.hpp launch_sponge_pre); the 2-D tile
-    // kernels work their small matrices off themselves: a launch more per F stage costs them more
-    std::vector<int32_t> cells((size_t)nslots);
-    for (int64_t e = 0; e < h->ncells; ++e)
-      if (slot[(size_t)e] >= 0) cells[(size_t)slot[(size_t)e]] = (int32_t)e;
-    HIPCHECK(h, hipMalloc((void**)&h->sponge_cells, cells.size() * sizeof(int32_t)));
-    HIPCHECK(h, hipMemcpy(h->sponge_cells, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHECK(h, hipMalloc((void**)&h->sponge_mat, mat_of.size() * sizeof(int32_t)));
-    HIPCHECK(h, hipMemcpy(h->sponge_mat, mat_of.data(), mat_of.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHECK(h, hipMalloc(&h->sponge_pre, (size_t)nslots * nd * d * (h->f32 ? sizeof(float) : sizeof(double))));
-    HIPCHECK(h, hipMemset(h->sponge_pre, 0, (size_t)nslots * nd * d * (h->f32 ? sizeof(float) : sizeof(double))));
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return false;
+    return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = up((void**)&h->sponge_slot, pl.slot.data(), pl.slot.size() * sizeof(int32_t));
+  h->sponge_nslots = pl.nslots;
+  h->sponge_pre_lines = (rq.line_layout && pl.nslots > 0) ? 1 : 0;
+  if (rq.pre_family && pl.nslots > 0) {
+    const size_t pre_bytes = (size_t)pl.nslots * nd * d * (h->f32 ? sizeof(float) : sizeof(double));
+    ok = ok && up((void**)&h->sponge_cells, pl.cells.data(), pl.cells.size() * sizeof(int32_t)) &&
+         up((void**)&h->sponge_mat, pl.mat_of.data(), pl.mat_of.size() * sizeof(int32_t)) && hipMalloc(&h->sponge_pre, pre_bytes) == hipSuccess &&
+         hipMemset(h->sponge_pre, 0, pre_bytes) == hipSuccess;
     // the cells with a matrix: every slot in order, or - line layout, affine cells among them - a list
-    h->sponge_nmat_slots = (int32_t)mat_slots.size();
-    if (line_pre || naffine > 0) {
-      HIPCHECK(h, hipMalloc((void**)&h->sponge_mat_slots, (mat_slots.size() ? mat_slots.size() : 1) * sizeof(int32_t)));
-      HIPCHECK(h, hipMemcpy(h->sponge_mat_slots, mat_slots.data(), mat_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
+    h->sponge_nmat_slots = (int32_t)pl.mat_slots.size();
+    if (h->sponge_pre_lines || pl.naffine > 0)
+      ok = ok && up((void**)&h->sponge_mat_slots, pl.mat_slots.data(), pl.mat_slots.size() * sizeof(int32_t));
   }
-  if (pre_family && naffine > 0) {
-    const int gw = (int)h->md.gw, ncls = h->ncls;
-    // X_k = Mhat^-1 int xi_k phi_a phi_b = sum_c xi_k(c) A1[a][c][b] over the nodes c of the degree-1 element (xi_k is one of
-    // its basis functions on a simplex, a sum of them on a tensor-product cell)
-    std::vector<double> A1 = sponge_tensor(d, h->cfg.degree, 1, h->re.kind);
-    std::vector<int> lat1;
-    lattice_points(d, 1, lat1, h->re.kind);
-    const int n1 = num_nodes(d, 1, h->re.kind);
-    std::vector<double> Xd((size_t)d * nd * nd, 0.0);
-    for (int k = 0; k < d; ++k)
-      for (int a = 0; a < nd; ++a)
-        for (int c = 0; c < n1; ++c) {
-          if (lat1[(size_t)c * d + k] == 0) continue;
-          for (int b = 0; b < nd; ++b) Xd[((size_t)k * nd + a) * nd + b] += A1[((size_t)a * n1 + c) * nd + b];
-        }
-    // rows in ELL form over the union of the d patterns: dense on simplices, 3 P + 1 entries on tensor-product cells
-    std::vector<std::vector<int32_t>> pat((size_t)nd);
-    int W = 0;
-    for (int a = 0; a < nd; ++a) {
-      for (int b = 0; b < nd; ++b) {
-        bool any = false;
-        for (int k = 0; k < d; ++k) any = any || std::fabs(Xd[((size_t)k * nd + a) * nd + b]) > 1e-14;
-        if (any) pat[(size_t)a].push_back(b);
-      }
-      W = std::max(W, (int)pat[(size_t)a].size());
-    }
-    const bool dense = W == nd;
-    std::vector<double> X((size_t)d * nd * W, 0.0);
-    std::vector<int32_t> colv((size_t)nd * W, 0);
-    for (int a = 0; a < nd; ++a)
-      for (int j = 0; j < W; ++j) {
-        const int b = dense ? j : (j < (int)pat[(size_t)a].size() ? pat[(size_t)a][(size_t)j] : a);   // padding: a zero entry
-        colv[(size_t)a * W + j] = b;
-        const bool real = dense || j < (int)pat[(size_t)a].size();
-        for (int k = 0; k < d; ++k) X[((size_t)k * nd + a) * W + j] = real ? Xd[((size_t)k * nd + a) * nd + b] : 0.0;
-      }
-    // the items (gw cells of one class, mesh_tables.hpp) that hold an affine cell, and their cells' slots
-    std::vector<int32_t> items, islots;
-    const int64_t ngroups = (h->ncells / ncls + gw - 1) / gw;
-    for (int64_t g = 0; g < ngroups; ++g)
-      for (int k = 0; k < ncls; ++k) {
-        bool any = false;
-        for (int w = 0; w < gw && !any; ++w) {
-          const int64_t c = g * gw + w, e = c * ncls + k;
-          any = e < h->ncells && slot[(size_t)e] >= 0 && mat_of[(size_t)slot[(size_t)e]] < 0;
-        }
-        if (!any) continue;
-        items.push_back((int32_t)(g * ncls + k));
-        for (int w = 0; w < gw; ++w) {
-          const int64_t c = g * gw + w, e = c * ncls + k;
-          const bool aff = c * ncls < h->ncells && e < h->ncells && slot[(size_t)e] >= 0 && mat_of[(size_t)slot[(size_t)e]] < 0;
-          islots.push_back(aff ? slot[(size_t)e] : -1);
-        }
-      }
-    if (sponge_pre_affine_lds(W, !dense, nd, d, gw) > ((size_t)150 << 10))
+  if (rq.pre_family && pl.naffine > 0) {
+    const size_t lds = sponge_pre_affine_lds(pl.W, !pl.dense, nd, d, rq.gw);
+    if (lds > ((size_t)150 << 10))
       return fail(h, SG_ERR_STATE, "sg_set_absorption: the affine-sigma tables of this element do not fit the LDS (set SEIGEN_HIP_SPONGE_AFFINE=0)");
-    if (prepare_sponge_pre_affine(d, h->f32, sponge_pre_affine_lds(W, !dense, nd, d, gw)) != 0)
+    if (prepare_sponge_pre_affine(d, h->f32, lds) != 0)
       return fail(h, SG_ERR_DEVICE, "sg_set_absorption: the affine-sigma pre-pass cannot have its LDS");
-    auto up = [&](void** dst, const void* src, size_t bytes) {
-      if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return false;
-      return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
-    };
-    aff_coef.resize((size_t)nslots * (d + 1), 0.0);
-    if (!up((void**)&h->sponge_aff_items, items.data(), items.size() * sizeof(int32_t)) ||
-        !up((void**)&h->sponge_aff_slots, islots.data(), islots.size() * sizeof(int32_t)) ||
-        !up((void**)&h->sponge_aff_coef, aff_coef.data(), aff_coef.size() * sizeof(double)) ||
-        !up((void**)&h->sponge_aff_X, X.data(), X.size() * sizeof(double)) ||
-        (!dense && !up((void**)&h->sponge_aff_col, colv.data(), colv.size() * sizeof(int32_t))))
-      return fail(h, SG_ERR_NOMEM, "hipMalloc of the affine-sigma tables failed");
+    ok = ok && up((void**)&h->sponge_aff_items, pl.items.data(), pl.items.size() * sizeof(int32_t)) &&
+         up((void**)&h->sponge_aff_slots, pl.item_slots.data(), pl.item_slots.size() * sizeof(int32_t)) &&
+         up((void**)&h->sponge_aff_coef, pl.aff_coef.data(), pl.aff_coef.size() * sizeof(double)) &&
+         up((void**)&h->sponge_aff_X, pl.X.data(), pl.X.size() * sizeof(double)) &&
+         (pl.dense || up((void**)&h->sponge_aff_col, pl.col.data(), pl.col.size() * sizeof(int32_t)));
     if (h->use_mfma && !h->f32 && d == 3) {      // on the matrix pipe (kernels_mfma.hip sponge_affine_mfma)
-      const std::vector<double> fX = mfma_frags_dense(h->re, Xd.data(), 3);
-      if (!up((void**)&h->sponge_aff_frag, fX.data(), fX.size() * sizeof(double)))
-        return fail(h, SG_ERR_NOMEM, "hipMalloc of the affine-sigma tiles failed");
+      const std::vector<double> fX = mfma_frags_dense(h->re, pl.Xd.data(), 3);
+      ok = ok && up((void**)&h->sponge_aff_frag, fX.data(), fX.size() * sizeof(double));
     }
-    h->sponge_aff_nitems = (int32_t)items.size();
-    h->sponge_aff_W = W;
+    h->sponge_aff_nitems = (int32_t)pl.items.size();
+    h->sponge_aff_W = pl.W;
   }
-  if (!sig.empty()) {
-    HIPCHECK(h, hipMalloc((void**)&h->sponge_sigma, sig.size() * sizeof(double)));
-    HIPCHECK(h, hipMemcpy(h->sponge_sigma, sig.data(), sig.size() * sizeof(double), hipMemcpyHostToDevice));
-  }
-  if (nslots > 0 && !B.empty()) {
-    HIPCHECK(h, hipMalloc((void**)&h->sponge_B, B.size() * sizeof(double)));
-    HIPCHECK(h, hipMemcpy(h->sponge_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
-  } else {
-    HIPCHECK(h, hipMalloc((void**)&h->sponge_B, sizeof(double)));
-  }
+  if (!pl.sig.empty()) ok = ok && up((void**)&h->sponge_sigma, pl.sig.data(), pl.sig.size() * sizeof(double));
+  ok = ok && up((void**)&h->sponge_B, pl.B.data(), pl.B.size() * sizeof(double));
+  if (!ok) return fail(h, SG_ERR_NOMEM, "sg_set_absorption: hipMalloc / upload of the sponge tables failed");
   return SG_OK;
 }
 

@@ -2,6 +2,7 @@
 // needs no device - reference elements, mesh tables, MFMA fragment tables, the device-free C-ABI entry points - built with
 // -fsanitize=address,undefined and walked over every (dim, degree, cell type, diagonal) the library accepts, plus the
 // argument errors the entry points must refuse.  Exit code 0 and no sanitizer report = clean.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,7 @@
 #include "hostlogic.hpp"
 #include "kernels.hpp"
 #include "mfma_tables.hpp"
+#include "sponge_tables.hpp"
 
 using namespace sg;
 
@@ -158,6 +160,97 @@ static void regions_and_coords() {
   EXPECT(sg_region_boxes(nullptr, 0, nullptr, 0) == SG_ERR_ARG);
 }
 
+// sg_set_absorption's host half (csrc/sponge_tables.cpp): every kind of cell - none, constant, affine, general - side by side on
+// ragged blocks (a last group with padding), every family flavour (scalar or not, pre-pass or not, records or lines)
+static void sponge_plans(int dim, int degree, int kind, int q) {
+  const int nd = num_nodes(dim, degree, kind), nq = num_nodes(dim, q, kind);
+  std::vector<int> latQ;
+  lattice_points(dim, q, latQ, kind);
+  const int ncls = kind == KIND_TENSOR ? 1 : (dim == 1 ? 1 : (dim == 2 ? 2 : 6));
+  for (int gw : {1, 16, 64}) {
+    const int64_t ncube = 37, ncells = ncube * ncls;      // 37 cubes: the last group is padded at gw = 16 and 64
+    std::vector<double> sigma((size_t)ncells * nq, 0.0);
+    unsigned seed = 12345u + (unsigned)(dim * 100 + degree * 10 + q);
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (double)(seed >> 8) / (double)(1u << 24); };
+    std::vector<int> want((size_t)ncells);
+    for (int64_t e = 0; e < ncells; ++e) {
+      const int what = (int)(rnd() * 4.0) & 3;      // 0 none, 1 constant, 2 affine, 3 general
+      want[(size_t)e] = what;
+      const double s0 = 1.0 + 9.0 * rnd(), g[3] = {rnd() - 0.5, rnd() - 0.5, rnd() - 0.5};
+      for (int c = 0; c < nq; ++c) {
+        double v = 0.0;
+        if (what == 1) v = s0;
+        if (what == 2) {
+          v = s0;
+          for (int k = 0; k < dim; ++k) v += g[k] * (double)latQ[(size_t)c * dim + k] / q;
+        }
+        if (what == 3) v = 10.0 * rnd();
+        sigma[(size_t)e * nq + c] = v;
+      }
+    }
+    for (int flavour = 0; flavour < 5; ++flavour) {
+      SpongeRequest rq;
+      rq.dim = dim; rq.degree = degree; rq.kind = kind; rq.sigma_degree = q; rq.ncells = ncells; rq.ncls = ncls; rq.gw = gw;
+      rq.want_scalar = flavour >= 1;
+      rq.pre_family = flavour >= 2;
+      rq.try_affine = flavour >= 3;
+      rq.line_layout = flavour == 4;
+      const SpongePlan pl = plan_sponge(rq, sigma.data());
+      EXPECT((int64_t)pl.slot.size() == ncells && pl.B.size() == (size_t)pl.nmat * nd * nd);
+      int naff = 0;
+      for (int64_t e = 0; e < ncells; ++e) {
+        const int what = want[(size_t)e], sl = pl.slot[(size_t)e];
+        const bool scalar = rq.want_scalar && what == 1;
+        EXPECT((sl >= 0) == (what != 0 && !scalar));
+        if (rq.want_scalar) {
+          const double sg_ = pl.sig[(size_t)e];
+          EXPECT(what == 0 ? sg_ == 0.0 : (what == 1 ? sg_ == sigma[(size_t)e * nq] : sg_ != sg_));
+        }
+        if (sl < 0) continue;
+        EXPECT(sl < pl.nslots);
+        if (!rq.pre_family) continue;
+        EXPECT(pl.cells[(size_t)sl] == (int32_t)e);
+        if (rq.line_layout) EXPECT(sl % gw == (int)((e / ncls) % gw));      // the cell's column of its item
+        const bool affine = pl.mat_of[(size_t)sl] < 0;
+        // q = 1 on a simplex: every sigma is affine; a constant cell of a family without scalars is affine too
+        const bool must = what == 2 || (what == 1 && !rq.want_scalar) || (what == 3 && q == 1 && kind == KIND_SIMPLEX);
+        EXPECT(affine == (rq.try_affine && must));
+        if (affine) {
+          naff += 1;
+          for (int c = 0; c < nq; ++c) {      // the coefficients reproduce the nodal sigma
+            double v = pl.aff_coef[(size_t)sl * (dim + 1)];
+            for (int k = 0; k < dim; ++k) v += pl.aff_coef[(size_t)sl * (dim + 1) + 1 + k] * (double)latQ[(size_t)c * dim + k] / q;
+            EXPECT(std::fabs(v - sigma[(size_t)e * nq + c]) < 1e-12);
+          }
+        } else {
+          EXPECT(pl.mat_of[(size_t)sl] < pl.nmat);
+        }
+      }
+      EXPECT(naff == pl.naffine);
+      if (rq.pre_family) {
+        for (int32_t ms : pl.mat_slots) EXPECT(ms >= 0 && ms < pl.nslots && pl.mat_of[(size_t)ms] >= 0);
+        EXPECT((int)pl.mat_slots.size() + pl.naffine == (int)std::count_if(pl.slot.begin(), pl.slot.end(), [](int32_t v) { return v >= 0; }));
+      }
+      if (pl.naffine > 0) {
+        EXPECT(pl.X.size() == (size_t)dim * nd * pl.W && pl.col.size() == (size_t)nd * pl.W && pl.item_slots.size() == pl.items.size() * gw);
+        // X_k is multiplication by xi_k followed by the L2 projection: it maps the constant 1 to xi_k at the nodes
+        std::vector<int> latP;
+        lattice_points(dim, degree, latP, kind);
+        for (int k = 0; k < dim; ++k)
+          for (int a = 0; a < nd; ++a) {
+            double row = 0.0, ell = 0.0;
+            for (int b = 0; b < nd; ++b) row += pl.Xd[((size_t)k * nd + a) * nd + b];
+            for (int j = 0; j < pl.W; ++j) ell += pl.X[((size_t)k * nd + a) * pl.W + j];
+            EXPECT(std::fabs(row - (double)latP[(size_t)a * dim + k] / degree) < 1e-10 && std::fabs(row - ell) < 1e-12);
+          }
+        int seen = 0;
+        for (int32_t s : pl.item_slots) seen += s >= 0;
+        EXPECT(seen == pl.naffine);
+      }
+    }
+  }
+}
+
 int main() {
   for (int cell_type : {0, 1})
     for (int dim = 1; dim <= 3; ++dim)
@@ -180,6 +273,13 @@ int main() {
     tile_tables_2d(degree, KIND_TENSOR);
   }
   regions_and_coords();
+  for (int dim = 1; dim <= 3; ++dim)
+    for (int degree : {1, 2, 4})
+      for (int kind : {KIND_SIMPLEX, KIND_TENSOR}) {
+        if (kind == KIND_TENSOR && dim == 1) continue;
+        if (kind == KIND_TENSOR && dim == 3 && degree == 4) continue;      // 125^3 sponge tensor: minutes under the sanitizers
+        for (int q : {1, 4}) sponge_plans(dim, degree, kind, q);
+      }
   // arguments the entry points must refuse
   EXPECT(sg_reference_operator_cell(7, 2, 2, 0, 0, nullptr, 0) == SG_ERR_ARG);
   EXPECT(sg_reference_operator_cell(0, 2, 2, 9, 0, nullptr, 0) == SG_ERR_ARG);
