@@ -73,3 +73,44 @@ def test_graph_replay_with_a_source_is_not_slower(gpu, monkeypatch):
         blk.sync()
         times[graph] = time.perf_counter() - t0
     assert times[True] < 1.05 * times[False], times
+
+
+@pytest.mark.parametrize("dim,degree,n,diagonal", [(3, 3, (18, 3, 2), "left"), (3, 4, (17, 2, 2), "left"), (3, 3, (5, 3, 2), "quadrilateral"),
+                                                   (3, 2, (6, 4, 3), "left")])
+@pytest.mark.parametrize("calls", [(19,), (9, 1, 12), (1, 1, 8, 3)])
+def test_graph_replay_with_a_sponge_pre_pass_is_bitwise_the_plain_run(gpu, monkeypatch, dim, degree, n, diagonal, calls):
+    """Round 6: the sponge pre-pass of the 3-D families belongs to a STATE of the velocity field and is launched only when
+    the buffer is stale (once per step, in stage UTEMP; stages.cpp fver / sponge_pre_ver).  That decision is made on the host
+    while a graph is captured and replayed on the device: replayed runs (graphs of eight steps and of one, runs continued by
+    further sg_step calls, an upload of the velocity in between) must equal the launch-by-launch runs bit for bit - with cells
+    of every kind: no sponge, constant, affine, general."""
+    from seigen_amd import _lib
+    from seigen_amd.backend import HipBlock
+    from tests.util import oracle_mesh
+    L = tuple(0.4 * k for k in n)
+    h = [L[a] / n[a] for a in range(dim)]
+    Xq = oracle_mesh(dim, n, L, diagonal).node_coords(4)
+    r = np.random.default_rng(5)
+    kind = r.integers(0, 4, size=Xq.shape[0])
+    sigma = np.zeros(Xq.shape[:2])
+    sigma[kind == 1] = 7.0
+    sigma[kind == 2] = (3.0 + 11.0 * Xq[..., 0] + 7.0 * Xq[..., 1] + 5.0 * Xq[..., 2])[kind == 2]
+    sigma[kind == 3] = r.uniform(0.0, 20.0, size=(int((kind == 3).sum()), Xq.shape[1]))
+    res = {}
+    for graph in (False, True):
+        monkeypatch.setenv("SEIGEN_HIP_GRAPH", "1" if graph else "0")
+        blk = HipBlock(dim, degree, n, h, [0.0] * dim, diagonal)
+        blk.set_params(1.0, 0.02 * min(h) / degree ** 2, 0.5, 0.25)
+        u0 = seeded(blk.field_shape(_lib.FIELD_U), 1)
+        blk.set_field(_lib.FIELD_U, u0)
+        s0 = seeded(blk.field_shape(_lib.FIELD_S), 2)
+        blk.set_field(_lib.FIELD_S, 0.5 * (s0 + np.swapaxes(s0, -1, -2)))
+        blk.set_absorption(sigma, 4)
+        for i, c in enumerate(calls):
+            blk.step(c)
+            if i == 0 and len(calls) > 2:      # the velocity is replaced between two calls: the buffer's state is stale
+                blk.set_field(_lib.FIELD_U, 0.5 * blk.get_field(_lib.FIELD_U) + 0.1 * u0)
+        res[graph] = (blk.get_field(_lib.FIELD_U), blk.get_field(_lib.FIELD_S))
+        blk.close()
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    assert np.isfinite(res[True][0]).all() and np.abs(res[True][0]).max() > 0
