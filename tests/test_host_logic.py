@@ -630,3 +630,18 @@ def test_experiment_patches_are_indexed_and_apply():
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok ") >= 11
+
+
+def test_every_environment_switch_is_documented():
+    """Every SEIGEN_* variable the product reads (library sources, host layer, bench.py) has a line in INTEGRATION.md."""
+    import glob
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    files = glob.glob(os.path.join(ROOT, "seigen_amd", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "bench.py")]
+    for ext in ("cpp", "hip", "hpp"):
+        files += glob.glob(os.path.join(ROOT, "seigen_amd", "csrc", "*." + ext))
+    names = set()
+    for f in files:
+        names |= set(re.findall(r"SEIGEN_[A-Z0-9_]+", open(f).read()))
+    names -= {"SEIGEN_HIP_H"}      # the header's include guard
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, "not in INTEGRATION.md's table: %s" % missing
