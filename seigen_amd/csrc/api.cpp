@@ -589,7 +589,7 @@ int sg_set_absorption(sg_handle* h, const double* sigma_nodes, int sigma_degree)
          (pl.dense || up((void**)&h->sponge_aff_col, pl.col.data(), pl.col.size() * sizeof(int32_t)));
     if (h->use_mfma && !h->f32 && d == 3) {      // on the matrix pipe (kernels_mfma.hip sponge_affine_mfma)
       const std::vector<double> fX = mfma_frags_dense(h->re, pl.Xd.data(), 3);
-      ok = ok && up((void**)&h->sponge_aff_frag, fX.data(), fX.size() * sizeof(double));
+      ok = ok && up((void**)&h->sponge_aff_frag, fX.data(), fX.size() * sizeof(double)) && prepare_sponge_affine_mfma(h->cfg.degree) == 0;
     }
     h->sponge_aff_nitems = (int32_t)pl.items.size();
     h->sponge_aff_W = pl.W;

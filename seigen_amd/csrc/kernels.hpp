@@ -255,6 +255,7 @@ int launch_sponge_pre_affine(const void* uabs, const double* X, const int32_t* c
 size_t sponge_pre_affine_lds(int W, int has_col, int nd, int dim, int gw);
 int prepare_sponge_pre_affine(int dim, int f32, size_t lds);   // once, outside any stream capture: allow that much dynamic LDS
 // ... on the matrix pipe for the 3-D MFMA family in double (kernels_mfma.hip): fragX = mfma_frags_dense of the three X_k
+int prepare_sponge_affine_mfma(int P);   // once, at set-up: the occupancy query behind the launch's grid size
 int launch_sponge_affine_mfma(int P, const void* uabs, const double* fragX, const int32_t* items, const int32_t* item_slots,
                               const double* coef, void* sp, int32_t nitems, void* stream);
 // the device-side step counter of SrcStep: *ctr = value (add = 0) or *ctr += value (add = 1), one thread

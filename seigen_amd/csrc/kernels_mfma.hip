@@ -1291,8 +1291,8 @@ __global__ __launch_bounds__(512) void sponge_affine_mfma(const double* __restri
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, w = lane & 15;
-  // A unit of work is ONE velocity component of one item: 9 B rows, 9 + 9 accumulator values - about 60 registers, so six
-  // waves per SIMD hide the unit's two dependent load latencies (slots -> coefficients, rows) behind each other's matrix
+  // A unit of work is ONE velocity component of one item: 9 B rows, 9 + 9 accumulator values - 108 registers at degree 4, so
+  // four waves per SIMD hide the unit's two dependent load latencies (slots -> coefficients, rows) behind each other's matrix
   // work.  (A wave per whole item - 27 rows, 81 accumulators, two waves per SIMD - took 0.50 ms per launch for 48 000 items
   // whose matrix work is 0.07 ms; the same wave with the next item's operands requested ahead spilled and took 0.9 ms.)
   const long nunits = (long)nitems * 3;
@@ -1353,11 +1353,32 @@ __global__ __launch_bounds__(512) void sponge_affine_mfma(const double* __restri
   }
 }
 
+// blocks of eight waves the device holds of the degree's instantiation (asked from the runtime once: registers and the tiles'
+// LDS decide - two per CU at degree 4).  sg_set_absorption asks at set-up (prepare_...), i.e. outside any stream capture.
+static int sponge_affine_resident(int P) {
+  static int resident[5] = {0, 0, 0, 0, 0};
+  if (P < 1 || P > 4) return 0;
+  if (resident[P] == 0) {
+    int per_cu = 0, dev = 0, ncu = 0;
+    const void* k = P == 1 ? (const void*)sponge_affine_mfma<1> : P == 2 ? (const void*)sponge_affine_mfma<2>
+                  : P == 3 ? (const void*)sponge_affine_mfma<3> : (const void*)sponge_affine_mfma<4>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 512, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+    resident[P] = per_cu * ncu;
+  }
+  return resident[P];
+}
+int prepare_sponge_affine_mfma(int P) { return sponge_affine_resident(P) > 0 ? 0 : -1; }
+
 int launch_sponge_affine_mfma(int P, const void* uabs, const double* fragX, const int32_t* items, const int32_t* item_slots,
                               const double* coef, void* sp, int32_t nitems, void* stream) {
   if (nitems <= 0) return 0;
+  // a persistent grid of exactly the resident blocks: more would run a second, partly empty round
+  const int resident = sponge_affine_resident(P);
+  if (resident <= 0) return -1;
   long blocks = ((long)nitems * 3 + 7) / 8;
-  if (blocks > 768) blocks = 768;      // three resident blocks of eight waves per CU (42 KB of tiles each at degree 4)
+  if (blocks > resident) blocks = resident;
   const dim3 grid((unsigned)blocks), block(512);
   hipStream_t s = (hipStream_t)stream;
   switch (P) {
