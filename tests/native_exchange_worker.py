@@ -5,7 +5,7 @@ ncclSend / ncclRecv and SECOND launch) over the transport double tests/fake_rccl
 sharing the test box's one GPU.  The unique id travels through a file, as a host without a process group would do it.
 
 argv: out dir, world, first rank of this process, ranks in this process (threads), grid gx,gy,gz, mesh nx,ny,nz, degree,
-steps, dtype, scenario (plain | source | wrap)."""
+steps, dtype, scenario (plain | source | wrap | c3golden)."""
 import os
 import sys
 import threading
@@ -51,6 +51,28 @@ def setup_block(blk, n, degree, scenario):
     return dt
 
 
+def golden_digest(blk, part, n, gold_cells):
+    """What tests/golden/fullsize_c3.npz holds of a field, restricted to this block: the values at the golden's sampled cells
+    that lie in the block, and the block's contribution to the sums over every z-layer of cubes of the whole mesh."""
+    from seigen_amd import _lib
+    ax = [np.arange(part.start[a], part.start[a] + part.n[a]) for a in range(3)]
+    cube = (ax[0][None, None, :] + n[0] * (ax[1][None, :, None] + n[1] * ax[2][:, None, None])).reshape(-1)
+    gcell = (cube[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)          # global cell of every local cell, local order
+    order = np.argsort(gcell)
+    pos = np.searchsorted(gcell[order], gold_cells)
+    pos[pos >= gcell.size] = 0
+    mine = gcell[order][pos] == gold_cells
+    local = order[pos[mine]]
+    out = {"which": np.nonzero(mine)[0]}
+    per_layer = part.n[0] * part.n[1] * 6
+    for name, f in (("u", _lib.FIELD_U), ("s", _lib.FIELD_S), ("uh", _lib.FIELD_UH), ("sh", _lib.FIELD_SH)):
+        full = blk.get_field(f)
+        out[name] = full[local]
+        out[name + "_layers"] = full.reshape(part.n[2], per_layer, -1).sum(axis=1)      # local z-layers part.start[2] ..
+        del full
+    return out
+
+
 def run_rank(args, rank, failures):
     try:
         _run_rank(args, rank)
@@ -74,7 +96,23 @@ def _run_rank(args, rank):
         mask |= 0x30
     h = [1.0 / n[a] for a in range(3)]
     blk = HipBlock(3, degree, part.n, h, [0.0] * 3, "left", mask, dtype=dtype, cube0=list(part.start))
-    setup_block(blk, n, degree, scenario)
+    if scenario == "c3golden":
+        # BASELINE config 3's input (the 3-D eigenmode, tests/fullsize_cases.C3) on this rank's block of the 2 x 2 x 2 grid
+        import bench
+        from seigen_amd import BoxMesh
+        from tests import fullsize_cases as fc
+        c = fc.C3
+        mesh = BoxMesh(n[0], n[1], n[2], 1.0, 1.0, 1.0)
+        mesh.set_partition(part)
+        blk.set_params(c["rho"], c["dt"], c["lam"], c["mu"])
+
+        class Shim(object):
+            pass
+        sh = Shim()
+        sh.block, sh.mesh, sh.degree = blk, mesh, degree
+        bench.fill_initial_condition(sh, c["dt"])
+    else:
+        setup_block(blk, n, degree, scenario)
     # the unique id: rank 0 makes it, the others find it in the file
     idfile = os.path.join(out, "unique_id.bin")
     if rank == 0:
@@ -119,9 +157,16 @@ def _run_rank(args, rank):
     face_bytes = sum(blk.halo_bytes(_lib.FIELD_U, s) for s in range(6) if peers[s] is not None)
     assert st["exchanges"] == 1 + 6 * steps and st["bytes_sent"] == (1 + 6 * steps) * face_bytes, (st, face_bytes)
     assert c["steps"] == steps and all(v == 2 * steps for v in c["launches"])      # FIRST + SECOND of every stage
-    np.savez(os.path.join(out, "rank%d.npz" % rank), u=blk.get_field(_lib.FIELD_U), s=blk.get_field(_lib.FIELD_S),
-             uh=blk.get_field(_lib.FIELD_UH), start=np.array(part.start), n=np.array(part.n), selftest=bad,
-             exchanges=st["exchanges"], bytes_sent=st["bytes_sent"], nsides=nsides, version=version, **sent)
+    if scenario == "c3golden":      # the fields are 1.3 GB per rank: only what the golden holds of them leaves the worker
+        gold_cells = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_c3.npz"))["cells"]
+        dig = golden_digest(blk, part, n, gold_cells)
+        np.savez(os.path.join(out, "rank%d.npz" % rank), start=np.array(part.start), n=np.array(part.n), selftest=bad,
+                 exchanges=st["exchanges"], bytes_sent=st["bytes_sent"], nsides=nsides, version=version,
+                 **{"g_" + k: v for k, v in dig.items()})
+    else:
+        np.savez(os.path.join(out, "rank%d.npz" % rank), u=blk.get_field(_lib.FIELD_U), s=blk.get_field(_lib.FIELD_S),
+                 uh=blk.get_field(_lib.FIELD_UH), start=np.array(part.start), n=np.array(part.n), selftest=bad,
+                 exchanges=st["exchanges"], bytes_sent=st["bytes_sent"], nsides=nsides, version=version, **sent)
     blk.comm_finalize()
     blk.close()
 

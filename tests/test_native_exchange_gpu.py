@@ -124,6 +124,44 @@ def test_native_exchange_between_ranks_bitwise(gpu, fake, tmp_path, world, layou
         assert log["bytes_sent"] >= int(d["bytes_sent"]) > 0
 
 
+def test_config3_golden_through_the_native_exchange_on_eight_ranks(gpu, fake, tmp_path):
+    """Config 4's partition at production block widths, oracle-backed, through the exchange INSIDE the library: BASELINE
+    config 3's input (64^3 cubes x 6 tets, P4, the eigenmode) on the 2 x 2 x 2 grid of eight 32^3 blocks - eight ranks (two
+    per worker process), each with three neighbours, group-thick x shells, `T.n` ghost records on three sides - stepped by
+    one sg_step per rank over the transport double, against the ORACLE's golden of the unsplit mesh (tests/golden/
+    fullsize_c3.npz: sampled cells and slab sums of every field).  tests/test_multigpu_gpu.py checks the same partition
+    with device copies between blocks of one process; this is the path the first 8-GPU job takes."""
+    from tests import fullsize_cases as fc
+    c = fc.C3
+    N, world = c["n"], 8
+    _spawn_workers(fake, tmp_path, world, [2, 2, 2, 2], (2, 2, 2), (N, N, N), c["P"], c["steps"], "f64", "c3golden")
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_c3.npz"))
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    assert all(int(d["selftest"]) == 0 and int(d["nsides"]) == 3 for d in ranks)
+    tol = dict(u=1e-10, s=1e-10, sh=1e-9, uh=1e-7)
+    seen = np.zeros(len(gold["cells"]), dtype=int)
+    for d in ranks:
+        seen[d["g_which"]] += 1
+    assert (seen == 1).all(), "every sampled cell of the golden lies in exactly one block"
+    for name in ("u", "s", "uh", "sh"):
+        want, want_layers = gold[name], gold[name + "_layers"]
+        scale, lscale = np.abs(want).max(), np.abs(want_layers).max()
+        if name == "uh":      # the UH buffer holds w = dt u1 + dt^3/24 utemp (csrc/stages.cpp; tests/test_fullsize_oracle_gpu.py _compare)
+            dt, c3 = c["dt"], c["dt"] ** 3 / 24.0
+            scale = lscale = (dt * tol["u"] * np.abs(gold["u"]).max() + c3 * tol["uh"] * np.abs(gold["uh"]).max()) / tol["uh"]
+            want, want_layers = dt * gold["u"] + c3 * gold["uh"], dt * gold["u_layers"] + c3 * gold["uh_layers"]
+        got = np.empty_like(want)
+        layers = np.zeros_like(want_layers)
+        for d in ranks:
+            got[d["g_which"]] = d["g_" + name]
+            z0, nz = int(d["start"][2]), int(d["n"][2])
+            layers[z0:z0 + nz] += d["g_" + name + "_layers"].reshape(nz, -1)
+        assert np.isfinite(got).all() and scale > 0
+        err = np.abs(got - want).max() / scale
+        lerr = np.abs(layers - want_layers).max() / max(lscale, scale)
+        assert err < tol[name] and lerr < 30 * tol[name], (name, err, lerr)
+
+
 def test_two_faces_between_one_pair_of_ranks_pair_by_facing_side(gpu, fake, tmp_path):
     """Two blocks around a wrapped z axis: each rank's z- and z+ sides both lead to the other rank.  RCCL pairs the two
     messages of such a pair in posting order; side s must get what the peer sent from its side s ^ 1 (comm.cpp posts the
